@@ -1,0 +1,91 @@
+"""ctypes binding of libeonerf_hip.so (include/eonerf_hip.h).
+
+PyTorch is plumbing here: it owns device memory (tensor.data_ptr()) and the current HIP stream; every arithmetic
+step of the hot path runs inside the HIP library.  There is NO fallback: if the library is missing, cannot be
+loaded, or no GPU is present, the product path raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libeonerf_hip.so")
+
+EONERF_FP32, EONERF_BF16 = 0, 1
+F_SHADOWS, F_EVAL, F_TRAIN, F_ONLY_DEPTH = 1, 2, 4, 8
+
+SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy", "eonerf_param_tensors",
+           "eonerf_param_info", "eonerf_param_floats", "eonerf_set_weights", "eonerf_field_workspace_bytes",
+           "eonerf_render_workspace_bytes", "eonerf_field_forward", "eonerf_query_density", "eonerf_render_forward",
+           "eonerf_render_backward", "eonerf_adam_step"]
+
+
+class EonerfConfig(C.Structure):
+    _fields_ = [("n_images", C.c_int), ("precision", C.c_int), ("n_samples", C.c_int), ("radiometric", C.c_int)]
+
+
+def build(verbose=False):
+    """Compile libeonerf_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:])
+        print(r.stderr[-8000:])
+    if r.returncode:
+        raise RuntimeError("building libeonerf_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (building it is an explicit step: __graft_entry__.build() / eonerf_code_amd._lib.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the EO-NeRF hot path has no non-HIP fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i, sz, fp = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+    L.eonerf_version.restype = i
+    L.eonerf_strerror.restype = C.c_char_p
+    L.eonerf_strerror.argtypes = [i]
+    L.eonerf_create.argtypes = [C.POINTER(vp), C.POINTER(EonerfConfig)]
+    L.eonerf_destroy.argtypes = [vp]
+    L.eonerf_param_tensors.argtypes = [vp]
+    L.eonerf_param_info.argtypes = [vp, i, C.POINTER(C.c_char_p), C.POINTER(sz), C.POINTER(i), C.POINTER(i)]
+    L.eonerf_param_floats.restype = sz
+    L.eonerf_param_floats.argtypes = [vp]
+    L.eonerf_set_weights.argtypes = [vp, vp, vp]
+    L.eonerf_field_workspace_bytes.restype = sz
+    L.eonerf_field_workspace_bytes.argtypes = [vp, i]
+    L.eonerf_render_workspace_bytes.restype = sz
+    L.eonerf_render_workspace_bytes.argtypes = [vp, i, i]
+    L.eonerf_field_forward.argtypes = [vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.eonerf_query_density.argtypes = [vp, vp, vp, i, vp, vp, sz, vp]
+    L.eonerf_render_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
+    L.eonerf_render_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
+    L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp]
+    for name in SYMBOLS:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libeonerf_hip: {lib().eonerf_strerror(rc).decode()} (code {rc})")
+
+
+def param_layout(ctx):
+    """[(name, offset, rows, cols)] of the flat fp32 parameter buffer."""
+    L = lib()
+    out = []
+    for k in range(L.eonerf_param_tensors(ctx)):
+        name, off, r, c = C.c_char_p(), C.c_size_t(), C.c_int(), C.c_int()
+        check(L.eonerf_param_info(ctx, k, C.byref(name), C.byref(off), C.byref(r), C.byref(c)))
+        out.append((name.value.decode(), off.value, r.value, c.value))
+    return out

@@ -1,0 +1,369 @@
+// C-ABI entry points of libeonerf_hip.so (include/eonerf_hip.h).  Host logic only: parameter layout, packed weight
+// streams, workspace carving and kernel sequencing.  No device memory is allocated after eonerf_create.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/eonerf_hip.h"
+#include "eonerf_kernels.h"
+#include "eonerf_pack.h"
+#include "eonerf_rays.h"
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+namespace {
+
+struct DevStream {
+    uint8_t* data = nullptr; size_t bytes = 0;
+    ChunkDesc* chunks = nullptr; int n_chunks = 0;
+    PackEntry *e16 = nullptr, *e32 = nullptr; int n16 = 0, n32 = 0;
+};
+
+// bump allocator over the caller's workspace (256-byte aligned); with base == nullptr it only measures
+struct Carver {
+    uint8_t* base; size_t off = 0;
+    explicit Carver(void* b) : base(reinterpret_cast<uint8_t*>(b)) {}
+    template <class T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct PassBuffers {       // one MLP pass (camera or sun) over up to p_cap samples
+    int *counts, *offsets, *n_pts;
+    float *px, *py, *pz, *tmid, *delta, *sigma, *albedo, *ts, *tb;
+    int* simg;
+    void *act, *grd; uint32_t* masks;
+    float *g_sigma, *g_albedo, *g_ts, *g_tb, *g_emb, *g_pos;
+};
+
+struct RenderWs {
+    int *cnt_first, *cnt_retry, *flags;
+    float* ray_rec; float* g_ray;
+    PassBuffers cam, sun;
+    WgradJob* jobs;
+    size_t bytes;
+};
+
+}  // namespace
+
+struct eonerf_ctx {
+    eonerf_config cfg;
+    bool bf16;
+    int n_cu;
+    ParamLayout pl;
+    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens;
+    int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
+    bool weights_set = false;
+};
+
+namespace {
+
+int upload(DevStream& d, const PackedStream& s) {
+    d.bytes = s.bytes; d.n_chunks = (int)s.chunks.size(); d.n16 = (int)s.e16.size(); d.n32 = (int)s.e32.size();
+    HIP_TRY(hipMalloc(&d.data, s.bytes));
+    HIP_TRY(hipMemset(d.data, 0, s.bytes));
+    HIP_TRY(hipMalloc(&d.chunks, s.chunks.size() * sizeof(ChunkDesc)));
+    HIP_TRY(hipMemcpy(d.chunks, s.chunks.data(), s.chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
+    if (d.n16) {
+        HIP_TRY(hipMalloc(&d.e16, s.e16.size() * sizeof(PackEntry)));
+        HIP_TRY(hipMemcpy(d.e16, s.e16.data(), s.e16.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&d.e32, s.e32.size() * sizeof(PackEntry)));
+    HIP_TRY(hipMemcpy(d.e32, s.e32.data(), s.e32.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+    return 0;
+}
+void release(DevStream& d) {
+    if (d.data) (void)hipFree(d.data);
+    if (d.chunks) (void)hipFree(d.chunks);
+    if (d.e16) (void)hipFree(d.e16);
+    if (d.e32) (void)hipFree(d.e32);
+    d = DevStream();
+}
+
+__global__ void k_pack16(const float* flat, const PackEntry* e, int n, uint8_t* stream) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PackEntry pe = e[i];
+    const float v = pe.src < 0 ? 0.f : flat[pe.src];
+    *reinterpret_cast<__bf16*>(stream + pe.dst) = (__bf16)v;
+}
+__global__ void k_pack32(const float* flat, const PackEntry* e, int n, uint8_t* stream) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PackEntry pe = e[i];
+    *reinterpret_cast<float*>(stream + pe.dst) = pe.src < 0 ? 0.f : flat[pe.src];
+}
+int pack(const DevStream& d, const float* flat, hipStream_t st) {
+    if (d.n16) hipLaunchKernelGGL(k_pack16, dim3((d.n16 + 255) / 256), dim3(256), 0, st, flat, d.e16, d.n16, d.data);
+    hipLaunchKernelGGL(k_pack32, dim3((d.n32 + 255) / 256), dim3(256), 0, st, flat, d.e32, d.n32, d.data);
+    return (int)hipGetLastError();
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int p_cap_of(int n_rays) { return round_up(std::max(n_rays, 1) * 127, 256); }
+
+void carve_pass(Carver& c, PassBuffers& b, int n_rays, int p_cap, bool full, bool train, bool input_grad, int act_bytes) {
+    b.counts = c.take<int>(n_rays);
+    b.offsets = c.take<int>(n_rays + 1);
+    b.n_pts = c.take<int>(4);
+    b.px = c.take<float>(p_cap); b.py = c.take<float>(p_cap); b.pz = c.take<float>(p_cap);
+    b.tmid = c.take<float>(p_cap); b.delta = c.take<float>(p_cap);
+    b.simg = c.take<int>(p_cap);
+    b.sigma = c.take<float>(p_cap);
+    b.albedo = full ? c.take<float>(3 * (size_t)p_cap) : nullptr;
+    b.ts = full ? c.take<float>(p_cap) : nullptr;
+    b.tb = full ? c.take<float>(p_cap) : nullptr;
+    b.act = b.grd = nullptr; b.masks = nullptr;
+    b.g_sigma = b.g_albedo = b.g_ts = b.g_tb = b.g_emb = b.g_pos = nullptr;
+    if (train) {
+        b.act = c.take<uint8_t>((size_t)(full ? ACT_ROWS_FULL : ACT_ROWS_DENSITY) * p_cap * act_bytes);
+        b.grd = c.take<uint8_t>((size_t)(full ? GRD_ROWS_FULL : GRD_ROWS_DENSITY) * p_cap * act_bytes);
+        b.masks = c.take<uint32_t>((size_t)(full ? MASK_SLOTS_FULL : MASK_SLOTS_DENSITY) * p_cap * 8);
+        b.g_sigma = c.take<float>(p_cap);
+        if (full) {
+            b.g_albedo = c.take<float>(3 * (size_t)p_cap);
+            b.g_ts = c.take<float>(p_cap); b.g_tb = c.take<float>(p_cap);
+            b.g_emb = c.take<float>(4 * (size_t)p_cap);
+        }
+        if (input_grad) b.g_pos = c.take<float>(3 * (size_t)p_cap);
+    }
+}
+
+RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) {
+    Carver c(base);
+    RenderWs w;
+    const int p_cap = p_cap_of(n_rays);
+    const bool train = flags & EONERF_F_TRAIN, shadows = flags & EONERF_F_SHADOWS, od = flags & EONERF_F_ONLY_DEPTH;
+    const int ab = ctx->bf16 ? 2 : 4;
+    w.cnt_first = c.take<int>(n_rays); w.cnt_retry = c.take<int>(n_rays); w.flags = c.take<int>(4);
+    w.ray_rec = c.take<float>((size_t)n_rays * RAY_REC);
+    w.g_ray = train ? c.take<float>((size_t)n_rays * RAY_REC) : nullptr;
+    carve_pass(c, w.cam, n_rays, p_cap, !od, train, false, ab);
+    if (shadows && !od) carve_pass(c, w.sun, n_rays, p_cap, false, train, true, ab); else memset(&w.sun, 0, sizeof(w.sun));
+    w.jobs = train ? c.take<WgradJob>(64) : nullptr;
+    w.bytes = c.off + 256;
+    return w;
+}
+
+AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
+    const ParamLayout& pl = ctx->pl;
+    return AmbientW{flat + pl.t[pl.am1_w].offset, flat + pl.t[pl.am1_b].offset, flat + pl.t[pl.am2_w].offset, flat + pl.t[pl.am2_b].offset};
+}
+
+int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_cap, bool full, bool train, hipStream_t st) {
+    const DevStream& ds = full ? ctx->fwd_full : ctx->fwd_dens;
+    MlpFwdArgs a;
+    a.px = b.px; a.py = b.py; a.pz = b.pz; a.simg = b.simg;
+    a.emb = flat + ctx->pl.t[ctx->pl.emb].offset;
+    a.n_pts = b.n_pts; a.p_pad = p_cap;
+    a.stream = ds.data; a.chunks = ds.chunks; a.n_chunks = ds.n_chunks;
+    a.sigma = b.sigma; a.albedo = b.albedo; a.ts = b.ts; a.tb = b.tb;
+    a.act = b.act; a.masks = b.masks;
+    const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
+    const int grid = std::min(ctx->n_cu, p_cap / tile);
+    return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, train, grid, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int eonerf_version(void) { return EONERF_VERSION; }
+
+const char* eonerf_strerror(int code) {
+    switch (code) {
+        case EONERF_OK: return "ok";
+        case EONERF_E_ARG: return "eonerf: invalid argument";
+        case EONERF_E_WORKSPACE: return "eonerf: workspace too small";
+        case EONERF_E_STATE: return "eonerf: call sequence error (set_weights / train forward missing)";
+        case EONERF_E_UNSUPPORTED: return "eonerf: unsupported configuration";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "eonerf: unknown error";
+    }
+}
+
+int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
+    if (!out || !cfg || cfg->n_images < 1) return EONERF_E_ARG;
+    if (cfg->n_samples != 128) return EONERF_E_UNSUPPORTED;
+    if (cfg->precision != EONERF_FP32 && cfg->precision != EONERF_BF16) return EONERF_E_ARG;
+    eonerf_ctx* ctx = new (std::nothrow) eonerf_ctx();
+    if (!ctx) return EONERF_E_ARG;
+    ctx->cfg = *cfg;
+    ctx->bf16 = cfg->precision == EONERF_BF16;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete ctx; return (int)hipErrorNoDevice; }
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->pl.build(cfg->n_images);
+    int rc = upload(ctx->fwd_full, build_fwd_stream(ctx->pl, ctx->bf16, true));
+    if (!rc) rc = upload(ctx->fwd_dens, build_fwd_stream(ctx->pl, ctx->bf16, false));
+    if (!rc) rc = upload(ctx->bwd_full, build_bwd_stream(ctx->pl, ctx->bf16, true, false));
+    if (!rc) rc = upload(ctx->bwd_dens, build_bwd_stream(ctx->pl, ctx->bf16, false, true));
+    if (!rc) {
+        int cm[64];
+        for (int s = 0; s < 64; ++s) cm[s] = enc_col_of_slot(ctx->bf16, s);
+        rc = (int)hipMalloc(&ctx->enc_colmap, sizeof(cm));
+        if (!rc) rc = (int)hipMemcpy(ctx->enc_colmap, cm, sizeof(cm), hipMemcpyHostToDevice);
+    }
+    if (rc) { eonerf_destroy(ctx); return rc; }
+    *out = ctx;
+    return EONERF_OK;
+}
+
+int eonerf_destroy(eonerf_ctx* ctx) {
+    if (!ctx) return EONERF_E_ARG;
+    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens);
+    if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
+    delete ctx;
+    return EONERF_OK;
+}
+
+int eonerf_param_tensors(const eonerf_ctx* ctx) { return ctx ? (int)ctx->pl.t.size() : 0; }
+size_t eonerf_param_floats(const eonerf_ctx* ctx) { return ctx ? ctx->pl.total : 0; }
+int eonerf_param_info(const eonerf_ctx* ctx, int index, const char** name, size_t* offset, int* rows, int* cols) {
+    if (!ctx || index < 0 || index >= (int)ctx->pl.t.size()) return EONERF_E_ARG;
+    const ParamInfo& p = ctx->pl.t[index];
+    if (name) *name = p.name.c_str();
+    if (offset) *offset = p.offset;
+    if (rows) *rows = p.rows;
+    if (cols) *cols = p.cols;
+    return EONERF_OK;
+}
+
+int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
+    if (!ctx || !flat) return EONERF_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = pack(ctx->fwd_full, flat, st);
+    if (!rc) rc = pack(ctx->fwd_dens, flat, st);
+    if (!rc) rc = pack(ctx->bwd_full, flat, st);
+    if (!rc) rc = pack(ctx->bwd_dens, flat, st);
+    if (!rc) ctx->weights_set = true;
+    return rc;
+}
+
+size_t eonerf_field_workspace_bytes(const eonerf_ctx* ctx, int n_points) {
+    if (!ctx || n_points < 0) return 0;
+    Carver c(nullptr);
+    PassBuffers b;
+    carve_pass(c, b, 1, round_up(std::max(n_points, 1), 256), true, false, false, ctx->bf16 ? 2 : 4);
+    return c.off + 256;
+}
+
+size_t eonerf_render_workspace_bytes(const eonerf_ctx* ctx, int n_rays, int flags) {
+    if (!ctx || n_rays < 0) return 0;
+    return carve_render(ctx, nullptr, n_rays, flags).bytes;
+}
+
+static int field_common(eonerf_ctx* ctx, const float* flat, const float* xyz, const int64_t* img, int n, bool full,
+                        void* ws, size_t ws_bytes, PassBuffers& b, int& p_cap, hipStream_t st) {
+    if (!ctx || !xyz || n < 0 || !ws) return EONERF_E_ARG;
+    if (!ctx->weights_set) return EONERF_E_STATE;
+    if (ws_bytes < eonerf_field_workspace_bytes(ctx, n)) return EONERF_E_WORKSPACE;
+    p_cap = round_up(std::max(n, 1), 256);
+    Carver c(ws);
+    carve_pass(c, b, 1, p_cap, true, false, false, ctx->bf16 ? 2 : 4);
+    HIP_TRY(eo_launch_points_to_soa(xyz, img, n, p_cap, b.px, b.py, b.pz, b.simg, b.n_pts, st));
+    return run_mlp_fwd(ctx, b, flat, p_cap, full, false, st);
+}
+
+int eonerf_field_forward(eonerf_ctx* ctx, const float* flat, const float* xyz, const float* sun, const int64_t* img, int n,
+                         float* sigma, float* albedo, float* ambient, float* ts, float* tb,
+                         void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!sun || !img || !sigma || !albedo || !ambient || !ts || !tb || !flat) return EONERF_E_ARG;
+    if (n == 0) return EONERF_OK;
+    PassBuffers b; int p_cap;
+    int rc = field_common(ctx, flat, xyz, img, n, true, ws, ws_bytes, b, p_cap, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(sigma, b.sigma, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts, b.ts, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(tb, b.tb, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(eo_launch_soa3_to_aos(b.albedo, p_cap, n, albedo, st));
+    return (int)eo_launch_ambient_points(ambient_w(ctx, flat), sun, n, ambient, st);
+}
+
+int eonerf_query_density(eonerf_ctx* ctx, const float* flat, const float* xyz, int n, float* sigma, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!sigma || !flat) return EONERF_E_ARG;
+    if (n == 0) return EONERF_OK;
+    PassBuffers b; int p_cap;
+    int rc = field_common(ctx, flat, xyz, nullptr, n, false, ws, ws_bytes, b, p_cap, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(sigma, b.sigma, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return EONERF_OK;
+}
+
+int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
+                          const float* zsteps, const float* u_cam, const float* u_retry, const float* u_sun,
+                          int n_rays, int flags, float* out, int* n_samples_dev,
+                          void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx || !flat || !rays || !img_idx || !zsteps || !u_cam || !out || n_rays < 0 || !ws) return EONERF_E_ARG;
+    if (!ctx->weights_set) return EONERF_E_STATE;
+    if (n_rays == 0) return EONERF_OK;
+    const bool shadows = (flags & EONERF_F_SHADOWS) && !(flags & EONERF_F_ONLY_DEPTH);
+    const bool train = flags & EONERF_F_TRAIN, od = flags & EONERF_F_ONLY_DEPTH;
+    if (shadows && !u_sun) return EONERF_E_ARG;
+    if (train && od) return EONERF_E_UNSUPPORTED;
+    RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    const int p_cap = p_cap_of(n_rays);
+    HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * sizeof(int), st));
+
+    // ---- camera pass: sample -> field -> composite -------------------------------------------------------
+    SampleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.rays = rays; sa.img_idx = img_idx; sa.zsteps = zsteps; sa.u = u_cam; sa.u_retry = u_retry;
+    sa.n_rays = n_rays; sa.sun_pass = 0; sa.patch_last = 1;
+    sa.cnt_first = w.cnt_first; sa.cnt_retry = w.cnt_retry; sa.counts = w.cam.counts; sa.offsets = w.cam.offsets;
+    sa.flags = w.flags; sa.n_pts = w.cam.n_pts;
+    sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
+    HIP_TRY(eo_launch_sampler(sa, st));
+    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !od, train, st);
+    if (rc) return rc;
+    CompositeArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.rays = rays; ca.offsets = w.cam.offsets; ca.counts = w.cam.counts;
+    ca.sigma = w.cam.sigma; ca.delta = w.cam.delta; ca.tmid = w.cam.tmid; ca.albedo = w.cam.albedo; ca.ts = w.cam.ts; ca.tb = w.cam.tb;
+    ca.p_pad = p_cap; ca.n_rays = n_rays; ca.shadow_only = 0; ca.depth_only = od ? 1 : 0;
+    ca.amb = ambient_w(ctx, flat); ca.ray_out = w.ray_rec;
+    HIP_TRY(eo_launch_composite_fwd(ca, st));
+
+    // ---- sun pass: shadow rays from the rendered surface toward the sun -----------------------------------
+    if (shadows) {
+        SampleArgs ss = sa;
+        ss.img_idx = nullptr; ss.u = u_sun; ss.u_retry = nullptr;
+        ss.depth = w.ray_rec + RR_DEPTH; ss.depth_stride = RAY_REC; ss.sun_pass = 1; ss.patch_last = 0;
+        ss.cnt_first = w.sun.counts; ss.cnt_retry = w.cnt_retry; ss.counts = w.sun.counts; ss.offsets = w.sun.offsets;
+        ss.n_pts = w.sun.n_pts;
+        ss.px = w.sun.px; ss.py = w.sun.py; ss.pz = w.sun.pz; ss.tmid = w.sun.tmid; ss.delta = w.sun.delta; ss.simg = w.sun.simg;
+        HIP_TRY(eo_launch_sampler(ss, st));
+        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train, st);
+        if (rc) return rc;
+        CompositeArgs cs = ca;
+        cs.offsets = w.sun.offsets; cs.counts = w.sun.counts; cs.sigma = w.sun.sigma; cs.delta = w.sun.delta; cs.tmid = w.sun.tmid;
+        cs.shadow_only = 1; cs.depth_only = 0;
+        HIP_TRY(eo_launch_composite_fwd(cs, st));
+    }
+
+    // ---- irradiance model + radiometric affine + packing ---------------------------------------------------
+    ShadeArgs sh;
+    sh.ray_rec = w.ray_rec; sh.img_idx = img_idx;
+    sh.radiometric = ctx->cfg.radiometric ? flat + ctx->pl.t[ctx->pl.rad].offset : nullptr;
+    sh.pts_first = w.cnt_first; sh.sc_counts = shadows ? w.sun.counts : w.cnt_first;
+    sh.n_rays = n_rays; sh.use_shadow = shadows ? 1 : 0; sh.eval = (flags & EONERF_F_EVAL) ? 1 : 0; sh.out = out;
+    HIP_TRY(eo_launch_shade_fwd(sh, st));
+    if (n_samples_dev) HIP_TRY(hipMemcpyAsync(n_samples_dev, w.cam.n_pts, sizeof(int), hipMemcpyDeviceToDevice, st));
+
+    return EONERF_OK;
+}
+
+int eonerf_render_backward(eonerf_ctx*, const float*, const float*, const int64_t*, int, int, const float*, float*, void*, size_t, void*) { return EONERF_E_UNSUPPORTED; }
+int eonerf_adam_step(eonerf_ctx*, float*, const float*, float*, float*, int, float, float, float, float, float, void*) { return EONERF_E_UNSUPPORTED; }
+
+}  // extern "C"
+

@@ -1,0 +1,196 @@
+// Common device-side definitions for the EO-NeRF HIP path (gfx950 / CDNA4 only).
+//
+// Layout vocabulary used by every kernel in this directory
+//   sample  : one (ray, interval) pair that survived the cube filter (sat_rendering.py:79-82); samples of a
+//             ray are contiguous, rays are in batch order -> "compact" index p in [0, n_pts).
+//   tile    : P::TILE consecutive samples handled by one workgroup; one wave owns 32 of them, sample = lane&31.
+//   H^T     : activations are kept TRANSPOSED in registers: MFMA rows = features, MFMA columns (lanes) = samples,
+//             so layer l+1 = W_l (A operand, streamed through LDS) x H_l^T (B operand, straight from the
+//             previous accumulators: no LDS round trip, no lane movement).
+//   k-group : the features covered by one 1-KiB A-operand read (ds_read_b128 per lane): 16 features for bf16
+//             (one v_mfma_f32_32x32x16_bf16), 8 features for fp32 (four v_mfma_f32_32x32x2_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define EO_DEV __device__ __forceinline__
+
+// row of the 32x32 accumulator tile held in register r by a lane of half h (cdna guide, C/D map)
+EO_DEV constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------
+// Precision policies
+// ------------------------------------------------------------------------------------------------
+struct PBf16 {
+    static constexpr bool IS_BF16 = true;
+    static constexpr int WAVES = 8, NT = 512, TILE = 256;
+    static constexpr int KF = 16;            // features per k-group
+    static constexpr int KG32 = 2;           // k-groups per 32 features
+    static constexpr int NE = 8;             // elements per lane per k-group
+    typedef bf16x8 U;                        // per-lane operand unit (A or B) of one k-group
+    typedef __bf16 act_t;                    // storage type of saved activations / gradients
+    static constexpr int ACT_BYTES = 2;
+    __host__ __device__ static constexpr int feat(int kg, int h, int e) { return 16 * kg + 8 * (e >> 2) + 4 * h + (e & 3); }
+    EO_DEV static f32x16 mma(const U& a, const U& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    EO_DEV static U zero() { U u; for (int i = 0; i < 8; ++i) u[i] = (__bf16)0.0f; return u; }
+};
+
+struct PF32 {
+    static constexpr bool IS_BF16 = false;
+    static constexpr int WAVES = 4, NT = 256, TILE = 128;
+    static constexpr int KF = 8;
+    static constexpr int KG32 = 4;
+    static constexpr int NE = 4;
+    typedef f32x4 U;
+    typedef float act_t;
+    static constexpr int ACT_BYTES = 4;
+    __host__ __device__ static constexpr int feat(int kg, int h, int e) { return 8 * kg + 4 * h + e; }
+    EO_DEV static f32x16 mma(const U& a, const U& b, f32x16 c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+    EO_DEV static U zero() { U u = {0.f, 0.f, 0.f, 0.f}; return u; }
+};
+
+// accumulator tile -> the KG32 B-operand units of the next layer (same feature order, no permutation)
+template <class P> struct Units32 { typename P::U u[P::KG32]; };
+
+EO_DEV Units32<PBf16> pack_units(PBf16, const f32x16& v) {
+    Units32<PBf16> o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.u[s][j] = (__bf16)v[8 * s + j];
+    return o;
+}
+EO_DEV Units32<PF32> pack_units(PF32, const f32x16& v) {
+    Units32<PF32> o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.u[q][e] = v[4 * q + e];
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight stream: packed chunks (built by eonerf_pack.cpp) are double-buffered through LDS.
+// chunk = G m-tiles; per m-tile KG x 1 KiB A units in fragment order, then G x 128 B of fp32 bias.
+// ------------------------------------------------------------------------------------------------
+struct ChunkDesc { uint32_t off, bytes; };
+
+template <class P, int SLOT_BYTES> struct WStream {
+    const uint8_t* g;            // packed stream (global)
+    const ChunkDesc* tab;        // chunk table (global, read through the scalar cache)
+    uint8_t* lds;                // 2 * SLOT_BYTES
+    int n_chunks;
+    int q;                       // index (in tab) of the chunk currently resident / being consumed
+    uint32_t par;                // slot parity of the resident chunk
+    int tid;
+
+    EO_DEV void issue(int qi, uint32_t slot) {
+        const ChunkDesc d = tab[qi];
+        const uint8_t* src = g + d.off;
+        uint8_t* dst = lds + slot * SLOT_BYTES;
+        const int wave_off = (tid & ~63) * 16;
+        for (uint32_t base = 0; base < d.bytes; base += P::NT * 16) {
+            uint32_t o = base + tid * 16;
+            if (o < d.bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + o),
+                                                 (__attribute__((address_space(3))) void*)(dst + base + wave_off), 16, 0, 0);
+        }
+    }
+    // first chunk of the launch
+    EO_DEV void start() {
+        q = 0; par = 0;
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // call before computing on the resident chunk: prefetch its successor into the other slot
+    EO_DEV void prefetch_next() {
+        int nq = q + 1; if (nq == n_chunks) nq = 0;
+        issue(nq, par ^ 1);
+    }
+    // call after computing on the resident chunk
+    EO_DEV void advance() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        q = q + 1; if (q == n_chunks) q = 0;
+        par ^= 1;
+    }
+    EO_DEV const uint8_t* cur() const { return lds + par * SLOT_BYTES; }
+};
+
+template <class P> EO_DEV typename P::U lds_unit(const uint8_t* p) {
+    return *reinterpret_cast<const typename P::U*>(p);   // 16 B per lane -> ds_read_b128
+}
+
+// acc tile initialised with the 32 bias values of its m-tile (bias region of the chunk, fp32)
+EO_DEV f32x16 bias_init(const uint8_t* bias32, int h) {
+    f32x16 acc;
+    const float* b = reinterpret_cast<const float*>(bias32);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(b + 8 * qd + 4 * h);
+        acc[4 * qd + 0] = v[0]; acc[4 * qd + 1] = v[1]; acc[4 * qd + 2] = v[2]; acc[4 * qd + 3] = v[3];
+    }
+    return acc;
+}
+EO_DEV f32x16 zero_acc() { f32x16 a; for (int i = 0; i < 16; ++i) a[i] = 0.f; return a; }
+
+// One chunk group of a layer:  for g in [0,G):  acc = bias + sum_kg A[g][kg] * B[kg];  epi(m0+g, acc)
+template <class P, int KG, int G, bool BIAS, class BArr, class Epi>
+EO_DEV void chunk_compute(const uint8_t* chunk, int lane, int h, const BArr& B, int m0, Epi&& epi) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        f32x16 acc = BIAS ? bias_init(chunk + G * KG * 1024 + g * 128, h) : zero_acc();
+        const uint8_t* a = chunk + g * KG * 1024 + lane * 16;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) acc = P::mma(lds_unit<P>(a + kg * 1024), B(kg), acc);
+        epi(m0 + g, acc);
+    }
+}
+
+// A whole layer: MT m-tiles in MT/G chunks.
+template <class P, int SLOT, int KG, int MT, int G, bool BIAS, class BArr, class Epi>
+EO_DEV void run_layer(WStream<P, SLOT>& ws, int lane, int h, const BArr& B, Epi&& epi) {
+    static_assert(MT % G == 0, "G must divide MT");
+    static_assert(G * (KG * 1024 + 128) <= SLOT, "chunk does not fit the LDS slot");
+#pragma unroll
+    for (int mg = 0; mg < MT / G; ++mg) {
+        ws.prefetch_next();
+        chunk_compute<P, KG, G, BIAS>(ws.cur(), lane, h, B, mg * G, epi);
+        ws.advance();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Activation functions (PyTorch semantics: Softplus beta=1 threshold=20; Sigmoid)
+// ------------------------------------------------------------------------------------------------
+EO_DEV float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+EO_DEV float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// Positional-encoding slots (radiance_fields/mlp.py:190-208, L=10): 64 slots, 32 per lane half.
+//   half 0, q<30 : sin(2^(q/3) * x[q%3])          q=30: x   q=31: y
+//   half 1, q<30 : sin(2^(q/3) * x[q%3] + pi/2)   q=30: z   q=31: 0 (pad)
+// q = kg*NE + e.  The packer maps slot -> reference encoding column with enc_col_of_slot().
+// ------------------------------------------------------------------------------------------------
+constexpr int ENC_SLOTS = 64;
+__host__ __device__ constexpr int enc_col_of_hq(int h, int q) {
+    return q < 30 ? (h ? 33 + q : 3 + q) : (q == 30 ? (h ? 2 : 0) : (h ? -1 : 1));
+}
+
+#define EO_PI_2_F 1.57079637050628662109375f   // fp32(0.5*math.pi), mlp.py:203

@@ -1,0 +1,92 @@
+// Host<->kernel argument blocks and layout constants shared by the launchers (eonerf_api.cpp) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "eonerf_common.h"
+
+// ---- rows of the saved-activation slab [ACT_ROWS][p_pad] (feature-major, see eonerf_mlp_fwd.hip) ----
+constexpr int ACT_ROW_ENC = 0;        // 64 encoding slots (slot order, see enc_col_of_hq)
+constexpr int ACT_ROW_X1 = 64;        // X1..X8 : outputs of trunk layers 0..7, 256 rows each
+constexpr int ACT_ROW_BOTT = 64 + 8 * 256;          // 2112
+constexpr int ACT_ROW_A1 = ACT_ROW_BOTT + 256;      // 2368, albedo hidden (128)
+constexpr int ACT_ROW_T1 = ACT_ROW_A1 + 128;        // 2496, transient hidden T1..T4 (4 x 128)
+constexpr int ACT_ROW_EMB = ACT_ROW_T1 + 512;       // 3008, transient embedding rows (8 used, 4 real)
+constexpr int ACT_ROWS_FULL = ACT_ROW_EMB + 32;     // 3040
+constexpr int ACT_ROWS_DENSITY = ACT_ROW_BOTT;      // 2112 (trunk only)
+
+// ---- rows of the saved-gradient slab [GRD_ROWS][p_pad] written by the backward chain ----
+constexpr int GRD_ROW_Y0 = 0;                       // dY of trunk layers 0..7 (pre-activation grads), 256 rows each
+constexpr int GRD_ROW_BOTT = 8 * 256;               // 2048: d bottleneck (256)
+constexpr int GRD_ROW_SIG = GRD_ROW_BOTT + 256;     // 2304: d sigma_pre (1 row used of 32)
+constexpr int GRD_ROW_A1 = GRD_ROW_SIG + 32;        // 2336: dY albedo hidden (128)
+constexpr int GRD_ROW_A2 = GRD_ROW_A1 + 128;        // 2464: d albedo_pre (3 rows used of 32)
+constexpr int GRD_ROW_T1 = GRD_ROW_A2 + 32;         // 2496: dY T1..T4 (4 x 128)
+constexpr int GRD_ROW_T5 = GRD_ROW_T1 + 512;        // 3008: d {ts_pre, tb_pre} (2 rows used of 32)
+constexpr int GRD_ROWS_FULL = GRD_ROW_T5 + 32;      // 3040
+constexpr int GRD_ROWS_DENSITY = GRD_ROW_SIG + 32;  // 2336
+
+constexpr int MASK_SLOTS_FULL = 13;                 // trunk 0..7, A1, T1..T4
+constexpr int MASK_SLOTS_DENSITY = 8;
+
+// LDS slot (one packed weight chunk) and chunk grouping
+template <class P> struct FwdSlot { static constexpr int KG_TARGET = P::IS_BF16 ? 20 : 40; static constexpr int BYTES = KG_TARGET * 1024 + 1024; };
+template <class P, int KG, int MT> struct FwdG {
+    static constexpr int pick() {
+        int best = 1;
+        for (int g = 1; g <= MT; ++g) if (MT % g == 0 && g * KG <= FwdSlot<P>::KG_TARGET && g <= 8) best = g;
+        return best;
+    }
+    static constexpr int G = pick();
+};
+__host__ __device__ constexpr int pick_group(bool bf16, int kg, int mt) {
+    int best = 1;
+    const int target = bf16 ? 20 : 40;
+    for (int g = 1; g <= mt; ++g) if (mt % g == 0 && g * kg <= target && g <= 8) best = g;
+    return best;
+}
+
+struct MlpFwdArgs {
+    const float *px, *py, *pz;     // [p_pad] compact sample positions (SoA)
+    const int* simg;               // [p_pad] image index of each sample (transient embedding row)
+    const float* emb;              // [n_img][4] transient_encoder.weight (fp32, read from the flat parameter buffer)
+    const int* n_pts;              // device scalar: number of live samples
+    int p_pad;                     // leading dimension of every per-sample array (multiple of 256)
+    const uint8_t* stream;         // packed weight stream of this kernel variant
+    const ChunkDesc* chunks;
+    int n_chunks;
+    float *sigma, *albedo, *ts, *tb;   // outputs: sigma[p_pad], albedo[3][p_pad], ts[p_pad], tb[p_pad]
+    void* act;                     // TRAIN: [ACT_ROWS][p_pad] of P::act_t
+    uint32_t* masks;               // TRAIN: [MASK_SLOTS][p_pad][2][4] ReLU masks
+};
+
+struct MlpBwdArgs {
+    const int* n_pts;
+    int p_pad;
+    const uint8_t* stream;
+    const ChunkDesc* chunks;
+    int n_chunks;
+    const float *sigma, *albedo, *ts, *tb;      // forward outputs (activation derivatives)
+    const float *g_sigma, *g_albedo, *g_ts, *g_tb;   // upstream grads per sample (same SoA shapes)
+    const uint32_t* masks;
+    void* grd;                     // [GRD_ROWS][p_pad] of P::act_t (A operand of the weight-gradient GEMM)
+    float* g_emb;                  // FULL: [p_pad][4] grad wrt the per-sample transient embedding
+    const float *px, *py, *pz;     // INPUT_GRAD: positions (encoder derivative)
+    float* g_pos;                  // INPUT_GRAD: [3][p_pad]
+};
+
+// One weight-gradient GEMM job:  dW[m][col_map[n]] += sum_p  dY^T[m][p] * X^T[n][p]
+struct WgradJob {
+    const void* a;        // dY^T rows (leading dimension p_pad)
+    const void* b;        // X^T rows
+    float* dw;            // destination inside the flat gradient buffer
+    float* db;            // bias gradient or nullptr
+    const int* col_map;   // nullptr = identity; -1 entries are dropped
+    int m_rows, n_rows;   // valid rows of a / b
+    int dw_ld;            // row stride of dw
+    int gm, gn, wm, wn;   // wave grid and tiles per wave: (gm*wm*32) x (gn*wn*32) >= m_rows x n_rows
+    int wg_begin, wg_count;   // workgroups [wg_begin, wg_begin+wg_count) split the sample range
+};
+
+hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, bool train, int grid, hipStream_t st);
+hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, int grid, hipStream_t st);
+hipError_t eo_launch_wgrad(const WgradJob* jobs_dev, int n_wg, const int* n_pts, int p_pad, bool bf16, hipStream_t st);

@@ -1,0 +1,254 @@
+// Fused EO-NeRF field forward (H4+H5+H6 of SURVEY.md 8a):
+//   positional encoding -> 8x256 trunk (skip-concat after layer 4) -> sigma | bottleneck -> albedo head,
+//   transient head (radiance_fields/eonerf.py:154-170, radiance_fields/mlp.py:87-101,190-208).
+// One persistent workgroup walks tiles of P::TILE samples.  Activations never leave registers (transposed
+// H^T chain, see eonerf_common.h); weights stream L2 -> LDS in packed fragment order (eonerf_pack.cpp).
+// TRAIN additionally saves, per layer, the post-activation tensor feature-major [F][P_pad] (the B operand
+// of the weight-gradient GEMM) and 1 bit/element ReLU masks (for the backward chain).
+#include "eonerf_common.h"
+#include "eonerf_kernels.h"
+
+namespace {
+
+template <class P> struct EncUnits { typename P::U u[ENC_SLOTS / P::KF]; };
+
+template <class P>
+EO_DEV EncUnits<P> encode_position(float x, float y, float z, int h) {
+    EncUnits<P> E;
+    const float off = h ? EO_PI_2_F : 0.0f;
+    constexpr int NU = ENC_SLOTS / P::KF;
+#pragma unroll
+    for (int kg = 0; kg < NU; ++kg)
+#pragma unroll
+        for (int e = 0; e < P::NE; ++e) {
+            const int q = kg * P::NE + e;
+            float v;
+            if (q < 30) {
+                const int k = q / 3, d = q % 3;
+                const float c = d == 0 ? x : (d == 1 ? y : z);
+                const float arg = c * (float)(1 << k) + off;     // exact scale, one fp32 add (mlp.py:199-203)
+                v = P::IS_BF16 ? __sinf(arg) : sinf(arg);
+            } else if (q == 30) {
+                v = h ? z : x;
+            } else {
+                v = h ? 0.0f : y;
+            }
+            if constexpr (P::IS_BF16) E.u[kg][e] = (__bf16)v; else E.u[kg][e] = v;
+        }
+    return E;
+}
+
+// ---- saving activations feature-major for the weight-gradient GEMM ---------------------------------------
+// All saves go through buffer stores: SGPR descriptor of the 32-row tile + scalar row offset + one per-lane
+// voffset that is constant for the whole sample tile (no 64-bit per-store address arithmetic in VGPRs).
+template <class P> EO_DEV __amdgpu_buffer_rsrc_t tile_rsrc(void* slab, size_t ld, int row0, int rows) {
+    uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)row0 * ld * P::ACT_BYTES;
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows * ld * P::ACT_BYTES), 0x00020000);
+}
+// per-lane byte offset inside a 32-row tile: fp32 -> (4h, p);  bf16 -> (4h + (p&1), p & ~1)  (see below)
+template <class P> EO_DEV int tile_voff(size_t ld, int p, int h) {
+    if constexpr (P::IS_BF16) return (int)(((size_t)(4 * h + (p & 1)) * ld + (p & ~1)) * 2);
+    else return (int)(((size_t)(4 * h) * ld + p) * 4);
+}
+// fp32: lane (c,h) stores its value for sample c: 32 lanes -> 128 B contiguous per feature row.
+EO_DEV void store_tile_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int, const Units32<PF32>& u) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u.u[r >> 2][r & 3]), rs, voff,
+                                              acc_row(r, 0) * ld * 4, 0);
+}
+// bf16: packed word i holds features (f, f+1) of sample c.  A quad_perm swap with the neighbour lane turns
+// that into (f; samples c,c+1) on even lanes and (f+1; samples c-1,c) on odd lanes: one dword store,
+// 16 lanes -> 64 B contiguous per feature row.
+EO_DEV void store_tile_T(PBf16, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int odd, const Units32<PBf16>& u) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32x4 words = __builtin_bit_cast(u32x4, u.u[i >> 2]);
+        const uint32_t w = words[i & 3];
+        const uint32_t nb = __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);          // lane ^ 1
+        // even: {own.lo, nb.lo}   odd: {nb.hi, own.hi}   (v_perm_b32 bytes: src0=w -> 4..7, src1=nb -> 0..3)
+        const uint32_t o = odd ? __builtin_amdgcn_perm(w, nb, 0x07060302) : __builtin_amdgcn_perm(w, nb, 0x01000504);
+        __builtin_amdgcn_raw_buffer_store_b32(o, rs, voff, acc_row(2 * i, 0) * ld * 2, 0);
+    }
+}
+// single element per lane (encoding / embedding rows): row = row_in_tile (+4h via voff1)
+EO_DEV void store_elem_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff1, int row, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff1, row * ld * 4, 0);
+}
+EO_DEV void store_elem_T(PBf16, __amdgpu_buffer_rsrc_t rs, int ld, int voff1, int row, __bf16 v) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rs, voff1, row * ld * 2, 0);
+}
+
+template <class P, bool FULL, bool TRAIN>
+__global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
+    constexpr int SLOT = FwdSlot<P>::BYTES;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typedef typename P::U U;
+    constexpr int HKG = 256 / P::KF;      // k-groups of a 256-wide activation
+    constexpr int QKG = 128 / P::KF;      // ... of a 128-wide activation
+    constexpr int EKG = ENC_SLOTS / P::KF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int n_pts = *a.n_pts;
+    const size_t ld = a.p_pad;
+
+    WStream<P, SLOT> ws;
+    ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks; ws.tid = tid;
+    if ((int)blockIdx.x * P::TILE >= n_pts) return;      // uniform per workgroup
+    ws.start();
+
+    for (int tile = blockIdx.x; tile * P::TILE < n_pts; tile += gridDim.x) {
+        const int p = tile * P::TILE + wave * 32 + c;          // this lane's sample (both halves share it)
+        const bool live = p < n_pts;
+        const float x = live ? a.px[p] : 0.f, y = live ? a.py[p] : 0.f, z = live ? a.pz[p] : 0.f;
+        const EncUnits<P> E = encode_position<P>(x, y, z, h);
+        const int ldi = a.p_pad;
+        const int voff = tile_voff<P>(ld, p, h);                       // 32-row tiles
+        const int voff1 = (int)(((size_t)(4 * h) * ld + p) * P::ACT_BYTES);   // one element per lane
+        if constexpr (TRAIN) {   // encoding slots, rows [0,64) of the activation slab
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc<P>(a.act, ld, ACT_ROW_ENC, 64);
+#pragma unroll
+            for (int kg = 0; kg < EKG; ++kg)
+#pragma unroll
+                for (int e = 0; e < P::NE; ++e) store_elem_T(P(), rs, ldi, voff1, P::feat(kg, 0, e), E.u[kg][e]);
+        }
+
+        U H[HKG], N[HKG];
+        uint32_t mbits[4];
+
+        // ---------------- trunk ----------------
+        auto relu_epi = [&](auto& dst, int act_row, int mt, const f32x16& accv) {
+            f32x16 v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(accv[r], 0.f);
+            Units32<P> u = pack_units(P(), v);
+#pragma unroll
+            for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
+            if constexpr (TRAIN) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m |= (accv[r] > 0.f) ? (1u << r) : 0u;
+                if (mt & 1) mbits[mt >> 1] |= m << 16; else mbits[mt >> 1] = m;
+                store_tile_T(P(), tile_rsrc<P>(a.act, ld, act_row + 32 * mt, 32), ldi, voff, p & 1, u);
+            }
+        };
+        auto save_mask = [&](int mask_slot, int nwords) {
+            if constexpr (TRAIN) {
+                uint32_t* mp = a.masks + ((size_t)mask_slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4;
+                if (nwords == 4) *reinterpret_cast<u32x4*>(mp) = u32x4{mbits[0], mbits[1], mbits[2], mbits[3]};
+                else *reinterpret_cast<u32x2*>(mp) = u32x2{mbits[0], mbits[1]};
+            }
+        };
+        auto plain_layer = [&](auto& src, auto& dst, int l) {
+            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, true>(ws, lane, h, [&](int kg) { return src[kg]; },
+                [&](int mt, const f32x16& v) { relu_epi(dst, ACT_ROW_X1 + 256 * l, mt, v); });
+            save_mask(l, 4);
+        };
+
+        // layer 0: enc(64) -> 256
+        run_layer<P, SLOT, EKG, 8, FwdG<P, EKG, 8>::G, true>(ws, lane, h, [&](int kg) { return E.u[kg]; },
+            [&](int mt, const f32x16& v) { relu_epi(H, ACT_ROW_X1, mt, v); });
+        save_mask(0, 4);
+        plain_layer(H, N, 1);
+        plain_layer(N, H, 2);
+        plain_layer(H, N, 3);
+        plain_layer(N, H, 4);
+        // layer 5 consumes [h, enc] (skip-concat after layer 4, mlp.py:92-97)
+        run_layer<P, SLOT, HKG + EKG, 8, FwdG<P, HKG + EKG, 8>::G, true>(ws, lane, h,
+            [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : E.u[kg >= HKG ? kg - HKG : 0]; },
+            [&](int mt, const f32x16& v) { relu_epi(N, ACT_ROW_X1 + 256 * 5, mt, v); });
+        save_mask(5, 4);
+        plain_layer(N, H, 6);
+        plain_layer(H, N, 7);
+        // after l=7 (odd) the trunk output X8 lives in N
+        // ---------------- sigma (+ bottleneck) ----------------
+        float sigma_raw = 0.f;
+        if constexpr (!FULL) {
+            run_layer<P, SLOT, HKG, 1, 1, true>(ws, lane, h, [&](int kg) { return N[kg]; },
+                [&](int, const f32x16& v) { sigma_raw = v[0]; });
+            if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
+        } else {
+            // m-tile 0 = sigma row, m-tiles 1..8 = bottleneck (identity activation) -> H
+            run_layer<P, SLOT, HKG, 9, FwdG<P, HKG, 9>::G, true>(ws, lane, h, [&](int kg) { return N[kg]; },
+                [&](int mt, const f32x16& v) {
+                    if (mt == 0) { sigma_raw = v[0]; return; }
+                    Units32<P> u = pack_units(P(), v);
+#pragma unroll
+                    for (int s = 0; s < P::KG32; ++s) H[(mt - 1) * P::KG32 + s] = u.u[s];
+                    if constexpr (TRAIN) store_tile_T(P(), tile_rsrc<P>(a.act, ld, ACT_ROW_BOTT + 32 * (mt - 1), 32), ldi, voff, p & 1, u);
+                });
+            if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
+
+            // ---------------- albedo head: 256 -> 128 (ReLU) -> 3 (Sigmoid) ----------------
+            U A1[QKG];
+            run_layer<P, SLOT, HKG, 4, FwdG<P, HKG, 4>::G, true>(ws, lane, h, [&](int kg) { return H[kg]; },
+                [&](int mt, const f32x16& v) { relu_epi(A1, ACT_ROW_A1, mt, v); });
+            save_mask(8, 2);
+            run_layer<P, SLOT, QKG, 1, 1, true>(ws, lane, h, [&](int kg) { return A1[kg]; },
+                [&](int, const f32x16& v) {
+                    if (h == 0 && live) {
+                        a.albedo[p] = sigmoid_f(v[0]);
+                        a.albedo[(size_t)a.p_pad + p] = sigmoid_f(v[1]);
+                        a.albedo[2 * (size_t)a.p_pad + p] = sigmoid_f(v[2]);
+                    }
+                });
+
+            // ---------------- transient head: [bottleneck, emb(img)] (260) -> 4x128 (ReLU) -> {Sigmoid, Softplus} ----
+            U EMB = P::zero();
+            if (h == 0) {
+                const int im = live ? a.simg[p] : 0;
+                const f32x4 ev = *reinterpret_cast<const f32x4*>(a.emb + 4 * im);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { if constexpr (P::IS_BF16) EMB[e] = (__bf16)ev[e]; else EMB[e] = ev[e]; }
+            }
+            if constexpr (TRAIN) {
+                const __amdgpu_buffer_rsrc_t rs = tile_rsrc<P>(a.act, ld, ACT_ROW_EMB, 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) store_elem_T(P(), rs, ldi, voff1, e, EMB[e]);
+            }
+            U T1[QKG], T2[QKG];
+            run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true>(ws, lane, h,
+                [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : EMB; },
+                [&](int mt, const f32x16& v) { relu_epi(T1, ACT_ROW_T1, mt, v); });
+            save_mask(9, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true>(ws, lane, h, [&](int kg) { return T1[kg]; },
+                [&](int mt, const f32x16& v) { relu_epi(T2, ACT_ROW_T1 + 128, mt, v); });
+            save_mask(10, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true>(ws, lane, h, [&](int kg) { return T2[kg]; },
+                [&](int mt, const f32x16& v) { relu_epi(T1, ACT_ROW_T1 + 256, mt, v); });
+            save_mask(11, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true>(ws, lane, h, [&](int kg) { return T1[kg]; },
+                [&](int mt, const f32x16& v) { relu_epi(T2, ACT_ROW_T1 + 384, mt, v); });
+            save_mask(12, 2);
+            run_layer<P, SLOT, QKG, 1, 1, true>(ws, lane, h, [&](int kg) { return T2[kg]; },
+                [&](int, const f32x16& v) {
+                    if (h == 0 && live) { a.ts[p] = sigmoid_f(v[0]); a.tb[p] = softplus_f(v[1]); }
+                });
+        }
+    }
+}
+
+template <class P, bool FULL, bool TRAIN>
+hipError_t launch(const MlpFwdArgs& a, int grid, hipStream_t st) {
+    constexpr int SMEM = 2 * FwdSlot<P>::BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, TRAIN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_mlp_fwd<P, FULL, TRAIN>), dim3(grid), dim3(P::NT), SMEM, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, bool train, int grid, hipStream_t st) {
+    if (bf16) {
+        if (full) return train ? launch<PBf16, true, true>(a, grid, st) : launch<PBf16, true, false>(a, grid, st);
+        return train ? launch<PBf16, false, true>(a, grid, st) : launch<PBf16, false, false>(a, grid, st);
+    }
+    if (full) return train ? launch<PF32, true, true>(a, grid, st) : launch<PF32, true, false>(a, grid, st);
+    return train ? launch<PF32, false, true>(a, grid, st) : launch<PF32, false, false>(a, grid, st);
+}

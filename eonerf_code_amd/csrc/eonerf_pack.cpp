@@ -1,0 +1,176 @@
+// Builds the flat parameter layout and the gather maps of the packed weight streams (see eonerf_pack.h).
+// Tensor names / shapes follow the reference state_dict (radiance_fields/eonerf.py:84-139).
+#include "eonerf_pack.h"
+#include "eonerf_kernels.h"
+
+void ParamLayout::build(int n_images) {
+    n_img = n_images;
+    t.clear();
+    total = 0;
+    auto add = [&](const std::string& name, int rows, int cols) {
+        ParamInfo p{name, total, rows, cols};
+        total += ((size_t)rows * cols + 3) & ~(size_t)3;     // 16-byte aligned tensors
+        t.push_back(p);
+        return (int)t.size() - 1;
+    };
+    emb = add("transient_encoder.weight", n_images, 4);
+    rad = add("radiometricT_enc.weight", n_images, 9);
+    const int trunk_in[8] = {63, 256, 256, 256, 256, 319, 256, 256};
+    for (int l = 0; l < 8; ++l) {
+        trunk_w[l] = add("base_mlp.hidden_layers." + std::to_string(l) + ".weight", 256, trunk_in[l]);
+        trunk_b[l] = add("base_mlp.hidden_layers." + std::to_string(l) + ".bias", 1, 256);
+    }
+    sig_w = add("sigma_layer.output_layer.weight", 1, 256);
+    sig_b = add("sigma_layer.output_layer.bias", 1, 1);
+    bot_w = add("bottleneck_layer.output_layer.weight", 256, 256);
+    bot_b = add("bottleneck_layer.output_layer.bias", 1, 256);
+    a1_w = add("albedo_mlp.hidden_layers.0.weight", 128, 256);
+    a1_b = add("albedo_mlp.hidden_layers.0.bias", 1, 128);
+    a2_w = add("albedo_mlp.output_layer.weight", 3, 128);
+    a2_b = add("albedo_mlp.output_layer.bias", 1, 3);
+    const int t_in[4] = {260, 128, 128, 128};
+    for (int l = 0; l < 4; ++l) {
+        t_w[l] = add("transient_mlp.hidden_layers." + std::to_string(l) + ".weight", 128, t_in[l]);
+        t_b[l] = add("transient_mlp.hidden_layers." + std::to_string(l) + ".bias", 1, 128);
+    }
+    tsc_w = add("transient_scalar.output_layer.weight", 1, 128);
+    tsc_b = add("transient_scalar.output_layer.bias", 1, 1);
+    tbe_w = add("transient_beta.output_layer.weight", 1, 128);
+    tbe_b = add("transient_beta.output_layer.bias", 1, 1);
+    am1_w = add("ambient_mlp.hidden_layers.0.weight", 128, 27);
+    am1_b = add("ambient_mlp.hidden_layers.0.bias", 1, 128);
+    am2_w = add("ambient_mlp.output_layer.weight", 3, 128);
+    am2_b = add("ambient_mlp.output_layer.bias", 1, 3);
+}
+
+static void slot_to_kghe(bool bf16, int slot, int& kg, int& h, int& e) {
+    if (bf16) { kg = slot / 16; const int rem = slot % 16; e = (rem / 8) * 4 + rem % 4; h = (rem % 8) / 4; }
+    else { kg = slot / 8; h = (slot % 8) / 4; e = slot % 4; }
+}
+
+int enc_col_of_slot(bool bf16, int slot) {
+    int kg, h, e;
+    slot_to_kghe(bf16, slot, kg, h, e);
+    const int q = kg * (bf16 ? 8 : 4) + e;
+    return enc_col_of_hq(h, q);
+}
+
+void append_layer(PackedStream& s, bool bf16, const PackLayer& L) {
+    const int G = pick_group(bf16, L.KG, L.MT);
+    const int ne = bf16 ? 8 : 4, esz = bf16 ? 2 : 4;
+    for (int mg = 0; mg < L.MT / G; ++mg) {
+        const uint32_t off = (uint32_t)s.bytes;
+        const uint32_t bytes = (uint32_t)(G * (L.KG * 1024 + 128));
+        s.chunks.push_back(ChunkDesc{off, bytes});
+        for (int g = 0; g < G; ++g) {
+            const int mt = mg * G + g;
+            for (int kg = 0; kg < L.KG; ++kg)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 31, h = lane >> 5;
+                    for (int e = 0; e < ne; ++e) {
+                        const int slot = bf16 ? PBf16::feat(kg, h, e) : PF32::feat(kg, h, e);
+                        PackEntry pe{off + (uint32_t)((g * L.KG + kg) * 1024 + lane * 16 + e * esz), L.w(32 * mt + r, slot)};
+                        (bf16 ? s.e16 : s.e32).push_back(pe);
+                    }
+                }
+            for (int i = 0; i < 32; ++i) {
+                PackEntry pe{off + (uint32_t)(G * L.KG * 1024 + g * 128 + i * 4), L.bias ? L.b(32 * mt + i) : -1};
+                s.e32.push_back(pe);
+            }
+        }
+        s.bytes += bytes;
+    }
+}
+
+PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full) {
+    PackedStream s;
+    const int KF = bf16 ? 16 : 8;
+    const int HKG = 256 / KF, QKG = 128 / KF, EKG = 64 / KF;
+    auto dense = [&](int wi, int bi, int out_rows, int in_cols, int KG, int MT) {
+        PackLayer L{KG, MT, true,
+            [=, &pl](int row, int slot) { return (row < out_rows && slot < in_cols) ? pl.at(wi, row, slot) : -1; },
+            [=, &pl](int row) { return row < out_rows ? pl.at(bi, 0, row) : -1; }};
+        append_layer(s, bf16, L);
+    };
+    // trunk layer 0: encoding slots -> columns of W0
+    append_layer(s, bf16, PackLayer{EKG, 8, true,
+        [&, bf16](int row, int slot) { const int c = enc_col_of_slot(bf16, slot); return c >= 0 ? pl.at(pl.trunk_w[0], row, c) : -1; },
+        [&](int row) { return pl.at(pl.trunk_b[0], 0, row); }});
+    for (int l = 1; l < 8; ++l) {
+        if (l == 5) {   // [h(256), enc slots(64)] -> columns [0,256) and 256 + enc column (mlp.py:92-97)
+            append_layer(s, bf16, PackLayer{HKG + EKG, 8, true,
+                [&, bf16](int row, int slot) {
+                    if (slot < 256) return pl.at(pl.trunk_w[5], row, slot);
+                    const int c = enc_col_of_slot(bf16, slot - 256);
+                    return c >= 0 ? pl.at(pl.trunk_w[5], row, 256 + c) : -1;
+                },
+                [&](int row) { return pl.at(pl.trunk_b[5], 0, row); }});
+        } else {
+            dense(pl.trunk_w[l], pl.trunk_b[l], 256, 256, HKG, 8);
+        }
+    }
+    // m-tile 0 = sigma row (sigma_layer), m-tiles 1..8 = bottleneck_layer (FULL only)
+    append_layer(s, bf16, PackLayer{HKG, full ? 9 : 1, true,
+        [&](int row, int slot) {
+            if (row == 0) return pl.at(pl.sig_w, 0, slot);
+            if (row >= 32) return pl.at(pl.bot_w, row - 32, slot);
+            return -1;
+        },
+        [&](int row) { return row == 0 ? pl.at(pl.sig_b, 0, 0) : (row >= 32 ? pl.at(pl.bot_b, 0, row - 32) : -1); }});
+    if (!full) return s;
+    dense(pl.a1_w, pl.a1_b, 128, 256, HKG, 4);
+    dense(pl.a2_w, pl.a2_b, 3, 128, QKG, 1);
+    dense(pl.t_w[0], pl.t_b[0], 128, 260, HKG + 1, 4);          // slots 256..259 = embedding columns
+    for (int l = 1; l < 4; ++l) dense(pl.t_w[l], pl.t_b[l], 128, 128, QKG, 4);
+    append_layer(s, bf16, PackLayer{QKG, 1, true,
+        [&](int row, int slot) { return row == 0 ? pl.at(pl.tsc_w, 0, slot) : (row == 1 ? pl.at(pl.tbe_w, 0, slot) : -1); },
+        [&](int row) { return row == 0 ? pl.at(pl.tsc_b, 0, 0) : (row == 1 ? pl.at(pl.tbe_b, 0, 0) : -1); }});
+    return s;
+}
+
+// Backward chain: dX^T = W^T dY^T.  "row" = INPUT feature of the forward layer, "slot" = OUTPUT feature.
+PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad) {
+    PackedStream s;
+    const int KF = bf16 ? 16 : 8;
+    const int HKG = 256 / KF, QKG = 128 / KF;
+    auto transposed = [&](int wi, int out_rows, int in_cols, int KG, int MT) {
+        append_layer(s, bf16, PackLayer{KG, MT, false,
+            [=, &pl](int row, int slot) { return (slot < out_rows && row < in_cols) ? pl.at(wi, slot, row) : -1; }, nullptr});
+    };
+    if (full) {
+        // d{ts_pre, tb_pre} (slots 0,1) -> T4 (128)
+        append_layer(s, bf16, PackLayer{1, 4, false,
+            [&](int row, int slot) { return slot == 0 ? pl.at(pl.tsc_w, 0, row) : (slot == 1 ? pl.at(pl.tbe_w, 0, row) : -1); }, nullptr});
+        for (int l = 3; l >= 1; --l) transposed(pl.t_w[l], 128, 128, QKG, 4);
+        // d albedo_pre (slots 0..2) -> A1 (128)
+        transposed(pl.a2_w, 3, 128, 1, 4);
+        // [dY_A1 (slots 0..127), dY_T1 (slots 128..255)] -> bottleneck rows 0..255, embedding rows 256..259
+        append_layer(s, bf16, PackLayer{2 * QKG, 9, false,
+            [&](int row, int slot) {
+                if (slot < 128) return row < 256 ? pl.at(pl.a1_w, slot, row) : -1;
+                return row < 260 ? pl.at(pl.t_w[0], slot - 128, row) : -1;
+            }, nullptr});
+        // [d bottleneck (slots 0..255), d sigma_pre (slot 256)] -> X8
+        append_layer(s, bf16, PackLayer{HKG + 1, 8, false,
+            [&](int row, int slot) { return slot < 256 ? pl.at(pl.bot_w, slot, row) : (slot == 256 ? pl.at(pl.sig_w, 0, row) : -1); }, nullptr});
+    } else {
+        append_layer(s, bf16, PackLayer{1, 8, false,
+            [&](int row, int slot) { return slot == 0 ? pl.at(pl.sig_w, 0, row) : -1; }, nullptr});
+    }
+    for (int l = 7; l >= 1; --l) {
+        if (l == 5) {
+            append_layer(s, bf16, PackLayer{HKG, input_grad ? 10 : 8, false,
+                [&, bf16](int row, int slot) {
+                    if (row < 256) return pl.at(pl.trunk_w[5], slot, row);
+                    const int c = enc_col_of_slot(bf16, row - 256);
+                    return c >= 0 ? pl.at(pl.trunk_w[5], slot, 256 + c) : -1;
+                }, nullptr});
+        } else {
+            transposed(pl.trunk_w[l], 256, 256, HKG, 8);
+        }
+    }
+    if (input_grad)
+        append_layer(s, bf16, PackLayer{HKG, 2, false,
+            [&, bf16](int row, int slot) { const int c = enc_col_of_slot(bf16, row); return c >= 0 ? pl.at(pl.trunk_w[0], slot, c) : -1; }, nullptr});
+    return s;
+}

@@ -1,0 +1,46 @@
+// Host-side description of the flat parameter buffer and of the packed weight streams.
+//
+// A stream is the concatenation of chunks in the exact order a chain kernel consumes them (eonerf_mlp_fwd.hip,
+// eonerf_mlp_bwd.hip).  chunk = G m-tiles:  [G][KG] units of 1 KiB (A operand in MFMA fragment order: lane (r,h)
+// holds row 32*m + r, features P::feat(kg, h, e)), then G x 32 fp32 biases.  The packer is a pure gather:
+// every destination element has a source index into the flat fp32 parameter buffer (or -1 = zero).
+#pragma once
+#include <stdint.h>
+#include <functional>
+#include <string>
+#include <vector>
+#include "eonerf_common.h"
+
+struct ParamInfo { std::string name; size_t offset; int rows, cols; };
+
+struct ParamLayout {
+    std::vector<ParamInfo> t;
+    size_t total = 0;
+    int n_img = 0;
+    // indices into t
+    int emb, rad, trunk_w[8], trunk_b[8], sig_w, sig_b, bot_w, bot_b, a1_w, a1_b, a2_w, a2_b;
+    int t_w[4], t_b[4], tsc_w, tsc_b, tbe_w, tbe_b, am1_w, am1_b, am2_w, am2_b;
+    void build(int n_images);
+    int at(int ti, int r, int c) const { return (int)(t[ti].offset + (size_t)r * t[ti].cols + c); }
+};
+
+struct PackEntry { uint32_t dst; int32_t src; };     // dst: byte offset into the stream
+
+struct PackedStream {
+    std::vector<ChunkDesc> chunks;
+    std::vector<PackEntry> e16;     // bf16 destinations
+    std::vector<PackEntry> e32;     // fp32 destinations
+    size_t bytes = 0;
+};
+
+struct PackLayer {
+    int KG, MT;
+    bool bias;
+    std::function<int(int row, int slot)> w;     // flat index of the weight multiplying input-slot `slot` for output row `row`
+    std::function<int(int row)> b;               // flat index of the bias of output row `row`
+};
+
+void append_layer(PackedStream& s, bool bf16, const PackLayer& L);
+PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full);
+PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad);
+int enc_col_of_slot(bool bf16, int slot);      // reference encoding column (mlp.py:190-208) of an encoding slot, -1 = pad

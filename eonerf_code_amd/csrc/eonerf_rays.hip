@@ -1,0 +1,380 @@
+// Per-ray kernels of the EO-NeRF hot path: stratified sampler + cube filter (H3), sample compaction, alpha
+// compositing as a per-ray wavefront scan (H7), shadow-ray transmittance (H8), S-NeRF irradiance + radiometric
+// affine + output packing (H9), and their backward passes.  One wave (64 lanes) owns one ray; a ray has at most
+// 127 intervals -> 2 per lane (i = lane, lane + 64).
+#include "eonerf_common.h"
+#include "eonerf_rays.h"
+
+namespace {
+
+constexpr int RAYS_PER_BLOCK = 4;   // 256 threads
+
+// ---- wave helpers -------------------------------------------------------------------------------------------
+EO_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes
+EO_DEV float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// inclusive SUFFIX scan (sum over lanes >= lane)
+EO_DEV float wave_suffix_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += t;
+    }
+    return v;
+}
+
+// ---- the SatNeRF sampler for one ray (sat_rendering.py:46-84), evaluated without FMA contraction so that
+//      t values and the cube-filter decisions are bit-identical to the reference's fp32 torch ops ------------
+struct RaySamples {
+    float ts[2], te[2], mid[2], x[2], y[2], z[2];
+    bool valid[2];
+};
+
+EO_DEV float zval(const float* zsteps, float near, int i) {
+    // near * (1 - s) + (near + 2) * s      (sat_rendering.py:60-68)
+    const float s = zsteps[i];
+    return __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, s)), __fmul_rn(__fadd_rn(near, 2.0f), s));
+}
+EO_DEV float zperturbed(const float* zsteps, float near, int i, float u) {
+    const float zi = zval(zsteps, near, i);
+    const float lower = i == 0 ? zi : __fmul_rn(0.5f, __fadd_rn(zval(zsteps, near, i - 1), zi));
+    const float upper = i == 127 ? zi : __fmul_rn(0.5f, __fadd_rn(zi, zval(zsteps, near, i + 1)));
+    return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u));       // perturb_z_vals, :46-54
+}
+
+EO_DEV RaySamples sample_ray(const float* zsteps, const float* u_row, float near, float ox, float oy, float oz,
+                             float dx, float dy, float dz, int lane) {
+    RaySamples s;
+    const float za = zperturbed(zsteps, near, lane, u_row[lane]);
+    const float zb = zperturbed(zsteps, near, lane + 64, u_row[lane + 64]);
+    float za1 = __shfl_down(za, 1, 64);
+    const float zb0 = __shfl(zb, 0, 64);
+    if (lane == 63) za1 = zb0;
+    const float zb1 = __shfl_down(zb, 1, 64);     // lane 63: interval 127 does not exist
+    const float zs[2] = {za, zb}, zn[2] = {za1, zb1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        s.ts[k] = zs[k];
+        s.te[k] = __fadd_rn(zs[k], __fsub_rn(zn[k], zs[k]));               // a + (b - a), :74
+        s.mid[k] = __fdiv_rn(__fadd_rn(s.ts[k], s.te[k]), 2.0f);           // :79
+        s.x[k] = __fadd_rn(ox, __fmul_rn(dx, s.mid[k]));                    // :80
+        s.y[k] = __fadd_rn(oy, __fmul_rn(dy, s.mid[k]));
+        s.z[k] = __fadd_rn(oz, __fmul_rn(dz, s.mid[k]));
+        const bool inside = fabsf(s.x[k]) < 1.0f && fabsf(s.y[k]) < 1.0f && fabsf(s.z[k]) < 1.0f;   // :18-22
+        s.valid[k] = inside && (k == 0 || lane < 63);
+    }
+    return s;
+}
+
+struct RayGeom { float ox, oy, oz, dx, dy, dz, near; };
+
+// camera rays come from the [R,11] table; sun rays start at the rendered surface point and look at the sun
+// (sat_rendering.py:90-91: origin = o + depth*d, dir = -sundir, near = 0)
+EO_DEV RayGeom ray_geom(const SampleArgs& a, int ray) {
+    const float* r = a.rays + (size_t)ray * 11;
+    RayGeom g;
+    if (a.sun_pass) {
+        const float depth = a.depth[(size_t)ray * a.depth_stride];
+        g.ox = __fadd_rn(r[0], __fmul_rn(depth, r[3]));
+        g.oy = __fadd_rn(r[1], __fmul_rn(depth, r[4]));
+        g.oz = __fadd_rn(r[2], __fmul_rn(depth, r[5]));
+        g.dx = -r[8]; g.dy = -r[9]; g.dz = -r[10];
+        g.near = 0.f;
+    } else {
+        g.ox = r[0]; g.oy = r[1]; g.oz = r[2]; g.dx = r[3]; g.dy = r[4]; g.dz = r[5];
+        g.near = r[6];
+    }
+    return g;
+}
+
+// ---- kernel 1: count samples per ray (for both the first draw and the "retry" draw) -----------------------
+__global__ __launch_bounds__(256) void k_count(SampleArgs a) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    const RayGeom g = ray_geom(a, ray);
+    RaySamples s = sample_ray(a.zsteps, a.u + (size_t)ray * 128, g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+    const int cnt = __popcll(__ballot(s.valid[0])) + __popcll(__ballot(s.valid[1]));
+    int cnt_retry = cnt;
+    if (a.u_retry) {
+        // the reference's retry passes near=None -> zeros (sat_rendering.py:262)
+        RaySamples s2 = sample_ray(a.zsteps, a.u_retry + (size_t)ray * 128, 0.f, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+        cnt_retry = __popcll(__ballot(s2.valid[0])) + __popcll(__ballot(s2.valid[1]));
+    }
+    if (lane == 0) {
+        a.cnt_first[ray] = cnt;
+        a.cnt_retry[ray] = cnt_retry;
+        if (cnt == 0 && a.u_retry) atomicOr(a.flags, 1);
+    }
+}
+
+// ---- kernel 2: exclusive scan of the chosen counts -> offsets[R+1]; n_pts; pts_per_ray (first draw) ---------
+__global__ __launch_bounds__(1024) void k_scan(SampleArgs a) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool retry = a.u_retry && (*a.flags & 1);
+    const int* cnt = retry ? a.cnt_retry : a.cnt_first;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < a.n_rays; base += 1024) {
+        const int i = base + tid;
+        const int v = i < a.n_rays ? cnt[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int c = carry;
+        if (i < a.n_rays) {
+            a.offsets[i] = c + woff + incl - v;
+            a.counts[i] = v;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) { a.offsets[a.n_rays] = carry; *a.n_pts = carry; }
+}
+
+// ---- kernel 3: recompute the samples and write them compactly ---------------------------------------------
+__global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    const RayGeom g = ray_geom(a, ray);
+    const bool retry = a.u_retry && (*a.flags & 1);
+    const float* u = (retry ? a.u_retry : a.u) + (size_t)ray * 128;
+    RaySamples s = sample_ray(a.zsteps, u, retry ? 0.f : g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+    const unsigned long long m0 = __ballot(s.valid[0]), m1 = __ballot(s.valid[1]);
+    const int n0 = __popcll(m0), n = n0 + __popcll(m1);
+    const int off = a.offsets[ray];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int img = a.img_idx ? (int)a.img_idx[ray] : 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!s.valid[k]) continue;
+        const int rank = k == 0 ? __popcll(m0 & below) : n0 + __popcll(m1 & below);
+        const int p = off + rank;
+        a.px[p] = s.x[k]; a.py[p] = s.y[k]; a.pz[p] = s.z[k];
+        a.simg[p] = img;
+        a.tmid[p] = s.mid[k];
+        // camera pass: the last interval of every ray ends at 1e10 (radiance_fields/eonerf.py:218-220)
+        const float te = (a.patch_last && rank == n - 1) ? 1e10f : s.te[k];
+        a.delta[p] = __fsub_rn(te, s.ts[k]);
+    }
+}
+
+// ---- ambient head for one ray, computed by the whole wave (radiance_fields/eonerf.py:132-139,163-164) ------
+struct AmbientRay { float out[3]; float hid[2]; float pre[3]; float enc[27]; };
+
+EO_DEV void sun_encoding(float sx, float sy, float sz, float* enc) {   // mlp.py:190-208, L=4, fp32
+    enc[0] = sx; enc[1] = sy; enc[2] = sz;
+    const float c[3] = {sx, sy, sz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float xb = c[d] * (float)(1 << k);
+            enc[3 + 3 * k + d] = sinf(xb);
+            enc[15 + 3 * k + d] = sinf(xb + EO_PI_2_F);
+        }
+}
+
+EO_DEV AmbientRay ambient_forward(const AmbientW& w, float sx, float sy, float sz, int lane) {
+    AmbientRay r;
+    sun_encoding(sx, sy, sz, r.enc);
+    float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = lane + 64 * k;
+        float acc = w.b1[j];
+        for (int i = 0; i < 27; ++i) acc = fmaf(w.w1[j * 27 + i], r.enc[i], acc);
+        r.hid[k] = fmaxf(acc, 0.f);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) part[o] = fmaf(w.w2[o * 128 + j], r.hid[k], part[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { r.pre[o] = wave_sum(part[o]) + w.b2[o]; r.out[o] = sigmoid_f(r.pre[o]); }
+    return r;
+}
+
+// ---- compositing forward ------------------------------------------------------------------------------------
+//   sd = sigma*delta;  T = exp(-exclusive_sum(sd));  alpha = 1-exp(-sd);  w = T*alpha   (nerfacc v0.5.2 volrend,
+//   call sites radiance_fields/eonerf.py:229-243)            per-ray sums of w*{mid, albedo, ts, tb, 1}
+struct RayWeights { float w[2], T[2], sd[2]; float total; };
+
+EO_DEV RayWeights ray_weights(const float* sigma, const float* delta, int off, int n, int lane) {
+    RayWeights r;
+    float sd[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        sd[k] = i < n ? sigma[off + i] * delta[off + i] : 0.f;
+    }
+    const float inc0 = wave_incl_scan(sd[0], lane);
+    const float tot0 = __shfl(inc0, 63, 64);
+    const float inc1 = wave_incl_scan(sd[1], lane);
+    const float ex[2] = {inc0 - sd[0], tot0 + (inc1 - sd[1])};
+    r.total = tot0 + __shfl(inc1, 63, 64);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        r.sd[k] = sd[k];
+        r.T[k] = expf(-ex[k]);
+        r.w[k] = i < n ? r.T[k] * (1.f - expf(-sd[k])) : 0.f;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    const int off = a.offsets[ray], n = a.counts[ray];
+    const RayWeights rw = ray_weights(a.sigma, a.delta, off, n, lane);
+    if (a.shadow_only) {
+        // geo_shadow = T at the LAST valid sample (exclusive), 1 for an empty ray (sat_rendering.py:112-116)
+        const int last = n - 1;
+        const float Tl = __shfl(last >= 64 ? rw.T[1] : rw.T[0], last & 63, 64);
+        if (lane == 0) a.ray_out[(size_t)ray * RAY_REC + RR_GEO] = n > 0 ? Tl : 1.0f;
+        return;
+    }
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // depth, albedo3, ts, tb, wsum
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) {
+            const int p = off + i;
+            const float w = rw.w[k];
+            acc[0] += w * a.tmid[p];
+            if (!a.depth_only) {
+                acc[1] += w * a.albedo[p];
+                acc[2] += w * a.albedo[(size_t)a.p_pad + p];
+                acc[3] += w * a.albedo[2 * (size_t)a.p_pad + p];
+                acc[4] += w * a.ts[p];
+                acc[5] += w * a.tb[p];
+            }
+            acc[6] += w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] = wave_sum(acc[j]);
+    float amb[3] = {0.f, 0.f, 0.f};
+    if (!a.depth_only) {
+        const float* r = a.rays + (size_t)ray * 11;
+        const AmbientRay ar = ambient_forward(a.amb, r[8], r[9], r[10], lane);
+        amb[0] = ar.out[0]; amb[1] = ar.out[1]; amb[2] = ar.out[2];
+    }
+    if (lane == 0) {
+        float* o = a.ray_out + (size_t)ray * RAY_REC;
+        o[RR_DEPTH] = acc[0];
+        o[RR_ALB + 0] = acc[1]; o[RR_ALB + 1] = acc[2]; o[RR_ALB + 2] = acc[3];
+        o[RR_TS] = acc[4];
+        o[RR_TB] = acc[5] + 0.05f;                      // beta_min, eonerf.py:87,243
+        o[RR_WSUM] = acc[6];
+        o[RR_AMB + 0] = amb[0]; o[RR_AMB + 1] = amb[1]; o[RR_AMB + 2] = amb[2];   // sigmoid output of the head
+        o[RR_GEO] = 1.0f;
+    }
+}
+
+// ---- shading + output packing (sat_rendering.py:265-312) -----------------------------------------------------
+__global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
+    const int ray = blockIdx.x * 256 + threadIdx.x;
+    if (ray >= a.n_rays) return;
+    const float* r = a.ray_rec + (size_t)ray * RAY_REC;
+    float* o = a.out + (size_t)ray * 21;
+    const float wsum = r[RR_WSUM];
+    const float geo = a.use_shadow ? r[RR_GEO] : 1.0f;
+    const float ts = r[RR_TS];
+    const float s = a.use_shadow ? geo * ts : 1.0f;                       // :269-276
+    const long img = a.eval ? a.img_idx[0] : a.img_idx[ray];               // :288-291
+    const float* T = a.radiometric ? a.radiometric + img * 9 : nullptr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float alb = r[RR_ALB + c];
+        const float amb = (wsum * r[RR_AMB + c]) * 0.2f;                   // accumulate (eonerf.py:240) then *0.2 (:265)
+        float rgb = alb * s + (1.f - s) * (amb * alb);                     // :294
+        const float A = T ? T[c] : 1.f, b = T ? T[3 + c] : 0.f;
+        rgb = A * rgb + b;
+        o[c] = fminf(fmaxf(rgb, 0.f), 1.f);                                // :304-305
+        o[4 + c] = alb;
+        o[7 + c] = amb;
+        o[18 + c] = A * alb + b;                                           // :306
+    }
+    o[3] = r[RR_DEPTH];
+    o[10] = geo;
+    o[11] = ts;
+    o[12] = r[RR_TB];
+    o[13] = 1.0f;                                                          // entropy, eonerf.py:246
+    o[14] = (float)a.pts_first[ray];                                       // counts of the FIRST draw (:259, stale on retry)
+    o[15] = a.use_shadow ? (float)a.sc_counts[ray] : 1.0f;                 // :272 / :96
+    o[16] = 1.0f; o[17] = 1.0f;                                            // opacity_after_surface, :283
+}
+
+// ---- small utility kernels ---------------------------------------------------------------------------------
+__global__ void k_points_to_soa(const float* xyz, const int64_t* img, int n, int p_pad, float* px, float* py, float* pz,
+                                int* simg, int* n_pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_pts = n;
+    if (i >= p_pad) return;
+    if (i < n) {
+        px[i] = xyz[3 * (size_t)i]; py[i] = xyz[3 * (size_t)i + 1]; pz[i] = xyz[3 * (size_t)i + 2];
+        simg[i] = img ? (int)img[i] : 0;
+    } else if (i < ((n + 255) & ~255)) {
+        px[i] = 0.f; py[i] = 0.f; pz[i] = 0.f; simg[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ambient_points(AmbientW w, const float* sun, int n, float* out) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const AmbientRay ar = ambient_forward(w, sun[3 * (size_t)i], sun[3 * (size_t)i + 1], sun[3 * (size_t)i + 2], lane);
+    if (lane < 3) out[3 * (size_t)i + lane] = lane == 0 ? ar.out[0] : (lane == 1 ? ar.out[1] : ar.out[2]);
+}
+
+__global__ void k_soa3_to_aos(const float* soa, int p_pad, int n, float* aos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { aos[3 * (size_t)i] = soa[i]; aos[3 * (size_t)i + 1] = soa[(size_t)p_pad + i]; aos[3 * (size_t)i + 2] = soa[2 * (size_t)p_pad + i]; }
+}
+
+}  // namespace
+
+hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st) {
+    const int blocks = (a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
+    hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_composite_fwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_shade_fwd(const ShadeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade_fwd, dim3((a.n_rays + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_points_to_soa(const float* xyz, const int64_t* img, int n, int p_pad, float* px, float* py, float* pz,
+                                   int* simg, int* n_pts, hipStream_t st) {
+    hipLaunchKernelGGL(k_points_to_soa, dim3((p_pad + 255) / 256), dim3(256), 0, st, xyz, img, n, p_pad, px, py, pz, simg, n_pts);
+    return hipGetLastError();
+}
+hipError_t eo_launch_ambient_points(const AmbientW& w, const float* sun, int n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_ambient_points, dim3((n + 3) / 4), dim3(256), 0, st, w, sun, n, out);
+    return hipGetLastError();
+}
+hipError_t eo_launch_soa3_to_aos(const float* soa, int p_pad, int n, float* aos, hipStream_t st) {
+    hipLaunchKernelGGL(k_soa3_to_aos, dim3((n + 255) / 256), dim3(256), 0, st, soa, p_pad, n, aos);
+    return hipGetLastError();
+}

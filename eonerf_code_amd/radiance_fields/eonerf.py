@@ -1,0 +1,169 @@
+"""EONerfMLP -- host-side mirror of radiance_fields/eonerf.py:69-248 over libeonerf_hip.so.
+
+Same constructor, attributes, state_dict (44 entries) and method signatures as the reference class; the arithmetic
+(encoding, trunk, heads, compositing) runs in hand-written HIP kernels for gfx950.  All parameters are views of ONE
+flat fp32 device buffer (`flat_params`), which is what the kernels read, what Adam updates and what the data-parallel
+launcher all-reduces.
+"""
+import ctypes as C
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .mlp import MLP, DenseLayer, SinusoidalEncoder
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class EONerfMLP(nn.Module):
+    def __init__(self, n_input_images: int, net_depth: int = 8, net_width: int = 256, skip_layer: int = 4,
+                 radiometric_normalization: bool = False, precision: str = None):
+        super().__init__()
+        if (net_depth, net_width, skip_layer) != (8, 256, 4):
+            raise ValueError("the HIP path implements the shipped EO-NeRF geometry only: depth 8, width 256, skip 4")
+        self.pos_enc_L, self.view_enc_L = 10, 4
+        self.n_input_images = n_input_images
+        self.posi_encoder = SinusoidalEncoder(3, 0, self.pos_enc_L, True)
+        self.view_encoder = SinusoidalEncoder(3, 0, self.view_enc_L, True)
+        self.transient_encoder = nn.Embedding(n_input_images, 4)
+        self.beta_min = 0.05
+        self.radiometric_normalization = radiometric_normalization
+        if radiometric_normalization:
+            init = torch.cat([torch.ones(n_input_images, 3), torch.zeros(n_input_images, 6)], dim=1)
+            self.radiometricT_enc = nn.Embedding.from_pretrained(init, freeze=False)
+        self.base_mlp = MLP(self.posi_encoder.latent_dim, None, net_depth, net_width, skip_layer, output_enabled=False)
+        self.sigma_layer = DenseLayer(self.base_mlp.output_dim, 1)
+        self.bottleneck_layer = DenseLayer(self.base_mlp.output_dim, net_width)
+        self.albedo_mlp = MLP(net_width, 3, 1, net_width // 2, None)
+        self.transient_mlp = MLP(net_width + 4, None, 4, net_width // 2, None, output_enabled=False)
+        self.transient_scalar = DenseLayer(self.transient_mlp.output_dim, 1)
+        self.transient_beta = DenseLayer(self.transient_mlp.output_dim, 1)
+        self.ambient_mlp = MLP(self.view_encoder.latent_dim, 3, 1, net_width // 2, None)
+
+        self.precision = (precision or os.environ.get("EONERF_PRECISION", "bf16")).lower()
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self._ctx = None          # eonerf_ctx*
+        self._flat = None         # flat fp32 parameter buffer (device)
+        self._layout = None
+        self._packed_version = None
+        self._ws = {}
+
+    # ------------------------------------------------------------------ native context / flat parameters
+    def _context(self):
+        if self._ctx is None:
+            L = _lib.lib()
+            cfg = _lib.EonerfConfig(self.n_input_images, _lib.EONERF_BF16 if self.precision == "bf16" else _lib.EONERF_FP32,
+                                    128, 1 if self.radiometric_normalization else 0)
+            ctx = C.c_void_p()
+            _lib.check(L.eonerf_create(C.byref(ctx), C.byref(cfg)))
+            self._ctx = ctx
+            self._layout = _lib.param_layout(ctx)
+            self._n_floats = L.eonerf_param_floats(ctx)
+        return self._ctx
+
+    def __del__(self):
+        try:
+            if self._ctx is not None:
+                _lib.lib().eonerf_destroy(self._ctx)
+        except Exception:
+            pass
+
+    def _named(self):
+        return dict(self.named_parameters())
+
+    def flat_params(self):
+        """The flat fp32 buffer all parameters are views of (re-established after .to()/load_state_dict rebinding)."""
+        self._context()
+        params = self._named()
+        dev = next(iter(params.values())).device
+        if dev.type != "cuda":
+            raise RuntimeError("EONerfMLP's hot path runs on an AMD GPU only; move the module to cuda first (no CPU fallback)")
+        ok = self._flat is not None and self._flat.device == dev
+        if ok:
+            base = self._flat.data_ptr()
+            for name, off, r, c in self._layout:
+                if name in params and params[name].data_ptr() != base + 4 * off:
+                    ok = False
+                    break
+        if not ok:
+            flat = torch.zeros(self._n_floats, dtype=torch.float32, device=dev)
+            for name, off, r, c in self._layout:
+                if name not in params:
+                    continue
+                p = params[name]
+                flat[off:off + r * c].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + r * c].view(p.shape)
+            self._flat = flat
+            self._packed_version = None
+        return self._flat
+
+    def _ensure_packed(self):
+        flat = self.flat_params()
+        ver = tuple(p._version for p in self.parameters())
+        if ver != self._packed_version:
+            _lib.check(_lib.lib().eonerf_set_weights(self._ctx, _ptr(flat), _stream()))
+            self._packed_version = ver
+        return flat
+
+    def grad_views(self, d_flat):
+        """Views of a flat gradient buffer in named_parameters() order (None for tensors absent from the layout)."""
+        by_name = {name: (off, r, c) for name, off, r, c in self._layout}
+        out = []
+        for name, p in self.named_parameters():
+            off, r, c = by_name[name]
+            out.append(d_flat[off:off + r * c].view(p.shape))
+        return out
+
+    def _workspace(self, key, nbytes):
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != self._flat.device:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ reference API (inference entry points)
+    @torch.no_grad()
+    def query_density(self, x):
+        """radiance_fields/eonerf.py:141-145: x[..., 3] -> sigma[..., 1]."""
+        flat = self._ensure_packed()
+        shape = x.shape[:-1]
+        xs = x.reshape(-1, 3).float().contiguous()
+        n = xs.shape[0]
+        sigma = torch.empty(n, dtype=torch.float32, device=xs.device)
+        L = _lib.lib()
+        nb = L.eonerf_field_workspace_bytes(self._ctx, n)
+        ws = self._workspace("field", nb)
+        _lib.check(L.eonerf_query_density(self._ctx, _ptr(flat), _ptr(xs), n, _ptr(sigma), _ptr(ws), ws.numel(), _stream()))
+        return sigma.view(*shape, 1)
+
+    def query_opacity(self, x, step_size):
+        """radiance_fields/eonerf.py:147-152."""
+        return self.query_density(x) * step_size
+
+    @torch.no_grad()
+    def forward(self, x, sun_dirs=None, img_indices=None):
+        """radiance_fields/eonerf.py:154-170: -> (sigma[N,1], albedo[N,3], ambient[N,3], transient_scalar[N,1], transient_beta[N,1]).
+        Inference entry point; training differentiates through render_image (sat_rendering.py) instead."""
+        flat = self._ensure_packed()
+        xs = x.reshape(-1, 3).float().contiguous()
+        n = xs.shape[0]
+        sun = sun_dirs.reshape(-1, 3).float().contiguous()
+        img = img_indices.reshape(-1).to(torch.int64).contiguous()
+        dev = xs.device
+        sigma, ts, tb = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
+        albedo, ambient = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(2))
+        L = _lib.lib()
+        nb = L.eonerf_field_workspace_bytes(self._ctx, n)
+        ws = self._workspace("field", nb)
+        _lib.check(L.eonerf_field_forward(self._ctx, _ptr(flat), _ptr(xs), _ptr(sun), _ptr(img), n, _ptr(sigma), _ptr(albedo),
+                                          _ptr(ambient), _ptr(ts), _ptr(tb), _ptr(ws), ws.numel(), _stream()))
+        return sigma.view(n, 1), albedo, ambient, ts.view(n, 1), tb.view(n, 1)

@@ -1,0 +1,142 @@
+"""render_image -- host-side mirror of sat_rendering.py:176-335 over libeonerf_hip.so.
+
+Same signature, same result dict (12 keys, sat_rendering.py:322-334) and the same chunk loop semantics; per chunk ONE
+library call replaces satnerf_sampling + EONerfMLP.rendering + compute_geometric_shadows + the irradiance /
+radiometric model (sat_rendering.py:252-312), and autograd is one library call back.
+
+The jitter noise the reference draws with torch.rand_like inside perturb_z_vals (:52) is drawn here with
+torch.rand on the device (same distribution, same draw order: camera, [retry], sun) or can be injected through
+`noise=` for parity tests.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .datasets.satellite import SatRays, namedtuple_map, satrays_to_table
+from .radiance_fields.eonerf import _ptr, _stream
+
+RESULT_SLICES = (("rgb", 0, 3), ("depth", 3, 4), ("albedo_rgb", 4, 7), ("ambient_rgb", 7, 10), ("geo_shadows", 10, 11),
+                 ("transient_s", 11, 12), ("beta", 12, 13), ("entropy", 13, 14), ("pts_per_ray", 14, 15),
+                 ("sc_pts_per_ray", 15, 16), ("opacity_after_surface", 16, 18), ("shadowless_rgb", 18, 21))
+
+_ZSTEPS = {}
+
+
+def _zsteps(device):
+    z = _ZSTEPS.get(device)
+    if z is None:
+        z = torch.linspace(0, 1, 128).to(device)     # the reference's fp32 table (sat_rendering.py:67), computed once
+        _ZSTEPS[device] = z
+    return z
+
+
+class _RenderChunk(torch.autograd.Function):
+    """One chunk of render_image as a differentiable op; the parameters are inputs so autograd routes their grads."""
+
+    @staticmethod
+    def forward(ctx, field, table, img, flags, u_cam, u_retry, u_sun, *params):
+        L = _lib.lib()
+        flat = field._ensure_packed()
+        n = table.shape[0]
+        train = bool(flags & _lib.F_TRAIN)
+        nb = L.eonerf_render_workspace_bytes(field._ctx, n, flags)
+        # a training chunk keeps its own workspace alive until its backward; inference chunks share one
+        ws = torch.empty(nb, dtype=torch.uint8, device=table.device) if train else field._workspace("render", nb)
+        out = torch.empty(n, 21, dtype=torch.float32, device=table.device)
+        n_samples = torch.zeros(1, dtype=torch.int32, device=table.device)
+        _lib.check(L.eonerf_render_forward(field._ctx, _ptr(flat), _ptr(table), _ptr(img), _ptr(_zsteps(table.device)),
+                                           _ptr(u_cam), _ptr(u_retry), _ptr(u_sun), n, flags, _ptr(out), _ptr(n_samples),
+                                           _ptr(ws), ws.numel(), _stream()))
+        if train:
+            ctx.field, ctx.flags, ctx.ws = field, flags, ws
+            ctx.save_for_backward(table, img)
+        ctx.mark_non_differentiable(n_samples)
+        return out, n_samples
+
+    @staticmethod
+    def backward(ctx, d_out, _d_n):
+        field, flags, ws = ctx.field, ctx.flags, ctx.ws
+        table, img = ctx.saved_tensors
+        L = _lib.lib()
+        flat = field.flat_params()
+        d_flat = torch.zeros_like(flat)
+        d_out = d_out.contiguous().float()
+        _lib.check(L.eonerf_render_backward(field._ctx, _ptr(flat), _ptr(table), _ptr(img), table.shape[0], flags,
+                                            _ptr(d_out), _ptr(d_flat), _ptr(ws), ws.numel(), _stream()))
+        ctx.ws = None
+        return (None,) * 7 + tuple(field.grad_views(d_flat))
+
+
+def render_rays_chunk(radiance_field, table, img, epoch_idx, eval=False, only_depth=False, noise=None):
+    """table [n,11] fp32, img [n] int64 -> (out [n,21], n_samples int32[1]) for one chunk."""
+    n, dev = table.shape[0], table.device
+    flags = 0
+    if epoch_idx is not None and epoch_idx >= 2:
+        flags |= _lib.F_SHADOWS
+    if eval:
+        flags |= _lib.F_EVAL
+    if only_depth:
+        flags |= _lib.F_ONLY_DEPTH
+    params = list(radiance_field.parameters())
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params) and not only_depth:
+        flags |= _lib.F_TRAIN
+    if noise is None:
+        u_cam = torch.rand(n, 128, device=dev)
+        u_retry = torch.rand(n, 128, device=dev)
+        u_sun = torch.rand(n, 128, device=dev) if flags & _lib.F_SHADOWS else None
+    else:
+        u_cam, u_retry, u_sun = (None if t is None else t.to(dev, torch.float32).contiguous() for t in noise)
+    return _RenderChunk.apply(radiance_field, table, img, flags, u_cam, u_retry, u_sun, *params)
+
+
+def render_image(
+    # scene
+    radiance_field,
+    occupancy_grid,
+    rays: SatRays,
+    scene_aabb,
+    args,
+    epoch_idx=None,
+    chunk: int = 5120,
+    # rendering options (accepted and ignored exactly as the reference's live sampler ignores them)
+    near_plane=None,
+    far_plane=None,
+    render_step_size: float = 1e-3,
+    render_bkgd=None,
+    cone_angle: float = 0.0,
+    alpha_thre: float = 0.0,
+    early_stop_eps: float = 0.0,
+    timestamps=None,
+    only_depth: bool = False,
+    eval: bool = False,
+    noise=None,
+):
+    """Render the pixels of an image (sat_rendering.py:176-335).  Returns (results dict, n_rendering_samples)."""
+    n_samples = int(2 / render_step_size)
+    if n_samples != 128:
+        raise ValueError(f"render_step_size={render_step_size} gives {n_samples} samples/ray; the HIP path supports 128 "
+                         "(run_JAX_RGB.sh:11)")
+    rays_shape = rays.origins.shape
+    if len(rays_shape) == 3:
+        height, width, _ = rays_shape
+        num_rays = height * width
+        rays = namedtuple_map(lambda r: r.reshape([num_rays] + list(r.shape[2:])), rays)
+    else:
+        num_rays, _ = rays_shape
+    table, img = satrays_to_table(rays)
+
+    outs, counts = [], []
+    for k, i in enumerate(range(0, num_rays, chunk)):
+        nz = None if noise is None else noise[k]
+        out, n = render_rays_chunk(radiance_field, table[i:i + chunk], img[i:i + chunk], epoch_idx, eval=eval,
+                                   only_depth=only_depth, noise=nz)
+        outs.append(out)
+        counts.append(n)
+    out = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+    n_rendering_samples = int(torch.stack(counts).sum().item())     # the only host sync of the call
+    lead = tuple(rays_shape[:-1])
+    if only_depth:
+        return {"depth": out[:, 3:4].reshape(*lead, -1)}, n_rendering_samples
+    results = {k: out[:, a:b].reshape(*lead, -1) for k, a, b in RESULT_SLICES}
+    return results, n_rendering_samples

@@ -1,0 +1,108 @@
+/* eonerf_hip.h -- C ABI of libeonerf_hip.so: the MI355X (gfx950) implementation of the EO-NeRF per-ray hot path.
+ *
+ * The reference (rogermm14/eonerf_code) has NO native boundary of its own: its hot path is a Python API
+ * (SURVEY.md 8b).  Each entry point below names the reference Python interface it sits under; the host-side
+ * mirror of those interfaces lives in eonerf_code_amd/ (ctypes), INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw DEVICE pointers + sizes + a hipStream_t (passed as void*).
+ *   - the caller (PyTorch) owns every buffer incl. the workspace; the library allocates device memory only in
+ *     eonerf_create (packed weights, tables) and frees it in eonerf_destroy.
+ *   - every call is asynchronous on `stream`; nothing synchronises the device.
+ *   - return value: 0 = OK, < 0 = EONERF_E_* (bad argument / unsupported), > 0 = hipError_t.
+ *   - one context per process/GPU, used from one host thread (the reference is single-threaded,
+ *     train_eonerf.py:98-161).
+ */
+#ifndef EONERF_HIP_H
+#define EONERF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EONERF_VERSION 100
+
+enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4 };
+
+/* arithmetic of the MLP GEMMs */
+enum { EONERF_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (parity mode, 1e-4 vs the reference) */
+       EONERF_BF16 = 1 }; /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (throughput mode) */
+
+/* flags of eonerf_render_forward */
+enum { EONERF_F_SHADOWS = 1,     /* epoch_idx >= 2: shadow-ray pass + s = geo_shadow * transient_s (sat_rendering.py:269-276) */
+       EONERF_F_EVAL = 2,        /* eval=True: radiometric row of the chunk's first ray (sat_rendering.py:288-291) */
+       EONERF_F_TRAIN = 4,       /* keep what eonerf_render_backward needs in the workspace */
+       EONERF_F_ONLY_DEPTH = 8 };/* only_depth=True branch (sat_rendering.py:227-249): out[:,3] only */
+
+typedef struct eonerf_ctx eonerf_ctx;
+
+typedef struct {
+    int n_images;        /* EONerfMLP(n_input_images), radiance_fields/eonerf.py:70-77 */
+    int precision;       /* EONERF_FP32 | EONERF_BF16 */
+    int n_samples;       /* int(2/render_step_size); only 128 is supported (run_JAX_RGB.sh:11, sat_rendering.py:64) */
+    int radiometric;     /* radiometric_normalization (opt.py:98-99 forces 1 for eo-nerf) */
+} eonerf_config;
+
+/* lifetime -- replaces EONerfMLP.__init__ / .to(device) (radiance_fields/eonerf.py:70-139, train_eonerf.py:60-61) */
+int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg);
+int eonerf_destroy(eonerf_ctx* ctx);
+
+/* Flat fp32 parameter buffer: every tensor of the reference state_dict lives at a fixed offset of one
+ * contiguous device buffer (which is also the Adam / all-reduce unit).  Enumerate with index 0..n-1. */
+int eonerf_param_tensors(const eonerf_ctx* ctx);
+int eonerf_param_info(const eonerf_ctx* ctx, int index, const char** name, size_t* offset, int* rows, int* cols);
+size_t eonerf_param_floats(const eonerf_ctx* ctx);
+
+/* Re-pack the fp32 master weights into the LDS fragment-order streams the kernels read.  Call after every
+ * optimizer step / load_state_dict (replaces nothing in the reference: nn.Linear reads its weights in place). */
+int eonerf_set_weights(eonerf_ctx* ctx, const float* flat_params, void* stream);
+
+/* workspace the caller must pass to the calls below for batches of up to n_points samples / n_rays rays */
+size_t eonerf_field_workspace_bytes(const eonerf_ctx* ctx, int n_points);
+size_t eonerf_render_workspace_bytes(const eonerf_ctx* ctx, int n_rays, int flags);
+
+/* EONerfMLP.forward(x, sun_dirs, img_indices) -- radiance_fields/eonerf.py:154-170.
+ * flat_params: the fp32 master buffer (embedding / ambient tables are read from it directly).
+ * xyz[n,3], sun[n,3], img[n] (int64) -> sigma[n], albedo[n,3], ambient[n,3], ts[n], tb[n]  (row-major fp32). */
+int eonerf_field_forward(eonerf_ctx* ctx, const float* flat_params, const float* xyz, const float* sun, const int64_t* img, int n,
+                         float* sigma, float* albedo, float* ambient, float* ts, float* tb,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* EONerfMLP.query_density(x) -- radiance_fields/eonerf.py:141-145 (query_opacity = density * step on the host). */
+int eonerf_query_density(eonerf_ctx* ctx, const float* flat_params, const float* xyz, int n, float* sigma,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* One chunk of sat_rendering.render_image (sat_rendering.py:252-312) = satnerf_sampling + EONerfMLP.rendering +
+ * compute_geometric_shadows + irradiance/radiometric model + output packing.
+ *   rays[R,11] fp32 (o3 d3 near far sun3), img_idx[R] int64, zsteps[128] = linspace(0,1,128),
+ *   u_cam/u_sun[R,128] jitter in [0,1) (the reference draws rand_like inside perturb_z_vals, :52),
+ *   u_retry (may be NULL): noise of the ":260-262 resample if some ray is empty" branch.
+ *   out[R,21] = rgb3 depth1 albedo3 ambient3 geo1 ts1 beta1 entropy1 pts1 sc_pts1 opacity2 shadowless3 (:311-312)
+ *   n_samples_dev: device int, number of camera samples (render_image's second return value). */
+int eonerf_render_forward(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
+                          const float* zsteps, const float* u_cam, const float* u_retry, const float* u_sun,
+                          int n_rays, int flags, float* out, int* n_samples_dev,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Autograd of the call above (loss.backward(), train_eonerf.py:160): d_out[R,21] -> gradient of every parameter,
+ * ACCUMULATED into d_flat_params (same layout as the flat parameter buffer).  `workspace` must be the one a
+ * render_forward with EONERF_F_TRAIN and the same (rays, img_idx, n_rays, flags) filled; nothing else is remembered
+ * between the two calls, so several forward chunks may be outstanding, each with its own workspace. */
+int eonerf_render_backward(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
+                           int n_rays, int flags, const float* d_out, float* d_flat_params,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam step on the flat buffers (train_eonerf.py:63,161): lr, betas (0.9,0.999), eps 1e-8, no weight decay.
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int eonerf_adam_step(eonerf_ctx* ctx, float* flat_params, const float* d_flat_params, float* exp_avg, float* exp_avg_sq,
+                     int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+const char* eonerf_strerror(int code);
+int eonerf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,32 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/eonerf_hip.h declares
+(no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import REPO
+
+
+def test_header_symbols_exported():
+    from eonerf_code_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    hdr = open(os.path.join(REPO, "include", "eonerf_hip.h")).read()
+    declared = set(re.findall(r"\b(eonerf_[a-z_]+)\s*\(", hdr))
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(_lib.SYMBOLS)
+    L.eonerf_version.restype = ctypes.c_int
+    assert L.eonerf_version() == 100
+    L.eonerf_strerror.restype = ctypes.c_char_p
+    assert b"workspace" in L.eonerf_strerror(-2)
+
+
+def test_product_path_does_not_import_oracle():
+    pkg = os.path.join(REPO, "eonerf_code_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src, f"{f} must not reference the oracle"
