@@ -274,8 +274,8 @@ int eonerf_field_forward(eonerf_ctx* ctx, const float* flat, const float* xyz, c
                          float* sigma, float* albedo, float* ambient, float* ts, float* tb,
                          void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!sun || !img || !sigma || !albedo || !ambient || !ts || !tb || !flat) return EONERF_E_ARG;
     if (n == 0) return EONERF_OK;
+    if (!sun || !img || !sigma || !albedo || !ambient || !ts || !tb || !flat) return EONERF_E_ARG;
     PassBuffers b; int p_cap;
     int rc = field_common(ctx, flat, xyz, img, n, true, ws, ws_bytes, b, p_cap, st);
     if (rc) return rc;
@@ -288,8 +288,8 @@ int eonerf_field_forward(eonerf_ctx* ctx, const float* flat, const float* xyz, c
 
 int eonerf_query_density(eonerf_ctx* ctx, const float* flat, const float* xyz, int n, float* sigma, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!sigma || !flat) return EONERF_E_ARG;
     if (n == 0) return EONERF_OK;
+    if (!sigma || !flat) return EONERF_E_ARG;
     PassBuffers b; int p_cap;
     int rc = field_common(ctx, flat, xyz, nullptr, n, false, ws, ws_bytes, b, p_cap, st);
     if (rc) return rc;

@@ -223,10 +223,13 @@ EO_DEV RayWeights ray_weights(const float* sigma, const float* delta, int off, i
         const int i = lane + 64 * k;
         sd[k] = i < n ? sigma[off + i] * delta[off + i] : 0.f;
     }
+    // exclusive prefix = inclusive prefix of the PREVIOUS lane (never "inclusive - self": the last interval has
+    // sigma*delta ~ 1e10 and would cancel the whole prefix)
     const float inc0 = wave_incl_scan(sd[0], lane);
     const float tot0 = __shfl(inc0, 63, 64);
     const float inc1 = wave_incl_scan(sd[1], lane);
-    const float ex[2] = {inc0 - sd[0], tot0 + (inc1 - sd[1])};
+    const float p0 = __shfl_up(inc0, 1, 64), p1 = __shfl_up(inc1, 1, 64);
+    const float ex[2] = {lane == 0 ? 0.f : p0, lane == 0 ? tot0 : tot0 + p1};
     r.total = tot0 + __shfl(inc1, 63, 64);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
