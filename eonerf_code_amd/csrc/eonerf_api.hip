@@ -45,7 +45,6 @@ struct RenderWs {
     int *cnt_first, *cnt_retry, *flags;
     float* ray_rec; float* g_ray;
     PassBuffers cam, sun;
-    WgradJob* jobs;
     size_t bytes;
 };
 
@@ -145,7 +144,6 @@ RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) 
     w.g_ray = train ? c.take<float>((size_t)n_rays * RAY_REC) : nullptr;
     carve_pass(c, w.cam, n_rays, p_cap, !od, train, false, ab);
     if (shadows && !od) carve_pass(c, w.sun, n_rays, p_cap, false, train, true, ab); else memset(&w.sun, 0, sizeof(w.sun));
-    w.jobs = train ? c.take<WgradJob>(64) : nullptr;
     w.bytes = c.off + 256;
     return w;
 }
@@ -362,8 +360,128 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     return EONERF_OK;
 }
 
-int eonerf_render_backward(eonerf_ctx*, const float*, const float*, const int64_t*, int, int, const float*, float*, void*, size_t, void*) { return EONERF_E_UNSUPPORTED; }
-int eonerf_adam_step(eonerf_ctx*, float*, const float*, float*, float*, int, float, float, float, float, float, void*) { return EONERF_E_UNSUPPORTED; }
+int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
+                           int n_rays, int flags, const float* d_out, float* d_flat,
+                           void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx || !flat || !rays || !img_idx || !d_out || !d_flat || n_rays < 0 || !ws) return EONERF_E_ARG;
+    if (!(flags & EONERF_F_TRAIN) || (flags & EONERF_F_ONLY_DEPTH)) return EONERF_E_STATE;
+    if (!ctx->weights_set) return EONERF_E_STATE;
+    if (n_rays == 0) return EONERF_OK;
+    const bool shadows = flags & EONERF_F_SHADOWS;
+    RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    const int p_cap = p_cap_of(n_rays);
+    const ParamLayout& pl = ctx->pl;
+    const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
+    const int grid = std::min(ctx->n_cu, p_cap / tile);
+    auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
+
+    // ---- d out -> d ray record (+ radiometric table) -----------------------------------------------------
+    ShadeBwdArgs sb;
+    sb.ray_rec = w.ray_rec; sb.d_out = d_out; sb.img_idx = img_idx;
+    sb.radiometric = ctx->cfg.radiometric ? flat + pl.t[pl.rad].offset : nullptr;
+    sb.d_radiometric = ctx->cfg.radiometric ? dptr(pl.rad) : nullptr;
+    sb.g_ray = w.g_ray; sb.n_rays = n_rays; sb.use_shadow = shadows ? 1 : 0; sb.eval = (flags & EONERF_F_EVAL) ? 1 : 0;
+    HIP_TRY(eo_launch_shade_bwd(sb, st));
+
+    CompositeBwdArgs cb;
+    memset(&cb, 0, sizeof(cb));
+    cb.rays = rays; cb.p_pad = p_cap; cb.n_rays = n_rays; cb.ray_rec = w.ray_rec; cb.g_ray = w.g_ray;
+
+    // ---- shadow pass backwards: d geo -> d sigma_sun -> (chain, input grad) -> d pos -> d depth -----------
+    if (shadows) {
+        CompositeBwdArgs cs = cb;
+        cs.offsets = w.sun.offsets; cs.counts = w.sun.counts; cs.sigma = w.sun.sigma; cs.delta = w.sun.delta;
+        cs.g_sigma = w.sun.g_sigma; cs.g_pos = w.sun.g_pos;
+        HIP_TRY(eo_launch_sun_composite_bwd(cs, st));
+        MlpBwdArgs ms;
+        memset(&ms, 0, sizeof(ms));
+        ms.n_pts = w.sun.n_pts; ms.p_pad = p_cap;
+        ms.stream = ctx->bwd_dens.data; ms.chunks = ctx->bwd_dens.chunks; ms.n_chunks = ctx->bwd_dens.n_chunks;
+        ms.sigma = w.sun.sigma; ms.g_sigma = w.sun.g_sigma; ms.masks = w.sun.masks; ms.grd = w.sun.grd;
+        ms.px = w.sun.px; ms.py = w.sun.py; ms.pz = w.sun.pz; ms.g_pos = w.sun.g_pos;
+        HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, grid, st));
+        HIP_TRY(eo_launch_sun_depth_grad(cs, st));
+    }
+
+    // ---- camera pass backwards -----------------------------------------------------------------------------
+    cb.offsets = w.cam.offsets; cb.counts = w.cam.counts; cb.sigma = w.cam.sigma; cb.delta = w.cam.delta; cb.tmid = w.cam.tmid;
+    cb.albedo = w.cam.albedo; cb.ts = w.cam.ts; cb.tb = w.cam.tb;
+    cb.g_sigma = w.cam.g_sigma; cb.g_albedo = w.cam.g_albedo; cb.g_ts = w.cam.g_ts; cb.g_tb = w.cam.g_tb;
+    HIP_TRY(eo_launch_cam_composite_bwd(cb, st));
+    MlpBwdArgs mc;
+    memset(&mc, 0, sizeof(mc));
+    mc.n_pts = w.cam.n_pts; mc.p_pad = p_cap;
+    mc.stream = ctx->bwd_full.data; mc.chunks = ctx->bwd_full.chunks; mc.n_chunks = ctx->bwd_full.n_chunks;
+    mc.sigma = w.cam.sigma; mc.albedo = w.cam.albedo; mc.ts = w.cam.ts; mc.tb = w.cam.tb;
+    mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
+    mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
+    HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, grid, st));
+
+    // ---- weight gradients: every layer of both passes in one split-K launch -------------------------------
+    WgradJobTable tab;
+    tab.n = 0;
+    std::vector<int> weight;
+    const size_t ab = ctx->bf16 ? 2 : 4;
+    auto rows = [&](const void* slab, int row) { return reinterpret_cast<const uint8_t*>(slab) + (size_t)row * p_cap * ab; };
+    auto add = [&](const PassBuffers& b, int grd_row, int m_rows, int act_row, int n_rows, float* dw, int dw_ld, float* db,
+                   const int* cmap, int gm, int gn, int wm, int wn) {
+        WgradJob& j = tab.j[tab.n++];
+        j.a = rows(b.grd, grd_row); j.b = rows(b.act, act_row); j.dw = dw; j.db = db; j.col_map = cmap; j.n_pts = b.n_pts;
+        j.m_rows = m_rows; j.n_rows = n_rows; j.dw_ld = dw_ld; j.gm = gm; j.gn = gn; j.wm = wm; j.wn = wn;
+        weight.push_back(wm * wn + 1);
+    };
+    auto trunk_jobs = [&](const PassBuffers& b) {
+        add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
+        for (int l = 1; l < 8; ++l) {
+            const int in_ld = l == 5 ? 319 : 256;
+            add(b, GRD_ROW_Y0 + 256 * l, 256, ACT_ROW_X1 + 256 * (l - 1), 256, dptr(pl.trunk_w[l]), in_ld, dptr(pl.trunk_b[l]), nullptr, 2, 4, 4, 2);
+            if (l == 5)   // skip columns 256..318 <- encoding slots
+                add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1);
+        }
+        add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
+    };
+    trunk_jobs(w.cam);
+    add(w.cam, GRD_ROW_BOTT, 256, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.bot_w), 256, dptr(pl.bot_b), nullptr, 2, 4, 4, 2);
+    add(w.cam, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
+    add(w.cam, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
+    add(w.cam, GRD_ROW_T1, 128, ACT_ROW_BOTT, 256, dptr(pl.t_w[0]), 260, dptr(pl.t_b[0]), nullptr, 2, 4, 2, 2);
+    add(w.cam, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
+    for (int l = 1; l < 4; ++l)
+        add(w.cam, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
+    add(w.cam, GRD_ROW_T5, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);
+    add(w.cam, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
+    if (shadows) trunk_jobs(w.sun);
+    int wsum = 0;
+    for (int v : weight) wsum += v;
+    const int target = 2 * ctx->n_cu;
+    int n_wg = 0;
+    for (int k = 0; k < tab.n; ++k) {
+        tab.j[k].wg_begin = n_wg;
+        tab.j[k].wg_count = std::max(1, (target * weight[k] + wsum / 2) / wsum);
+        n_wg += tab.j[k].wg_count;
+    }
+    HIP_TRY(eo_launch_wgrad(tab, n_wg, p_cap, ctx->bf16, st));
+
+    // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
+    EmbGradArgs eg;
+    eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays;
+    HIP_TRY(eo_launch_emb_grad(eg, st));
+    AmbientBwdArgs ag;
+    ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.n_rays = n_rays;
+    ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
+    HIP_TRY(eo_launch_ambient_bwd(ag, st));
+    return EONERF_OK;
+}
+
+int eonerf_adam_step(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
+                     int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!ctx || !flat || !d_flat || !exp_avg || !exp_avg_sq || step < 1) return EONERF_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(eo_launch_adam(flat, d_flat, exp_avg, exp_avg_sq, ctx->pl.total, step, lr, beta1, beta2, eps, grad_scale, st));
+    return eonerf_set_weights(ctx, flat, stream);
+}
 
 }  // extern "C"
 

@@ -81,6 +81,7 @@ struct WgradJob {
     float* dw;            // destination inside the flat gradient buffer
     float* db;            // bias gradient or nullptr
     const int* col_map;   // nullptr = identity; -1 entries are dropped
+    const int* n_pts;     // device scalar: live samples of the pass these slabs belong to
     int m_rows, n_rows;   // valid rows of a / b
     int dw_ld;            // row stride of dw
     int gm, gn, wm, wn;   // wave grid and tiles per wave: (gm*wm*32) x (gn*wn*32) >= m_rows x n_rows
@@ -89,4 +90,6 @@ struct WgradJob {
 
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, bool train, int grid, hipStream_t st);
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, int grid, hipStream_t st);
-hipError_t eo_launch_wgrad(const WgradJob* jobs_dev, int n_wg, const int* n_pts, int p_pad, bool bf16, hipStream_t st);
+constexpr int WGRAD_MAX_JOBS = 40;
+struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; };     // passed by value in the kernel-argument segment
+hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, bool bf16, hipStream_t st);

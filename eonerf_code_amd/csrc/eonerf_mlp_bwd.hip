@@ -1,2 +1,244 @@
+// Fused EO-NeRF field backward chain (H10 of SURVEY.md 8a: the autograd of radiance_fields/eonerf.py:154-170).
+// Mirror image of eonerf_mlp_fwd.hip: gradients flow through the layers in reverse as TRANSPOSED register tiles
+// (dX^T = W^T dY^T: A operand = packed W^T streamed through LDS, B operand = the previous accumulators), ReLU
+// derivatives come from the 1-bit masks the forward saved, and every pre-activation gradient dY_l is written
+// feature-major [rows][p_pad] -- the A operand of the weight-gradient GEMM (eonerf_wgrad.hip).
+// INPUT_GRAD (shadow pass): continues through layer 0 / the skip columns of layer 5 and the encoder derivative
+// 2^k cos(2^k x [+ pi/2]) to d sigma / d position (sat_rendering.py:90 keeps depth attached).
+#include "eonerf_common.h"
 #include "eonerf_kernels.h"
-hipError_t eo_launch_mlp_bwd(const MlpBwdArgs&, bool, bool, bool, int, hipStream_t) { return hipErrorNotSupported; }
+
+namespace {
+
+template <class P> EO_DEV __amdgpu_buffer_rsrc_t tile_rsrc(void* slab, size_t ld, int row0, int rows) {
+    uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)row0 * ld * P::ACT_BYTES;
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows * ld * P::ACT_BYTES), 0x00020000);
+}
+template <class P> EO_DEV int tile_voff(size_t ld, int p, int h) {
+    if constexpr (P::IS_BF16) return (int)(((size_t)(4 * h + (p & 1)) * ld + (p & ~1)) * 2);
+    else return (int)(((size_t)(4 * h) * ld + p) * 4);
+}
+EO_DEV void store_tile_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int, const Units32<PF32>& u) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float x = u.u[r >> 2][r & 3];      // copy first: __builtin_bit_cast on a vector ELEMENT reads element 0
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, acc_row(r, 0) * ld * 4, 0);
+    }
+}
+EO_DEV void store_tile_T(PBf16, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int odd, const Units32<PBf16>& u) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32x4 words = __builtin_bit_cast(u32x4, u.u[i >> 2]);
+        const uint32_t w = words[i & 3];
+        const uint32_t nb = __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);
+        const uint32_t o = odd ? __builtin_amdgcn_perm(w, nb, 0x07060302) : __builtin_amdgcn_perm(w, nb, 0x01000504);
+        __builtin_amdgcn_raw_buffer_store_b32(o, rs, voff, acc_row(2 * i, 0) * ld * 2, 0);
+    }
+}
+EO_DEV void store_elem_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff1, int row, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff1, row * ld * 4, 0);
+}
+EO_DEV void store_elem_T(PBf16, __amdgpu_buffer_rsrc_t rs, int ld, int voff1, int row, float v) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), rs, voff1, row * ld * 2, 0);
+}
+
+// k-group whose first (up to 4) features carry `v` on the h==0 lanes (rows 0..3 of a 32-row tile), zero elsewhere
+template <class P> EO_DEV typename P::U small_unit(const float (&v)[4], int h) {
+    typename P::U u = P::zero();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = h == 0 ? v[e] : 0.f;
+        if constexpr (P::IS_BF16) u[e] = (__bf16)x; else u[e] = x;
+    }
+    return u;
+}
+
+template <class P, bool FULL, bool IG>
+__global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
+    constexpr int SLOT = FwdSlot<P>::BYTES;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typedef typename P::U U;
+    constexpr int HKG = 256 / P::KF, QKG = 128 / P::KF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int n_pts = *a.n_pts;
+    const size_t ld = a.p_pad;
+    const int ldi = a.p_pad;
+
+    WStream<P, SLOT> ws;
+    ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks; ws.tid = tid;
+    if ((int)blockIdx.x * P::TILE >= n_pts) return;
+    ws.start();
+
+    for (int tile = blockIdx.x; tile * P::TILE < n_pts; tile += gridDim.x) {
+        const int p = tile * P::TILE + wave * 32 + c;
+        const bool live = p < n_pts;
+        const int voff = tile_voff<P>(ld, p, h);
+        const int voff1 = (int)(((size_t)(4 * h) * ld + p) * P::ACT_BYTES);
+        uint32_t mb[4];
+
+        auto load_mask = [&](int slot, int nwords) {
+            const uint32_t* mp = a.masks + ((size_t)slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4;
+            if (nwords == 4) { const u32x4 v = *reinterpret_cast<const u32x4*>(mp); mb[0] = v[0]; mb[1] = v[1]; mb[2] = v[2]; mb[3] = v[3]; }
+            else { const u32x2 v = *reinterpret_cast<const u32x2*>(mp); mb[0] = v[0]; mb[1] = v[1]; }
+        };
+        // dX tile -> (optional ReLU mask) -> units of the next backward layer + feature-major save for the wgrad GEMM
+        auto grad_epi = [&](auto& dst, int grd_row, bool masked, int mt, const f32x16& accv) {
+            f32x16 v = accv;
+            if (masked) {
+                const uint32_t bits = mb[mt >> 1] >> ((mt & 1) * 16);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = (bits >> r) & 1u ? accv[r] : 0.f;
+            }
+            Units32<P> u = pack_units(P(), v);
+#pragma unroll
+            for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
+            store_tile_T(P(), tile_rsrc<P>(a.grd, ld, grd_row + 32 * mt, 32), ldi, voff, p & 1, u);
+        };
+
+        // ---------------- output heads: activation derivatives from the saved forward outputs ----------------
+        const float sg = live ? a.sigma[p] : 0.f;
+        float dsig[4] = {live ? a.g_sigma[p] * (1.f - expf(-sg)) : 0.f, 0.f, 0.f, 0.f};    // softplus' = 1 - exp(-softplus)
+        store_elem_T(P(), tile_rsrc<P>(a.grd, ld, GRD_ROW_SIG, 8), ldi, voff1, 0, h == 0 ? dsig[0] : 0.f);
+
+        U D[HKG], N[HKG];
+        if constexpr (FULL) {
+            float dalb[4] = {0.f, 0.f, 0.f, 0.f}, dtr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float av = a.albedo[(size_t)k * a.p_pad + p];
+                    dalb[k] = a.g_albedo[(size_t)k * a.p_pad + p] * av * (1.f - av);           // sigmoid'
+                }
+                const float tsv = a.ts[p], tbv = a.tb[p];
+                dtr[0] = a.g_ts[p] * tsv * (1.f - tsv);
+                dtr[1] = a.g_tb[p] * (1.f - expf(-tbv));
+            }
+            {
+                const __amdgpu_buffer_rsrc_t r5 = tile_rsrc<P>(a.grd, ld, GRD_ROW_T5, 8), r2 = tile_rsrc<P>(a.grd, ld, GRD_ROW_A2, 8);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) store_elem_T(P(), r5, ldi, voff1, e, h == 0 ? dtr[e] : 0.f);
+#pragma unroll
+                for (int e = 0; e < 3; ++e) store_elem_T(P(), r2, ldi, voff1, e, h == 0 ? dalb[e] : 0.f);
+            }
+            // ---- transient head backwards: {ts,tb}_pre -> T4 -> T3 -> T2 -> T1 ----
+            U TA[QKG], TB[QKG], DA1[QKG];
+            const U u_tr = small_unit<P>(dtr, h);
+            load_mask(12, 2);
+            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false>(ws, lane, h, [&](int) { return u_tr; },
+                [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v); });
+            load_mask(11, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false>(ws, lane, h, [&](int kg) { return TA[kg]; },
+                [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v); });
+            load_mask(10, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false>(ws, lane, h, [&](int kg) { return TB[kg]; },
+                [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v); });
+            load_mask(9, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false>(ws, lane, h, [&](int kg) { return TA[kg]; },
+                [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1, true, mt, v); });        // TB = dY_T1
+            // ---- albedo head backwards: albedo_pre -> A1 ----
+            const U u_al = small_unit<P>(dalb, h);
+            load_mask(8, 2);
+            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false>(ws, lane, h, [&](int) { return u_al; },
+                [&](int mt, const f32x16& v) { grad_epi(DA1, GRD_ROW_A1, true, mt, v); });
+            // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
+            run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, lane, h,
+                [&](int kg) { return kg < QKG ? DA1[kg < QKG ? kg : 0] : TB[kg >= QKG ? kg - QKG : 0]; },
+                [&](int mt, const f32x16& v) {
+                    if (mt < 8) { grad_epi(N, GRD_ROW_BOTT, false, mt, v); return; }
+                    if (h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
+                });
+            // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
+            const U u_sg = small_unit<P>(dsig, h);
+            load_mask(7, 4);
+            run_layer<P, SLOT, HKG + 1, 8, FwdG<P, HKG + 1, 8>::G, false>(ws, lane, h,
+                [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
+                [&](int mt, const f32x16& v) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v); });
+        } else {
+            const U u_sg = small_unit<P>(dsig, h);
+            load_mask(7, 4);
+            run_layer<P, SLOT, 1, 8, FwdG<P, 1, 8>::G, false>(ws, lane, h, [&](int) { return u_sg; },
+                [&](int mt, const f32x16& v) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v); });
+        }
+
+        // ---------------- trunk backwards: dY_l -> dX_l -> mask(layer l-1) -> dY_{l-1} ----------------
+        f32x16 denc[2];
+        auto trunk_step = [&](auto& src, auto& dst, int l) {      // consumes dY_l, produces dY_{l-1}
+            load_mask(l - 1, 4);
+            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, false>(ws, lane, h, [&](int kg) { return src[kg]; },
+                [&](int mt, const f32x16& v) { grad_epi(dst, GRD_ROW_Y0 + (l - 1) * 256, true, mt, v); });
+        };
+        trunk_step(D, N, 7);
+        trunk_step(N, D, 6);
+        // layer 5 consumed [h, enc]: rows 0..255 go on down the trunk, rows 256..319 are d enc (skip path)
+        load_mask(4, 4);
+        run_layer<P, SLOT, HKG, IG ? 10 : 8, FwdG<P, HKG, IG ? 10 : 8>::G, false>(ws, lane, h, [&](int kg) { return D[kg]; },
+            [&](int mt, const f32x16& v) {
+                if (mt < 8) { grad_epi(N, GRD_ROW_Y0 + 4 * 256, true, mt, v); return; }
+                if constexpr (IG) denc[mt == 8 ? 0 : 1] = v;
+            });
+        trunk_step(N, D, 4);
+        trunk_step(D, N, 3);
+        trunk_step(N, D, 2);
+        trunk_step(D, N, 1);                                        // N = dY_0
+
+        if constexpr (IG) {
+            run_layer<P, SLOT, HKG, 2, FwdG<P, HKG, 2>::G, false>(ws, lane, h, [&](int kg) { return N[kg]; },
+                [&](int mt, const f32x16& v) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) denc[mt == 0 ? 0 : 1][r] += v[r];
+                });
+            // encoder derivative: slot q = 16*t + r of lane half h (see encode_position / enc_col_of_hq)
+            const float x = live ? a.px[p] : 0.f, y = live ? a.py[p] : 0.f, z = live ? a.pz[p] : 0.f;
+            const float off = h ? EO_PI_2_F : 0.0f;
+            float gp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = 16 * t + r;
+                    const float g = denc[t][r];
+                    if (q < 30) {
+                        const int k = q / 3, d = q % 3;
+                        const float cc = d == 0 ? x : (d == 1 ? y : z);
+                        const float arg = cc * (float)(1 << k) + off;
+                        const float dv = (P::IS_BF16 ? __cosf(arg) : cosf(arg)) * (float)(1 << k);
+                        gp[d] += g * dv;
+                    } else if (q == 30) {
+                        if (h) gp[2] += g; else gp[0] += g;
+                    } else {
+                        if (!h) gp[1] += g;
+                    }
+                }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) gp[d] += __shfl_xor(gp[d], 32, 64);       // both halves hold slots of the same sample
+            if (h == 0 && live) {
+                a.g_pos[p] = gp[0]; a.g_pos[(size_t)a.p_pad + p] = gp[1]; a.g_pos[2 * (size_t)a.p_pad + p] = gp[2];
+            }
+        }
+    }
+}
+
+template <class P, bool FULL, bool IG>
+hipError_t launch(const MlpBwdArgs& a, int grid, hipStream_t st) {
+    constexpr int SMEM = 2 * FwdSlot<P>::BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_mlp_bwd<P, FULL, IG>), dim3(grid), dim3(P::NT), SMEM, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// only the two variants the render path needs: camera pass (all heads, no input grad) and shadow pass
+// (density only, with input grad)
+hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, int grid, hipStream_t st) {
+    if (full == input_grad) return hipErrorInvalidValue;
+    if (bf16) return full ? launch<PBf16, true, false>(a, grid, st) : launch<PBf16, false, true>(a, grid, st);
+    return full ? launch<PF32, true, false>(a, grid, st) : launch<PF32, false, true>(a, grid, st);
+}

@@ -53,9 +53,10 @@ template <class P> EO_DEV int tile_voff(size_t ld, int p, int h) {
 // fp32: lane (c,h) stores its value for sample c: 32 lanes -> 128 B contiguous per feature row.
 EO_DEV void store_tile_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int, const Units32<PF32>& u) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u.u[r >> 2][r & 3]), rs, voff,
-                                              acc_row(r, 0) * ld * 4, 0);
+    for (int r = 0; r < 16; ++r) {
+        const float x = u.u[r >> 2][r & 3];      // copy first: __builtin_bit_cast on a vector ELEMENT reads element 0
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, acc_row(r, 0) * ld * 4, 0);
+    }
 }
 // bf16: packed word i holds features (f, f+1) of sample c.  A quad_perm swap with the neighbour lane turns
 // that into (f; samples c,c+1) on even lanes and (f+1; samples c-1,c) on odd lanes: one dword store,

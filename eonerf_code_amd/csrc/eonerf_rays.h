@@ -45,7 +45,50 @@ struct ShadeArgs {
     float* out;                 // [R][21]
 };
 
+struct ShadeBwdArgs {
+    const float *ray_rec, *d_out;
+    const int64_t* img_idx;
+    const float* radiometric;
+    float* d_radiometric;       // inside the flat gradient buffer, or nullptr
+    float* g_ray;               // [R][RAY_REC] gradient of the per-ray record
+    int n_rays, use_shadow, eval;
+};
+
+struct CompositeBwdArgs {
+    const float* rays;
+    const int *offsets, *counts;
+    const float *sigma, *delta, *tmid, *albedo, *ts, *tb;
+    int p_pad, n_rays;
+    const float* ray_rec;
+    float* g_ray;
+    float *g_sigma, *g_albedo, *g_ts, *g_tb;   // per-sample outputs
+    const float* g_pos;                        // sun pass: [3][p_pad] d sigma / d position
+};
+
+struct AmbientBwdArgs {
+    AmbientW w;
+    const float *rays, *ray_rec, *g_ray;
+    int n_rays;
+    float *d_w1, *d_b1, *d_w2, *d_b2;
+};
+
+struct EmbGradArgs {
+    const int *offsets, *counts;
+    const int64_t* img_idx;
+    const float* g_emb;      // [p_pad][4]
+    float* d_emb;            // [n_img][4] inside the flat gradient buffer
+    int n_rays;
+};
+
 hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st);
+hipError_t eo_launch_shade_bwd(const ShadeBwdArgs& a, hipStream_t st);
+hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
+hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st);
+hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
+hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st);
+hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st);
+hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
+                          float gscale, hipStream_t st);
 hipError_t eo_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 hipError_t eo_launch_shade_fwd(const ShadeArgs& a, hipStream_t st);
 hipError_t eo_launch_points_to_soa(const float* xyz, const int64_t* img, int n, int p_pad, float* px, float* py, float* pz,

@@ -1,1 +1,241 @@
+// Backward of the per-ray kernels (H10 of SURVEY.md 8a: autograd of sat_rendering.py:264-306 and of the nerfacc
+// compositing calls at radiance_fields/eonerf.py:229-243, sat_rendering.py:106-116), plus the fused Adam update.
+#include "eonerf_common.h"
 #include "eonerf_rays.h"
+#include "eonerf_rays_dev.h"
+
+namespace {
+
+// ---- shading backward: d out[R,21] -> d ray record, d radiometric table ------------------------------------
+__global__ __launch_bounds__(256) void k_shade_bwd(ShadeBwdArgs a) {
+    const int ray = blockIdx.x * 256 + threadIdx.x;
+    if (ray >= a.n_rays) return;
+    const float* r = a.ray_rec + (size_t)ray * RAY_REC;
+    const float* go = a.d_out + (size_t)ray * 21;
+    float* g = a.g_ray + (size_t)ray * RAY_REC;
+    const float wsum = r[RR_WSUM], ts = r[RR_TS];
+    const float geo = a.use_shadow ? r[RR_GEO] : 1.0f;
+    const float s = a.use_shadow ? geo * ts : 1.0f;
+    const long img = a.eval ? a.img_idx[0] : a.img_idx[ray];
+    const float* T = a.radiometric ? a.radiometric + img * 9 : nullptr;
+    float* dT = a.d_radiometric ? a.d_radiometric + img * 9 : nullptr;
+    float g_s = 0.f, g_wsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float alb = r[RR_ALB + c], head = r[RR_AMB + c];
+        const float amb = (wsum * head) * 0.2f;
+        const float pre = alb * s + (1.f - s) * (amb * alb);
+        const float A = T ? T[c] : 1.f, b = T ? T[3 + c] : 0.f;
+        const float lin = A * pre + b;
+        const float g_lin = (lin >= 0.f && lin <= 1.f) ? go[c] : 0.f;        // torch.clip backward (inclusive bounds)
+        const float g_shl = go[18 + c];
+        if (dT) {
+            atomicAdd(dT + c, g_lin * pre + g_shl * alb);
+            atomicAdd(dT + 3 + c, g_lin + g_shl);
+        }
+        const float g_pre = g_lin * A;
+        g[RR_ALB + c] = g_pre * (s + (1.f - s) * amb) + go[4 + c] + g_shl * A;
+        const float g_amb = g_pre * (1.f - s) * alb + go[7 + c];
+        g_s += g_pre * (alb - amb * alb);
+        g_wsum += g_amb * 0.2f * head;
+        g[RR_AMB + c] = g_amb * 0.2f * wsum;
+    }
+    g[RR_DEPTH] = go[3];
+    g[RR_TS] = (a.use_shadow ? g_s * geo : 0.f) + go[11];
+    g[RR_GEO] = a.use_shadow ? g_s * ts + go[10] : 0.f;
+    g[RR_TB] = go[12];
+    g[RR_WSUM] = g_wsum;
+}
+
+// ---- shadow-ray transmittance backward: geo = exp(-sum_{j<last} sigma_j delta_j) ------------------------------
+__global__ __launch_bounds__(256) void k_sun_composite_bwd(CompositeBwdArgs a) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    const int off = a.offsets[ray], n = a.counts[ray];
+    const float g_geo = a.g_ray[(size_t)ray * RAY_REC + RR_GEO];
+    const float geo = a.ray_rec[(size_t)ray * RAY_REC + RR_GEO];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) a.g_sigma[off + i] = i < n - 1 ? -g_geo * geo * a.delta[off + i] : 0.f;
+    }
+}
+
+// ---- d depth += sum over the ray's shadow samples of <d pos, viewdir>  (origin = o + depth*d, sat_rendering.py:90) --
+__global__ __launch_bounds__(256) void k_sun_depth_grad(CompositeBwdArgs a) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    const int off = a.offsets[ray], n = a.counts[ray];
+    const float* r = a.rays + (size_t)ray * 11;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) {
+            const int p = off + i;
+            acc += a.g_pos[p] * r[3] + a.g_pos[(size_t)a.p_pad + p] * r[4] + a.g_pos[2 * (size_t)a.p_pad + p] * r[5];
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.g_ray[(size_t)ray * RAY_REC + RR_DEPTH] += acc;
+}
+
+// ---- camera compositing backward ---------------------------------------------------------------------------
+//   w_i = T_i (1 - e_i), e_i = exp(-sd_i), T_i = exp(-sum_{j<i} sd_j)
+//   dL/dsd_i = g_w_i T_i e_i - sum_{j>i} g_w_j w_j          dL/dsigma_i = delta_i dL/dsd_i
+__global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    const int off = a.offsets[ray], n = a.counts[ray];
+    const float* g = a.g_ray + (size_t)ray * RAY_REC;
+    const float g_depth = g[RR_DEPTH], g_ts = g[RR_TS], g_tb = g[RR_TB], g_wsum = g[RR_WSUM];
+    const float g_alb[3] = {g[RR_ALB], g[RR_ALB + 1], g[RR_ALB + 2]};
+    const RayWeights rw = ray_weights(a.sigma, a.delta, off, n, lane);
+    float gw_w[2], gw[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        gw[k] = 0.f; gw_w[k] = 0.f;
+        if (i < n) {
+            const int p = off + i;
+            const float w = rw.w[k];
+            const float alb0 = a.albedo[p], alb1 = a.albedo[(size_t)a.p_pad + p], alb2 = a.albedo[2 * (size_t)a.p_pad + p];
+            gw[k] = g_depth * a.tmid[p] + g_alb[0] * alb0 + g_alb[1] * alb1 + g_alb[2] * alb2 + g_ts * a.ts[p] + g_tb * a.tb[p] + g_wsum;
+            gw_w[k] = gw[k] * w;
+            a.g_albedo[p] = w * g_alb[0];
+            a.g_albedo[(size_t)a.p_pad + p] = w * g_alb[1];
+            a.g_albedo[2 * (size_t)a.p_pad + p] = w * g_alb[2];
+            a.g_ts[p] = w * g_ts;
+            a.g_tb[p] = w * g_tb;
+        }
+    }
+    // exclusive suffix sums of g_w*w over the ray (element i = lane + 64k)
+    const float suf1 = wave_suffix_scan(gw_w[1], lane);
+    const float tot1 = __shfl(suf1, 0, 64);
+    const float suf0 = wave_suffix_scan(gw_w[0], lane);
+    const float n1 = __shfl_down(suf1, 1, 64), n0 = __shfl_down(suf0, 1, 64);
+    const float after[2] = {(lane == 63 ? 0.f : n0) + tot1, lane == 63 ? 0.f : n1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) {
+            const int p = off + i;
+            const float e = expf(-rw.sd[k]);
+            a.g_sigma[p] = a.delta[p] * (gw[k] * rw.T[k] * e - after[k]);
+        }
+    }
+}
+
+// ---- ambient head backward (radiance_fields/eonerf.py:132-139): one thread per hidden unit, rays strided over WGs
+__global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
+    const int j = threadIdx.x;
+    float dw1[27], dw2[3] = {0.f, 0.f, 0.f}, db1 = 0.f, db2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 27; ++i) dw1[i] = 0.f;
+    float w1[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) w1[i] = a.w.w1[j * 27 + i];
+    const float b1 = a.w.b1[j];
+    const float w2[3] = {a.w.w2[j], a.w.w2[128 + j], a.w.w2[256 + j]};
+    for (int ray = blockIdx.x; ray < a.n_rays; ray += gridDim.x) {
+        const float* r = a.rays + (size_t)ray * 11;
+        const float* rec = a.ray_rec + (size_t)ray * RAY_REC;
+        const float* g = a.g_ray + (size_t)ray * RAY_REC;
+        float enc[27];
+        sun_encoding(r[8], r[9], r[10], enc);
+        float hid = b1;
+#pragma unroll
+        for (int i = 0; i < 27; ++i) hid = fmaf(w1[i], enc[i], hid);
+        hid = fmaxf(hid, 0.f);
+        float gpre[3], ghid = 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float out = rec[RR_AMB + o];
+            gpre[o] = g[RR_AMB + o] * out * (1.f - out);
+            dw2[o] += gpre[o] * hid;
+            db2[o] += gpre[o];
+            ghid += w2[o] * gpre[o];
+        }
+        if (hid <= 0.f) ghid = 0.f;
+        db1 += ghid;
+#pragma unroll
+        for (int i = 0; i < 27; ++i) dw1[i] += ghid * enc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) atomicAdd(a.d_w1 + j * 27 + i, dw1[i]);
+    atomicAdd(a.d_b1 + j, db1);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) atomicAdd(a.d_w2 + o * 128 + j, dw2[o]);
+    if (j == 0) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) atomicAdd(a.d_b2 + o, db2[o]);
+    }
+}
+
+// ---- transient embedding gradient: per-sample d emb (from the backward chain) summed per ray, added per image ---
+__global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    const int off = a.offsets[ray], n = a.counts[ray];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.g_emb + 4 * (size_t)(off + i));
+            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = wave_sum(acc[e]);
+    if (lane < 4) {
+        const float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+        atomicAdd(a.d_emb + a.img_idx[ray] * 4 + lane, v);
+    }
+}
+
+// ---- torch.optim.Adam (no weight decay, no amsgrad) on the flat buffers --------------------------------------
+__global__ void k_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                       float bc1, float bc2_sqrt, float gscale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+
+hipError_t eo_launch_shade_bwd(const ShadeBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade_bwd, dim3((a.n_rays + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_sun_composite_bwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_sun_depth_grad, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_cam_composite_bwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_ambient_bwd, dim3(a.n_rays < 256 ? a.n_rays : 256), dim3(128), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_emb_grad, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
+                          float gscale, hipStream_t st) {
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale);
+    return hipGetLastError();
+}

@@ -1,0 +1,101 @@
+// Device helpers shared by the per-ray forward and backward kernels.
+#pragma once
+#include "eonerf_common.h"
+#include "eonerf_rays.h"
+
+namespace {
+
+constexpr int RAYS_PER_BLOCK = 4;   // 256 threads
+
+// ---- wave helpers -------------------------------------------------------------------------------------------
+EO_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes
+EO_DEV float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// inclusive SUFFIX scan (sum over lanes >= lane)
+EO_DEV float wave_suffix_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += t;
+    }
+    return v;
+}
+
+// ---- ambient head for one ray, computed by the whole wave (radiance_fields/eonerf.py:132-139,163-164) ------
+struct AmbientRay { float out[3]; float hid[2]; float pre[3]; float enc[27]; };
+
+EO_DEV void sun_encoding(float sx, float sy, float sz, float* enc) {   // mlp.py:190-208, L=4, fp32
+    enc[0] = sx; enc[1] = sy; enc[2] = sz;
+    const float c[3] = {sx, sy, sz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float xb = c[d] * (float)(1 << k);
+            enc[3 + 3 * k + d] = sinf(xb);
+            enc[15 + 3 * k + d] = sinf(xb + EO_PI_2_F);
+        }
+}
+
+EO_DEV AmbientRay ambient_forward(const AmbientW& w, float sx, float sy, float sz, int lane) {
+    AmbientRay r;
+    sun_encoding(sx, sy, sz, r.enc);
+    float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = lane + 64 * k;
+        float acc = w.b1[j];
+        for (int i = 0; i < 27; ++i) acc = fmaf(w.w1[j * 27 + i], r.enc[i], acc);
+        r.hid[k] = fmaxf(acc, 0.f);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) part[o] = fmaf(w.w2[o * 128 + j], r.hid[k], part[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { r.pre[o] = wave_sum(part[o]) + w.b2[o]; r.out[o] = sigmoid_f(r.pre[o]); }
+    return r;
+}
+
+// ---- compositing forward ------------------------------------------------------------------------------------
+//   sd = sigma*delta;  T = exp(-exclusive_sum(sd));  alpha = 1-exp(-sd);  w = T*alpha   (nerfacc v0.5.2 volrend,
+//   call sites radiance_fields/eonerf.py:229-243)            per-ray sums of w*{mid, albedo, ts, tb, 1}
+struct RayWeights { float w[2], T[2], sd[2]; float total; };
+
+EO_DEV RayWeights ray_weights(const float* sigma, const float* delta, int off, int n, int lane) {
+    RayWeights r;
+    float sd[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        sd[k] = i < n ? sigma[off + i] * delta[off + i] : 0.f;
+    }
+    // exclusive prefix = inclusive prefix of the PREVIOUS lane (never "inclusive - self": the last interval has
+    // sigma*delta ~ 1e10 and would cancel the whole prefix)
+    const float inc0 = wave_incl_scan(sd[0], lane);
+    const float tot0 = __shfl(inc0, 63, 64);
+    const float inc1 = wave_incl_scan(sd[1], lane);
+    const float p0 = __shfl_up(inc0, 1, 64), p1 = __shfl_up(inc1, 1, 64);
+    const float ex[2] = {lane == 0 ? 0.f : p0, lane == 0 ? tot0 : tot0 + p1};
+    r.total = tot0 + __shfl(inc1, 63, 64);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        r.sd[k] = sd[k];
+        r.T[k] = expf(-ex[k]);
+        r.w[k] = i < n ? r.T[k] * (1.f - expf(-sd[k])) : 0.f;
+    }
+    return r;
+}
+
+
+}  // namespace
