@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- train rays/sec of the EO-NeRF hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one complete optimisation step on one synthetic ray batch per GPU that is already resident in HBM:
+jitter noise -> render forward (sampler, fused MLP chain, compositing, shading) -> loss -> backward (compositing,
+backward chain, weight-gradient GEMM) -> [RCCL all-reduce of the flat gradient] -> Adam + weight re-pack.
+Workload at every N: BASELINE.json configs[1] -- JAX_068-like synthetic rays, 4096 rays x 128
+samples per GPU, shadow pass off (epoch_idx < 2, MSE loss), bf16 MFMA; `--workload full` runs configs[2]
+(shadow-ray pass + uncertainty loss).  Weak scaling: per-GPU work is fixed, rays are independent units.
+
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (HIP-event timed inside the timed region through
+the library's measurement hooks), `cpu_baseline` is the oracle (CPU port of the reference algorithm) timed on this
+box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+N_IMG = 19            # JAX_068-like
+RAYS = 4096
+STEP_SIZE = 2.0 / 128
+MAC_FWD = 672640      # MACs/sample inside the forward chain kernel: trunk 491,008 + sigma 256 + bottleneck 65,536
+                      #   + albedo 33,152 + transient 82,688  (SURVEY.md 8a H6 minus the per-ray ambient head)
+MAC_BWD = MAC_FWD - 63 * 256          # dX chain: no input gradient on the camera pass
+MAC_WGRAD = MAC_FWD                   # one MAC per weight per sample
+MAC_DENS_FWD = 491008 + 256
+MAC_DENS_BWD = 491008 + 256           # incl. input gradient through layer 0 / skip columns
+PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3
+
+
+def cpu_baseline(workload, n_rays=128, reps=1):
+    """The oracle (CPU restatement of the reference algorithm, torch fp32) timed on the host cores."""
+    from oracle import eonerf_oracle as orc
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))      # more threads only add contention at this batch size
+    epoch = 3 if workload == "full" else 0
+    sd = orc.random_state_dict(N_IMG, seed=42)
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    opt = torch.optim.Adam([v for v in params.values() if v.is_floating_point()], lr=5e-4)
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(n_rays, N_IMG, seed=1234)
+    orc.train_step(params, rays, ts, rgbs, u_cam, u_sun, epoch, STEP_SIZE, opt)        # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.train_step(params, rays, ts, rgbs, u_cam, u_sun, epoch, STEP_SIZE, opt)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} full train steps (render+loss+backward+Adam) of {n_rays} rays x 128 samples, torch CPU fp32, "
+                      f"{dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=("rgb", "full"), default="rgb")
+    ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from eonerf_code_amd.synthetic import synthetic_batch
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    from eonerf_code_amd.trainer import FusedTrainer
+
+    torch.manual_seed(42)                                     # train_eonerf.py:37
+    field = EONerfMLP(N_IMG, radiometric_normalization=True, precision=args.precision).to(dev)
+    trainer = FusedTrainer(field, lr=5e-4, max_rays=RAYS)
+    epoch = 3 if args.workload == "full" else 0
+
+    # a table of synthetic rays resident in HBM; every step takes a different contiguous batch of it
+    n_batches = 8
+    rays, img, rgbs = (t.to(dev) for t in synthetic_batch(RAYS * n_batches, N_IMG, seed=1234 + rank))
+    torch.manual_seed(1000 + rank)
+
+    def one_step(i):
+        b = (i % n_batches) * RAYS
+        return trainer.step(rays[b:b + RAYS], img[b:b + RAYS], rgbs[b:b + RAYS], epoch)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    trainer.profile_enable(args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+
+    prof = trainer.profile_read()
+    n_cam = int(trainer.n_samples.item())
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
+        kernels = {}
+        for name, macs in (("fwd_chain_camera", MAC_FWD), ("bwd_chain_camera", MAC_BWD), ("wgrad_gemm", MAC_WGRAD)):
+            ms, cnt = prof[name]
+            if cnt:
+                kernels[name] = {"avg_ms": ms / cnt, "tflops": 2.0 * macs * n_cam / (ms / cnt * 1e-3) / 1e12}
+        if args.workload == "full":
+            pass   # shadow-pass kernels are reported by --workload full runs through avg_ms only (sample count differs)
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+        macs = {"fwd_chain_camera": MAC_FWD, "bwd_chain_camera": MAC_BWD, "wgrad_gemm": MAC_WGRAD}[dom]
+        achieved = kernels[dom]["tflops"]
+        step_flops = 2.0 * (MAC_FWD + MAC_BWD + MAC_WGRAD) * n_cam
+        result = {
+            "metric": "train rays/sec on JAX_068 (4096 rays x 128 samples)", "value": world * RAYS * args.steps / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": ("JAX_068-like synthetic rays, sigma+albedo path (shadow pass off, epoch<2, MSE), 4096 rays x 128 samples per GPU"
+                                    if args.workload == "rgb" else
+                                    "JAX_068-like synthetic rays, full EO-NeRF (shadow-ray pass + uncertainty loss), 4096 rays x 128 samples per GPU"),
+                       "rays_per_gpu": RAYS, "n_samples": 128, "n_images": N_IMG, "parallelism": f"dp{world}",
+                       "camera_samples_per_step": n_cam, "final_loss": float(loss)},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None,
+                         "algorithmic_flop_per_launch": 2.0 * macs * n_cam, "avg_launch_ms": kernels[dom]["avg_ms"]},
+            "kernels": kernels,
+            "step_mfma_frac": step_flops / (ms_step * 1e-3) / 1e12 / peak,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ F_SHADOWS, F_EVAL, F_TRAIN, F_ONLY_DEPTH = 1, 2, 4, 8
 SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy", "eonerf_param_tensors",
            "eonerf_param_info", "eonerf_param_floats", "eonerf_set_weights", "eonerf_field_workspace_bytes",
            "eonerf_render_workspace_bytes", "eonerf_field_forward", "eonerf_query_density", "eonerf_render_forward",
-           "eonerf_render_backward", "eonerf_adam_step"]
+           "eonerf_render_backward", "eonerf_adam_step", "eonerf_profile_enable", "eonerf_profile_read"]
 
 
 class EonerfConfig(C.Structure):
@@ -69,6 +69,8 @@ def lib():
     L.eonerf_render_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_render_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp]
+    L.eonerf_profile_enable.argtypes = [vp, i]
+    L.eonerf_profile_read.argtypes = [vp, i, C.POINTER(fp), C.POINTER(i)]
     for name in SYMBOLS:
         getattr(L, name)
     _lib = L

@@ -58,6 +58,10 @@ struct eonerf_ctx {
     DevStream fwd_full, fwd_dens, bwd_full, bwd_dens;
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
     bool weights_set = false;
+    // measurement hooks
+    int prof_cap = 0;
+    std::vector<hipEvent_t> prof_ev[5][2];
+    int prof_n[5] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -102,6 +106,14 @@ int pack(const DevStream& d, const float* flat, hipStream_t st) {
     hipLaunchKernelGGL(k_pack32, dim3((d.n32 + 255) / 256), dim3(256), 0, st, flat, d.e32, d.n32, d.data);
     return (int)hipGetLastError();
 }
+
+struct ProfScope {      // brackets one kernel launch with events when profiling is on
+    eonerf_ctx* c; int k; hipStream_t st; bool on;
+    ProfScope(eonerf_ctx* ctx, int kernel, hipStream_t s) : c(ctx), k(kernel), st(s), on(ctx->prof_cap > 0 && ctx->prof_n[kernel] < ctx->prof_cap) {
+        if (on) (void)hipEventRecord(c->prof_ev[k][0][c->prof_n[k]], st);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(c->prof_ev[k][1][c->prof_n[k]], st); c->prof_n[k]++; } }
+};
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int p_cap_of(int n_rays) { return round_up(std::max(n_rays, 1) * 127, 256); }
@@ -153,7 +165,7 @@ AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
     return AmbientW{flat + pl.t[pl.am1_w].offset, flat + pl.t[pl.am1_b].offset, flat + pl.t[pl.am2_w].offset, flat + pl.t[pl.am2_b].offset};
 }
 
-int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_cap, bool full, bool train, hipStream_t st) {
+int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_cap, bool full, bool train, hipStream_t st, int prof_id = -1) {
     const DevStream& ds = full ? ctx->fwd_full : ctx->fwd_dens;
     MlpFwdArgs a;
     a.px = b.px; a.py = b.py; a.pz = b.pz; a.simg = b.simg;
@@ -164,6 +176,8 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     a.act = b.act; a.masks = b.masks;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
+    if (prof_id < 0) return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, train, grid, st);
+    ProfScope ps(ctx, prof_id, st);
     return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, train, grid, st);
 }
 
@@ -212,8 +226,36 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     return EONERF_OK;
 }
 
+int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches) {
+    if (!ctx || max_launches < 0) return EONERF_E_ARG;
+    for (int k = 0; k < 5; ++k) {
+        for (int s = 0; s < 2; ++s) {
+            for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
+            ctx->prof_ev[k][s].clear();
+            for (int i = 0; i < max_launches; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->prof_ev[k][s].push_back(e); }
+        }
+        ctx->prof_n[k] = 0;
+    }
+    ctx->prof_cap = max_launches;
+    return EONERF_OK;
+}
+
+int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launches) {
+    if (!ctx || kernel < 0 || kernel >= 5 || !total_ms || !launches) return EONERF_E_ARG;
+    float sum = 0.f;
+    for (int i = 0; i < ctx->prof_n[kernel]; ++i) {
+        HIP_TRY(hipEventSynchronize(ctx->prof_ev[kernel][1][i]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_ev[kernel][0][i], ctx->prof_ev[kernel][1][i]));
+        sum += ms;
+    }
+    *total_ms = sum; *launches = ctx->prof_n[kernel];
+    return EONERF_OK;
+}
+
 int eonerf_destroy(eonerf_ctx* ctx) {
     if (!ctx) return EONERF_E_ARG;
+    for (int k = 0; k < 5; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
     release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     delete ctx;
@@ -321,7 +363,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     sa.flags = w.flags; sa.n_pts = w.cam.n_pts;
     sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
     HIP_TRY(eo_launch_sampler(sa, st));
-    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !od, train, st);
+    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !od, train, st, 0);
     if (rc) return rc;
     CompositeArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -340,7 +382,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
         ss.n_pts = w.sun.n_pts;
         ss.px = w.sun.px; ss.py = w.sun.py; ss.pz = w.sun.pz; ss.tmid = w.sun.tmid; ss.delta = w.sun.delta; ss.simg = w.sun.simg;
         HIP_TRY(eo_launch_sampler(ss, st));
-        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train, st);
+        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train, st, 3);
         if (rc) return rc;
         CompositeArgs cs = ca;
         cs.offsets = w.sun.offsets; cs.counts = w.sun.counts; cs.sigma = w.sun.sigma; cs.delta = w.sun.delta; cs.tmid = w.sun.tmid;
@@ -401,7 +443,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         ms.stream = ctx->bwd_dens.data; ms.chunks = ctx->bwd_dens.chunks; ms.n_chunks = ctx->bwd_dens.n_chunks;
         ms.sigma = w.sun.sigma; ms.g_sigma = w.sun.g_sigma; ms.masks = w.sun.masks; ms.grd = w.sun.grd;
         ms.px = w.sun.px; ms.py = w.sun.py; ms.pz = w.sun.pz; ms.g_pos = w.sun.g_pos;
-        HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, grid, st));
+        { ProfScope ps(ctx, 4, st); HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, grid, st)); }
         HIP_TRY(eo_launch_sun_depth_grad(cs, st));
     }
 
@@ -417,7 +459,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     mc.sigma = w.cam.sigma; mc.albedo = w.cam.albedo; mc.ts = w.cam.ts; mc.tb = w.cam.tb;
     mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
     mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
-    HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, grid, st));
+    { ProfScope ps(ctx, 1, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, grid, st)); }
 
     // ---- weight gradients: every layer of both passes in one split-K launch -------------------------------
     WgradJobTable tab;
@@ -462,7 +504,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         tab.j[k].wg_count = std::max(1, (target * weight[k] + wsum / 2) / wsum);
         n_wg += tab.j[k].wg_count;
     }
-    HIP_TRY(eo_launch_wgrad(tab, n_wg, p_cap, ctx->bf16, st));
+    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(tab, n_wg, p_cap, ctx->bf16, st)); }
 
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
     EmbGradArgs eg;

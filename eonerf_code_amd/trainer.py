@@ -1,0 +1,110 @@
+"""Fused training step over libeonerf_hip.so -- the loop body of train_eonerf.py:104-161 without autograd plumbing:
+
+    jitter noise -> eonerf_render_forward(TRAIN) -> loss gradient on [R,21] -> eonerf_render_backward
+      -> [RCCL all-reduce of the flat gradient] -> eonerf_adam_step (+ weight re-pack)
+
+One process per GPU; with torch.distributed initialised (backend "nccl" = RCCL over xGMI) the flat fp32 gradient
+(679,821 floats at 20 images, 2.7 MB) is summed across ranks in ONE collective per step and scaled by 1/world inside
+the Adam kernel.  Rays are independent units, so ranks render disjoint ray batches and nothing else is exchanged.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .radiance_fields.eonerf import EONerfMLP, _ptr, _stream
+from .sat_rendering import _zsteps
+
+
+class FusedTrainer:
+    def __init__(self, field: EONerfMLP, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_rays: int = 4096):
+        self.field = field
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.flat = field._ensure_packed()
+        dev = self.flat.device
+        self.d_flat = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        self.L = _lib.lib()
+        self.ctx = field._ctx
+        self.max_rays = max_rays
+        self._ws = {}
+        self.out = torch.empty(max_rays, 21, dtype=torch.float32, device=dev)
+        self.d_out = torch.zeros(max_rays, 21, dtype=torch.float32, device=dev)
+        self.n_samples = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.zsteps = _zsteps(dev)
+        if self.world > 1:     # identical replicas: broadcast rank 0's parameters once (train_eonerf.py has one process)
+            torch.distributed.broadcast(self.flat, src=0)
+            _lib.check(self.L.eonerf_set_weights(self.ctx, _ptr(self.flat), _stream()))
+
+    def set_lr(self, lr):
+        """StepLR(gamma=0.9) is applied by the caller once per epoch (train_eonerf.py:64,304)."""
+        self.lr = lr
+
+    def _workspace(self, n, flags):
+        key = (n, flags)
+        ws = self._ws.get(key)
+        if ws is None:
+            nb = self.L.eonerf_render_workspace_bytes(self.ctx, n, flags)
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.flat.device)
+            self._ws = {key: ws}
+        return ws
+
+    def loss_grad(self, out, pixels, epoch_idx, d_out):
+        """train_eonerf.py:139-143: MSE for epoch < 2, metrics.uncertainty_aware_loss (metrics.py:17-22) afterwards.
+        Writes dL/d out into d_out (only the rgb and beta columns are non-zero); returns the loss (device scalar)."""
+        n = out.shape[0]
+        diff = out[:, 0:3] - pixels
+        if epoch_idx < 2:
+            loss = (diff * diff).mean()
+            d_out[:n, 0:3] = diff * (2.0 / (3 * n))
+            d_out[:n, 12] = 0
+        else:
+            beta = out[:, 12:13]
+            inv_b2 = 1.0 / (beta * beta)
+            loss = (diff * diff * inv_b2).mean() * 0.5 + (3 + torch.log(beta).mean()) * 0.5
+            d_out[:n, 0:3] = diff * inv_b2 * (1.0 / (3 * n))
+            d_out[:n, 12:13] = -(diff * diff).sum(dim=1, keepdim=True) * inv_b2 / beta * (1.0 / (3 * n)) + 0.5 / (n * beta)
+        return loss
+
+    def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False):
+        """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar."""
+        n = rays.shape[0]
+        dev = rays.device
+        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else 0)
+        if noise is None:
+            u = torch.rand(3 if flags & _lib.F_SHADOWS else 2, n, 128, device=dev)
+            u_cam, u_retry, u_sun = u[0], u[1], (u[2] if flags & _lib.F_SHADOWS else None)
+        else:
+            u_cam, u_retry, u_sun = noise
+        ws = self._workspace(n, flags)
+        st = _stream()
+        _lib.check(self.L.eonerf_render_forward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), _ptr(self.zsteps),
+                                                _ptr(u_cam), _ptr(u_retry), _ptr(u_sun), n, flags, _ptr(self.out), _ptr(self.n_samples),
+                                                _ptr(ws), ws.numel(), st))
+        loss = self.loss_grad(self.out[:n], pixels, epoch_idx, self.d_out)
+        self.d_flat.zero_()
+        _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
+                                                 _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
+        if self.world > 1:
+            torch.distributed.all_reduce(self.d_flat, op=torch.distributed.ReduceOp.SUM)
+        self.step_count += 1
+        _lib.check(self.L.eonerf_adam_step(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world, st))
+        self.field._packed_version = tuple(p._version for p in self.field.parameters())   # adam_step re-packed the weights
+        return loss
+
+    # ---- measurement hooks ----
+    def profile_enable(self, max_launches):
+        _lib.check(self.L.eonerf_profile_enable(self.ctx, max_launches))
+
+    def profile_read(self):
+        names = ("fwd_chain_camera", "bwd_chain_camera", "wgrad_gemm", "fwd_chain_sun", "bwd_chain_sun")
+        res = {}
+        for k, name in enumerate(names):
+            ms, cnt = C.c_float(), C.c_int()
+            _lib.check(self.L.eonerf_profile_read(self.ctx, k, C.byref(ms), C.byref(cnt)))
+            res[name] = (ms.value, cnt.value)
+        return res

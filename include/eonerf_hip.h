@@ -99,6 +99,13 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat_params, const floa
 int eonerf_adam_step(eonerf_ctx* ctx, float* flat_params, const float* d_flat_params, float* exp_avg, float* exp_avg_sq,
                      int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* Measurement hooks (no reference counterpart): with profiling enabled every launch of the three MFMA kernels is
+ * bracketed by hipEvents on the caller's stream.  kernel: 0 = forward chain (camera), 1 = backward chain (camera),
+ * 2 = weight-gradient GEMM, 3 = forward chain (shadow pass), 4 = backward chain (shadow pass).
+ * eonerf_profile_read synchronises on the recorded events and returns the summed duration and launch count. */
+int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches_per_kernel);
+int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launches);
+
 const char* eonerf_strerror(int code);
 int eonerf_version(void);
 
