@@ -16,6 +16,24 @@ from .radiance_fields.eonerf import EONerfMLP, _ptr, _stream
 from .sat_rendering import _zsteps
 
 
+def reduce_gradients(d_flat):
+    """The ONE exchange step of data-parallel training: sum the flat fp32 gradient over all ranks (RCCL on GPUs, gloo in
+    the CPU tests).  Returns the factor the optimizer must scale it by (1/world: every rank holds the mean-loss gradient
+    of its own equally-sized batch, so the mean over ranks is the gradient of the global-batch mean loss)."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1.0
+    dist.all_reduce(d_flat, op=dist.ReduceOp.SUM)
+    return 1.0 / dist.get_world_size()
+
+
+def rank_slice(n_total, rank, world):
+    """Contiguous share of a shared permutation that rank `rank` consumes (equal sizes; the tail is dropped as
+    DataLoader(drop_last) would)."""
+    per = n_total // world
+    return rank * per, (rank + 1) * per
+
+
 class FusedTrainer:
     def __init__(self, field: EONerfMLP, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_rays: int = 4096):
         self.field = field
@@ -88,11 +106,10 @@ class FusedTrainer:
         self.d_flat.zero_()
         _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
                                                  _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
-        if self.world > 1:
-            torch.distributed.all_reduce(self.d_flat, op=torch.distributed.ReduceOp.SUM)
+        gscale = reduce_gradients(self.d_flat)
         self.step_count += 1
         _lib.check(self.L.eonerf_adam_step(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world, st))
+                                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, gscale, st))
         self.field._packed_version = tuple(p._version for p in self.field.parameters())   # adam_step re-packed the weights
         return loss
 

@@ -1,0 +1,58 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange step (eonerf_code_amd.trainer.reduce_gradients) turns per-rank
+mean-loss gradients of disjoint ray batches into the gradient of the global-batch mean loss.
+The per-rank gradients come from the oracle here (no GPU); on the GPU box the same function reduces the HIP path's
+flat gradient over RCCL."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from oracle import eonerf_oracle as orc
+
+STEP = 2.0 / 128
+N_IMG, R = 3, 8
+
+
+def flat_grad(sd, rays, ts, rgbs, u_cam, u_sun, epoch):
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    orc.train_step(params, rays, ts, rgbs, u_cam, u_sun, epoch, STEP)
+    return torch.cat([(v.grad if v.grad is not None else torch.zeros_like(v)).reshape(-1)
+                      for k, v in params.items() if v.is_floating_point()])
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from eonerf_code_amd.trainer import reduce_gradients, rank_slice
+    sd = orc.random_state_dict(N_IMG, seed=5)
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R * world, N_IMG, seed=6)
+    a, b = rank_slice(R * world, rank, world)
+    g = flat_grad(sd, rays[a:b], ts[a:b], rgbs[a:b], u_cam[a:b], u_sun[a:b], 0)
+    scale = reduce_gradients(g)
+    torch.save((g * scale), os.path.join(out_dir, f"g{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_mean_equals_global_batch_gradient(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    assert torch.equal(g0, g1), "every rank must hold the same reduced gradient"
+    torch.set_num_threads(4)
+    sd = orc.random_state_dict(N_IMG, seed=5)
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R * 2, N_IMG, seed=6)
+    ref = flat_grad(sd, rays, ts, rgbs, u_cam, u_sun, 0)
+    assert torch.allclose(g0, ref, atol=1e-6 * ref.abs().max().item() + 1e-9, rtol=1e-4)
+
+
+def test_rank_slices_are_disjoint_and_equal():
+    from eonerf_code_amd.trainer import rank_slice
+    spans = [rank_slice(4099, r, 8) for r in range(8)]
+    assert all(b - a == 512 for a, b in spans)
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(7))
