@@ -465,12 +465,14 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     WgradJobTable tab;
     tab.n = 0;
     std::vector<int> weight;
-    const size_t ab = ctx->bf16 ? 2 : 4;
-    auto rows = [&](const void* slab, int row) { return reinterpret_cast<const uint8_t*>(slab) + (size_t)row * p_cap * ab; };
+    auto rows = [&](const void* slab, int row) { return reinterpret_cast<const uint8_t*>(slab) + (size_t)row * SEG_B; };
     auto add = [&](const PassBuffers& b, int grd_row, int m_rows, int act_row, int n_rows, float* dw, int dw_ld, float* db,
                    const int* cmap, int gm, int gn, int wm, int wn) {
         WgradJob& j = tab.j[tab.n++];
+        const bool full = &b == &w.cam;
         j.a = rows(b.grd, grd_row); j.b = rows(b.act, act_row); j.dw = dw; j.db = db; j.col_map = cmap; j.n_pts = b.n_pts;
+        j.a_stride = (uint32_t)((full ? GRD_ROWS_FULL : GRD_ROWS_DENSITY) * SEG_B);
+        j.b_stride = (uint32_t)((full ? ACT_ROWS_FULL : ACT_ROWS_DENSITY) * SEG_B);
         j.m_rows = m_rows; j.n_rows = n_rows; j.dw_ld = dw_ld; j.gm = gm; j.gn = gn; j.wm = wm; j.wn = wn;
         weight.push_back(wm * wn + 1);
     };
@@ -495,16 +497,14 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     add(w.cam, GRD_ROW_T5, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);
     add(w.cam, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
     if (shadows) trunk_jobs(w.sun);
-    int wsum = 0;
-    for (int v : weight) wsum += v;
-    const int target = 2 * ctx->n_cu;
-    int n_wg = 0;
-    for (int k = 0; k < tab.n; ++k) {
-        tab.j[k].wg_begin = n_wg;
-        tab.j[k].wg_count = std::max(1, (target * weight[k] + wsum / 2) / wsum);
-        n_wg += tab.j[k].wg_count;
-    }
-    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(tab, n_wg, p_cap, ctx->bf16, st)); }
+    // heaviest jobs first (longest-processing-time order for the work queue)
+    std::vector<int> order(tab.n);
+    for (int k = 0; k < tab.n; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+    WgradJobTable sorted;
+    sorted.n = tab.n; sorted.slices = 48;
+    for (int k = 0; k < tab.n; ++k) sorted.j[k] = tab.j[order[k]];
+    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(sorted, ctx->n_cu, p_cap, w.flags + 2, ctx->bf16, st)); }
 
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
     EmbGradArgs eg;

@@ -177,6 +177,61 @@ EO_DEV void run_layer(WStream<P, SLOT>& ws, int lane, int h, const BArr& B, Epi&
 }
 
 // ------------------------------------------------------------------------------------------------
+// Saved-activation / saved-gradient slabs: TILED feature-major layout  [sample tile][feature row][64 B]
+//   one 64-byte segment = one feature row of one sample tile (bf16: 32 samples = the samples of one wave;
+//   fp32: 16 samples).  The chain kernels write whole segments; the weight-gradient GEMM's K step reads
+//   ONE contiguous rows x 64 B region per operand (DRAM-page friendly, unlike rows 1 MB apart).
+// ------------------------------------------------------------------------------------------------
+constexpr int SEG_B = 64;
+template <class P> struct Slab {
+    static constexpr int TSAMP = SEG_B / P::ACT_BYTES;     // samples per segment
+    static constexpr int WAVE_TILES = 32 / TSAMP;          // sample tiles covered by one wave (bf16 1, fp32 2)
+};
+// descriptor of the sample tile(s) of the wave whose first sample is wave_p0
+template <class P> EO_DEV __amdgpu_buffer_rsrc_t slab_rsrc(void* slab, int rows, int wave_p0) {
+    uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)(wave_p0 / Slab<P>::TSAMP) * rows * SEG_B;
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * SEG_B * Slab<P>::WAVE_TILES, 0x00020000);
+}
+// per-lane byte offsets: `voff` for 32-row accumulator tiles, `voff1` for single elements (row 4h + r)
+template <class P> EO_DEV int slab_voff(int rows, int c, int h) {
+    if constexpr (P::IS_BF16) return (4 * h + (c & 1)) * SEG_B + (c & ~1) * 2;       // see store_tile_T(PBf16)
+    else return (c >> 4) * rows * SEG_B + 4 * h * SEG_B + (c & 15) * 4;
+}
+template <class P> EO_DEV int slab_voff1(int rows, int c, int h) {
+    if constexpr (P::IS_BF16) return 4 * h * SEG_B + c * 2;
+    else return (c >> 4) * rows * SEG_B + 4 * h * SEG_B + (c & 15) * 4;
+}
+// fp32: lane (c,h) stores its value for sample c: 16 lanes -> one 64-B segment per feature row.
+EO_DEV void store_tile_T(PF32, __amdgpu_buffer_rsrc_t rs, int row0, int voff, int, const Units32<PF32>& u) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float x = u.u[r >> 2][r & 3];      // copy first: __builtin_bit_cast on a vector ELEMENT reads element 0
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, (row0 + acc_row(r, 0)) * SEG_B, 0);
+    }
+}
+// bf16: packed word i holds features (f, f+1) of sample c.  A quad_perm swap with the neighbour lane turns that into
+// (f; samples c,c+1) on even lanes and (f+1; samples c-1,c) on odd lanes: one dword store per lane, 16 lanes = one
+// whole 64-B segment per feature row.
+EO_DEV void store_tile_T(PBf16, __amdgpu_buffer_rsrc_t rs, int row0, int voff, int odd, const Units32<PBf16>& u) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32x4 words = __builtin_bit_cast(u32x4, u.u[i >> 2]);
+        const uint32_t w = words[i & 3];
+        const uint32_t nb = __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);          // lane ^ 1
+        // even: {own.lo, nb.lo}   odd: {nb.hi, own.hi}   (v_perm_b32 bytes: src0=w -> 4..7, src1=nb -> 0..3)
+        const uint32_t o = odd ? __builtin_amdgcn_perm(w, nb, 0x07060302) : __builtin_amdgcn_perm(w, nb, 0x01000504);
+        __builtin_amdgcn_raw_buffer_store_b32(o, rs, voff, (row0 + acc_row(2 * i, 0)) * SEG_B, 0);
+    }
+}
+// single element per lane: row (+4h through voff1)
+EO_DEV void store_elem_T(PF32, __amdgpu_buffer_rsrc_t rs, int voff1, int row, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff1, row * SEG_B, 0);
+}
+EO_DEV void store_elem_T(PBf16, __amdgpu_buffer_rsrc_t rs, int voff1, int row, float v) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), rs, voff1, row * SEG_B, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Activation functions (PyTorch semantics: Softplus beta=1 threshold=20; Sigmoid)
 // ------------------------------------------------------------------------------------------------
 EO_DEV float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }

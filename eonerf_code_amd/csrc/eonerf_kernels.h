@@ -29,7 +29,7 @@ constexpr int MASK_SLOTS_FULL = 13;                 // trunk 0..7, A1, T1..T4
 constexpr int MASK_SLOTS_DENSITY = 8;
 
 // LDS slot (one packed weight chunk) and chunk grouping
-template <class P> struct FwdSlot { static constexpr int KG_TARGET = P::IS_BF16 ? 20 : 40; static constexpr int BYTES = KG_TARGET * 1024 + 1024; };
+template <class P> struct FwdSlot { static constexpr int KG_TARGET = 40; static constexpr int BYTES = KG_TARGET * 1024 + 1024; };
 template <class P, int KG, int MT> struct FwdG {
     static constexpr int pick() {
         int best = 1;
@@ -40,7 +40,7 @@ template <class P, int KG, int MT> struct FwdG {
 };
 __host__ __device__ constexpr int pick_group(bool bf16, int kg, int mt) {
     int best = 1;
-    const int target = bf16 ? 20 : 40;
+    const int target = 40; (void)bf16;
     for (int g = 1; g <= mt; ++g) if (mt % g == 0 && g * kg <= target && g <= 8) best = g;
     return best;
 }
@@ -76,8 +76,9 @@ struct MlpBwdArgs {
 
 // One weight-gradient GEMM job:  dW[m][col_map[n]] += sum_p  dY^T[m][p] * X^T[n][p]
 struct WgradJob {
-    const void* a;        // dY^T rows (leading dimension p_pad)
-    const void* b;        // X^T rows
+    const void* a;        // dY^T: first row of the job inside sample tile 0 of the gradient slab
+    const void* b;        // X^T : first row of the job inside sample tile 0 of the activation slab
+    uint32_t a_stride, b_stride;   // bytes between consecutive sample tiles (= slab rows x 64)
     float* dw;            // destination inside the flat gradient buffer
     float* db;            // bias gradient or nullptr
     const int* col_map;   // nullptr = identity; -1 entries are dropped
@@ -85,11 +86,10 @@ struct WgradJob {
     int m_rows, n_rows;   // valid rows of a / b
     int dw_ld;            // row stride of dw
     int gm, gn, wm, wn;   // wave grid and tiles per wave: (gm*wm*32) x (gn*wn*32) >= m_rows x n_rows
-    int wg_begin, wg_count;   // workgroups [wg_begin, wg_begin+wg_count) split the sample range
 };
 
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, bool train, int grid, hipStream_t st);
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, int grid, hipStream_t st);
 constexpr int WGRAD_MAX_JOBS = 40;
-struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; };     // passed by value in the kernel-argument segment
-hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, bool bf16, hipStream_t st);
+struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int slices; };   // by value in the kernel-argument segment; jobs sorted heaviest first
+hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st);

@@ -10,38 +10,6 @@
 
 namespace {
 
-template <class P> EO_DEV __amdgpu_buffer_rsrc_t tile_rsrc(void* slab, size_t ld, int row0, int rows) {
-    uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)row0 * ld * P::ACT_BYTES;
-    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows * ld * P::ACT_BYTES), 0x00020000);
-}
-template <class P> EO_DEV int tile_voff(size_t ld, int p, int h) {
-    if constexpr (P::IS_BF16) return (int)(((size_t)(4 * h + (p & 1)) * ld + (p & ~1)) * 2);
-    else return (int)(((size_t)(4 * h) * ld + p) * 4);
-}
-EO_DEV void store_tile_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int, const Units32<PF32>& u) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float x = u.u[r >> 2][r & 3];      // copy first: __builtin_bit_cast on a vector ELEMENT reads element 0
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, acc_row(r, 0) * ld * 4, 0);
-    }
-}
-EO_DEV void store_tile_T(PBf16, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int odd, const Units32<PBf16>& u) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const u32x4 words = __builtin_bit_cast(u32x4, u.u[i >> 2]);
-        const uint32_t w = words[i & 3];
-        const uint32_t nb = __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);
-        const uint32_t o = odd ? __builtin_amdgcn_perm(w, nb, 0x07060302) : __builtin_amdgcn_perm(w, nb, 0x01000504);
-        __builtin_amdgcn_raw_buffer_store_b32(o, rs, voff, acc_row(2 * i, 0) * ld * 2, 0);
-    }
-}
-EO_DEV void store_elem_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff1, int row, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff1, row * ld * 4, 0);
-}
-EO_DEV void store_elem_T(PBf16, __amdgpu_buffer_rsrc_t rs, int ld, int voff1, int row, float v) {
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), rs, voff1, row * ld * 2, 0);
-}
-
 // k-group whose first (up to 4) features carry `v` on the h==0 lanes (rows 0..3 of a 32-row tile), zero elsewhere
 template <class P> EO_DEV typename P::U small_unit(const float (&v)[4], int h) {
     typename P::U u = P::zero();
@@ -62,8 +30,6 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int n_pts = *a.n_pts;
-    const size_t ld = a.p_pad;
-    const int ldi = a.p_pad;
 
     WStream<P, SLOT> ws;
     ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks; ws.tid = tid;
@@ -73,8 +39,9 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     for (int tile = blockIdx.x; tile * P::TILE < n_pts; tile += gridDim.x) {
         const int p = tile * P::TILE + wave * 32 + c;
         const bool live = p < n_pts;
-        const int voff = tile_voff<P>(ld, p, h);
-        const int voff1 = (int)(((size_t)(4 * h) * ld + p) * P::ACT_BYTES);
+        constexpr int GROWS = FULL ? GRD_ROWS_FULL : GRD_ROWS_DENSITY;
+        const __amdgpu_buffer_rsrc_t grs = slab_rsrc<P>(a.grd, GROWS, tile * P::TILE + wave * 32);
+        const int voff = slab_voff<P>(GROWS, c, h), voff1 = slab_voff1<P>(GROWS, c, h);
         uint32_t mb[4];
 
         auto load_mask = [&](int slot, int nwords) {
@@ -93,13 +60,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             Units32<P> u = pack_units(P(), v);
 #pragma unroll
             for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
-            store_tile_T(P(), tile_rsrc<P>(a.grd, ld, grd_row + 32 * mt, 32), ldi, voff, p & 1, u);
+            store_tile_T(P(), grs, grd_row + 32 * mt, voff, c & 1, u);
         };
 
         // ---------------- output heads: activation derivatives from the saved forward outputs ----------------
         const float sg = live ? a.sigma[p] : 0.f;
         float dsig[4] = {live ? a.g_sigma[p] * (1.f - expf(-sg)) : 0.f, 0.f, 0.f, 0.f};    // softplus' = 1 - exp(-softplus)
-        store_elem_T(P(), tile_rsrc<P>(a.grd, ld, GRD_ROW_SIG, 8), ldi, voff1, 0, h == 0 ? dsig[0] : 0.f);
+        store_elem_T(P(), grs, voff1, GRD_ROW_SIG, h == 0 ? dsig[0] : 0.f);
 
         U D[HKG], N[HKG];
         if constexpr (FULL) {
@@ -114,13 +81,10 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 dtr[0] = a.g_ts[p] * tsv * (1.f - tsv);
                 dtr[1] = a.g_tb[p] * (1.f - expf(-tbv));
             }
-            {
-                const __amdgpu_buffer_rsrc_t r5 = tile_rsrc<P>(a.grd, ld, GRD_ROW_T5, 8), r2 = tile_rsrc<P>(a.grd, ld, GRD_ROW_A2, 8);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) store_elem_T(P(), r5, ldi, voff1, e, h == 0 ? dtr[e] : 0.f);
+            for (int e = 0; e < 2; ++e) store_elem_T(P(), grs, voff1, GRD_ROW_T5 + e, h == 0 ? dtr[e] : 0.f);
 #pragma unroll
-                for (int e = 0; e < 3; ++e) store_elem_T(P(), r2, ldi, voff1, e, h == 0 ? dalb[e] : 0.f);
-            }
+            for (int e = 0; e < 3; ++e) store_elem_T(P(), grs, voff1, GRD_ROW_A2 + e, h == 0 ? dalb[e] : 0.f);
             // ---- transient head backwards: {ts,tb}_pre -> T4 -> T3 -> T2 -> T1 ----
             U TA[QKG], TB[QKG], DA1[QKG];
             const U u_tr = small_unit<P>(dtr, h);

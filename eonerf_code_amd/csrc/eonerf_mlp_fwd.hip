@@ -38,48 +38,6 @@ EO_DEV EncUnits<P> encode_position(float x, float y, float z, int h) {
     return E;
 }
 
-// ---- saving activations feature-major for the weight-gradient GEMM ---------------------------------------
-// All saves go through buffer stores: SGPR descriptor of the 32-row tile + scalar row offset + one per-lane
-// voffset that is constant for the whole sample tile (no 64-bit per-store address arithmetic in VGPRs).
-template <class P> EO_DEV __amdgpu_buffer_rsrc_t tile_rsrc(void* slab, size_t ld, int row0, int rows) {
-    uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)row0 * ld * P::ACT_BYTES;
-    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows * ld * P::ACT_BYTES), 0x00020000);
-}
-// per-lane byte offset inside a 32-row tile: fp32 -> (4h, p);  bf16 -> (4h + (p&1), p & ~1)  (see below)
-template <class P> EO_DEV int tile_voff(size_t ld, int p, int h) {
-    if constexpr (P::IS_BF16) return (int)(((size_t)(4 * h + (p & 1)) * ld + (p & ~1)) * 2);
-    else return (int)(((size_t)(4 * h) * ld + p) * 4);
-}
-// fp32: lane (c,h) stores its value for sample c: 32 lanes -> 128 B contiguous per feature row.
-EO_DEV void store_tile_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int, const Units32<PF32>& u) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float x = u.u[r >> 2][r & 3];      // copy first: __builtin_bit_cast on a vector ELEMENT reads element 0
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, acc_row(r, 0) * ld * 4, 0);
-    }
-}
-// bf16: packed word i holds features (f, f+1) of sample c.  A quad_perm swap with the neighbour lane turns
-// that into (f; samples c,c+1) on even lanes and (f+1; samples c-1,c) on odd lanes: one dword store,
-// 16 lanes -> 64 B contiguous per feature row.
-EO_DEV void store_tile_T(PBf16, __amdgpu_buffer_rsrc_t rs, int ld, int voff, int odd, const Units32<PBf16>& u) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const u32x4 words = __builtin_bit_cast(u32x4, u.u[i >> 2]);
-        const uint32_t w = words[i & 3];
-        const uint32_t nb = __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);          // lane ^ 1
-        // even: {own.lo, nb.lo}   odd: {nb.hi, own.hi}   (v_perm_b32 bytes: src0=w -> 4..7, src1=nb -> 0..3)
-        const uint32_t o = odd ? __builtin_amdgcn_perm(w, nb, 0x07060302) : __builtin_amdgcn_perm(w, nb, 0x01000504);
-        __builtin_amdgcn_raw_buffer_store_b32(o, rs, voff, acc_row(2 * i, 0) * ld * 2, 0);
-    }
-}
-// single element per lane (encoding / embedding rows): row = row_in_tile (+4h via voff1)
-EO_DEV void store_elem_T(PF32, __amdgpu_buffer_rsrc_t rs, int ld, int voff1, int row, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff1, row * ld * 4, 0);
-}
-EO_DEV void store_elem_T(PBf16, __amdgpu_buffer_rsrc_t rs, int ld, int voff1, int row, __bf16 v) {
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rs, voff1, row * ld * 2, 0);
-}
-
 template <class P, bool FULL, bool TRAIN>
 __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
     constexpr int SLOT = FwdSlot<P>::BYTES;
@@ -91,7 +49,6 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int n_pts = *a.n_pts;
-    const size_t ld = a.p_pad;
 
     WStream<P, SLOT> ws;
     ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks; ws.tid = tid;
@@ -103,15 +60,15 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         const bool live = p < n_pts;
         const float x = live ? a.px[p] : 0.f, y = live ? a.py[p] : 0.f, z = live ? a.pz[p] : 0.f;
         const EncUnits<P> E = encode_position<P>(x, y, z, h);
-        const int ldi = a.p_pad;
-        const int voff = tile_voff<P>(ld, p, h);                       // 32-row tiles
-        const int voff1 = (int)(((size_t)(4 * h) * ld + p) * P::ACT_BYTES);   // one element per lane
+        constexpr int AROWS = FULL ? ACT_ROWS_FULL : ACT_ROWS_DENSITY;
+        const int wave_p0 = tile * P::TILE + wave * 32;
+        const __amdgpu_buffer_rsrc_t ars = slab_rsrc<P>(a.act, AROWS, wave_p0);      // this wave's sample tile(s) of the slab
+        const int voff = slab_voff<P>(AROWS, c, h), voff1 = slab_voff1<P>(AROWS, c, h);
         if constexpr (TRAIN) {   // encoding slots, rows [0,64) of the activation slab
-            const __amdgpu_buffer_rsrc_t rs = tile_rsrc<P>(a.act, ld, ACT_ROW_ENC, 64);
 #pragma unroll
             for (int kg = 0; kg < EKG; ++kg)
 #pragma unroll
-                for (int e = 0; e < P::NE; ++e) store_elem_T(P(), rs, ldi, voff1, P::feat(kg, 0, e), E.u[kg][e]);
+                for (int e = 0; e < P::NE; ++e) store_elem_T(P(), ars, voff1, ACT_ROW_ENC + P::feat(kg, 0, e), (float)E.u[kg][e]);
         }
 
         U H[HKG], N[HKG];
@@ -130,7 +87,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m |= (accv[r] > 0.f) ? (1u << r) : 0u;
                 if (mt & 1) mbits[mt >> 1] |= m << 16; else mbits[mt >> 1] = m;
-                store_tile_T(P(), tile_rsrc<P>(a.act, ld, act_row + 32 * mt, 32), ldi, voff, p & 1, u);
+                store_tile_T(P(), ars, act_row + 32 * mt, voff, c & 1, u);
             }
         };
         auto save_mask = [&](int mask_slot, int nwords) {
@@ -176,7 +133,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                     Units32<P> u = pack_units(P(), v);
 #pragma unroll
                     for (int s = 0; s < P::KG32; ++s) H[(mt - 1) * P::KG32 + s] = u.u[s];
-                    if constexpr (TRAIN) store_tile_T(P(), tile_rsrc<P>(a.act, ld, ACT_ROW_BOTT + 32 * (mt - 1), 32), ldi, voff, p & 1, u);
+                    if constexpr (TRAIN) store_tile_T(P(), ars, ACT_ROW_BOTT + 32 * (mt - 1), voff, c & 1, u);
                 });
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
 
@@ -203,9 +160,8 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                 for (int e = 0; e < 4; ++e) { if constexpr (P::IS_BF16) EMB[e] = (__bf16)ev[e]; else EMB[e] = ev[e]; }
             }
             if constexpr (TRAIN) {
-                const __amdgpu_buffer_rsrc_t rs = tile_rsrc<P>(a.act, ld, ACT_ROW_EMB, 8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) store_elem_T(P(), rs, ldi, voff1, e, EMB[e]);
+                for (int e = 0; e < 4; ++e) store_elem_T(P(), ars, voff1, ACT_ROW_EMB + e, (float)EMB[e]);
             }
             U T1[QKG], T2[QKG];
             run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true>(ws, lane, h,

@@ -4,9 +4,11 @@
 // this is an "NT" GEMM whose contraction runs over the ~5e5 samples of a batch and whose output is tiny: every
 // workgroup owns a whole (<= 256 x 256) output tile in registers for a slice of the sample range (split-K over
 // workgroups, all layers of both passes in ONE launch) and flushes it with fp32 atomics at the end.
-// LDS tiles: [rows][128 B] (bf16: 64 samples, fp32: 32 samples), 16-B chunks XOR-swizzled by (row>>1)&7 so that the
-// ds_read_b128 operand reads (16 different rows per lane group) are bank-conflict free; register-staged double
-// buffering (global -> VGPR early, VGPR -> LDS after the MFMAs, one barrier per K step).
+// The kernel is HBM-bound (131 FLOP/B: ~650 TFLOP/s at 5 TB/s), so the loop is built to keep bytes in flight: a 4-slot LDS
+// ring filled by LDS-DMA (buffer_load_dwordx4 ... lds, no staging registers), three K steps (96 KiB) outstanding per CU
+// behind a COUNTED s_waitcnt vmcnt, one raw s_barrier per step.  LDS tiles are [rows][64 B] (bf16: 32 samples, fp32:
+// 16), 16-B chunks XOR-swizzled through the per-lane SOURCE address so the ds_read_b128 operand reads are
+// bank-conflict free.
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
 
@@ -14,59 +16,70 @@ namespace {
 
 constexpr int WG_NT = 512;
 constexpr int MAX_ROWS = 256;
-constexpr int ROW_B = 128;                       // bytes per LDS row
-constexpr int TILE_B = MAX_ROWS * ROW_B;         // 32 KiB per operand buffer
+constexpr int ROW_B = SEG_B;                     // bytes per LDS row per K step = one slab segment (bf16: 32 samples, fp32: 16)
+constexpr int OPND_B = MAX_ROWS * ROW_B;         // 16 KiB per operand per ring slot
+constexpr int SLOT_B = 2 * OPND_B;               // A + B
+constexpr int NS = 4;                            // ring slots (128 KiB)
+constexpr int DEPTH = NS - 1;                    // K steps in flight ahead of the one being multiplied
 constexpr int WMAX = 4, NMAX = 2;
+constexpr int GLDS_PER_STEP = 4;                 // per wave: 2 x 16 rows of A, 2 x 16 rows of B
 
-EO_DEV int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) * 16; }
+// 16-B chunk c of row `row` lives at chunk position c ^ ((row >> 2) & 3): a ds_read_b128 lane group (16 rows, one
+// chunk) then covers all 64 banks exactly once
+EO_DEV int wg_swz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }
 
 template <class P>
-__global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_pad) {
+__global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_pad, int* queue) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef typename P::U U;
     constexpr int BK = ROW_B / P::ACT_BYTES;             // samples per K step
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, r = lane & 31;
+    int* const lds_item = reinterpret_cast<int*>(smem + NS * SLOT_B);
 
-    int ji = 0;
-    for (int j = 0; j < tab.n; ++j) if ((int)blockIdx.x >= tab.j[j].wg_begin) ji = j;
-    const WgradJob job = tab.j[ji];
-    const int w = blockIdx.x - job.wg_begin;
+  // Work items = (job, slice of the job's K steps), heaviest jobs first; persistent workgroups pull them from one
+  // global counter, so slow (latency-bound, few-row) jobs and fast ones balance without any host-side cost model.
+  for (;;) {
+    __syncthreads();                                    // previous item fully consumed (LDS ring + lds_item)
+    if (tid == 0) *lds_item = atomicAdd(queue, 1);
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(*lds_item);
+    if (item >= tab.n * tab.slices) return;
+    const WgradJob job = tab.j[item / tab.slices];
+    const int w = item % tab.slices;
     const int n_pts = *job.n_pts;
     const int n_pad = (n_pts + P::TILE - 1) / P::TILE * P::TILE;
     const int steps = n_pad / BK;
-    const int s0 = (int)((long long)w * steps / job.wg_count), s1 = (int)((long long)(w + 1) * steps / job.wg_count);
-    if (s0 >= s1) return;
+    const int s0 = (int)((long long)w * steps / tab.slices), s1 = (int)((long long)(w + 1) * steps / tab.slices);
+    if (s0 >= s1) continue;
 
     const int wm = job.wm, wn = job.wn, gn = job.gn;
-    const int a_rows = job.gm * wm * 32, b_rows = gn * wn * 32;
     const bool active = wid < job.gm * gn;
     const int wm_idx = wid / gn, wn_idx = wid % gn;
 
-    uint8_t* lds_a = smem;                      // [2][TILE_B]
-    uint8_t* lds_b = smem + 2 * TILE_B;         // [2][TILE_B]
-
-    // ---- staging: thread -> (row = tid/8 + 64*pass, 16-B chunk = tid%8) ----
-    const int ld_row = tid >> 3, ld_chunk = tid & 7;
-    u32x4 ra[4], rb[4];
-    auto fetch = [&](int step) {
-        const size_t k_off = (size_t)step * ROW_B + ld_chunk * 16;
+    // ---- LDS-DMA staging: wave `wid` owns rows [32 wid, 32 wid + 32) of both operand tiles; one
+    //      buffer_load_dwordx4 ... lds moves 16 rows x 64 B.  Rows past the valid count re-read the last valid row:
+    //      they only feed output rows/columns that are never flushed, and every wave issues the same number of loads
+    //      per step, which is what the counted vmcnt below relies on. ----
+    int voff_a[2], voff_b[2];
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int row = ld_row + 64 * ps;
-            ra[ps] = u32x4{0, 0, 0, 0};
-            rb[ps] = u32x4{0, 0, 0, 0};
-            if (row < a_rows && row < job.m_rows)
-                ra[ps] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(job.a) + (size_t)row * p_pad * P::ACT_BYTES + k_off);
-            if (row < b_rows && row < job.n_rows)
-                rb[ps] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(job.b) + (size_t)row * p_pad * P::ACT_BYTES + k_off);
-        }
-    };
-    auto stage = [&](int buf) {
+    for (int j = 0; j < 2; ++j) {
+        const int row = 32 * wid + 16 * j + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        const int ra = row < job.m_rows ? row : job.m_rows - 1, rb = row < job.n_rows ? row : job.n_rows - 1;
+        voff_a[j] = ra * SEG_B + chunk * 16;
+        voff_b[j] = rb * SEG_B + chunk * 16;
+    }
+    // K step s = sample tile s of the slabs: one contiguous rows x 64 B region per operand
+    auto issue = [&](int step, int slot) {
+        uint8_t* base = smem + slot * SLOT_B + (32 * wid) * ROW_B;
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.a)) + (size_t)step * job.a_stride, 0, job.m_rows * SEG_B, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.b)) + (size_t)step * job.b_stride, 0, job.n_rows * SEG_B, 0x00020000);
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int row = ld_row + 64 * ps;
-            if (row < a_rows) *reinterpret_cast<u32x4*>(lds_a + buf * TILE_B + row * ROW_B + swz(row, ld_chunk)) = ra[ps];
-            if (row < b_rows) *reinterpret_cast<u32x4*>(lds_b + buf * TILE_B + row * ROW_B + swz(row, ld_chunk)) = rb[ps];
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(base + 16 * j * ROW_B), 16, voff_a[j], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(base + OPND_B + 16 * j * ROW_B), 16, voff_b[j], 0, 0, 0);
         }
     };
 
@@ -83,26 +96,33 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
     }
     const bool do_bias = job.db != nullptr && active && wn_idx < wm;
 
-    fetch(s0);
-    stage(0);
-    __syncthreads();
-    int cur = 0;
-    for (int s = s0; s < s1; ++s) {
-        const bool more = s + 1 < s1;
-        if (more) fetch(s + 1);
-        if (active) {
-            const uint8_t* A = lds_a + cur * TILE_B;
-            const uint8_t* B = lds_b + cur * TILE_B;
+    // per-lane LDS offsets of the operand fragments (row, k-group) -> swizzled chunk
+    int off_a[WMAX][2], off_b[NMAX][2];
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                const int chunk = 2 * kg + h;
+    for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+        for (int i = 0; i < WMAX; ++i) { const int row = (wm_idx * wm + i) * 32 + r; off_a[i][kg] = row * ROW_B + wg_swz(row, 2 * kg + h); }
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) { const int row = (wn_idx * wn + j) * 32 + r; off_b[j][kg] = OPND_B + row * ROW_B + wg_swz(row, 2 * kg + h); }
+    }
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(s0 + d < s1 ? s0 + d : s1 - 1, d);
+    for (int s = s0; s < s1; ++s) {
+        const int slot = (s - s0) & (NS - 1);
+        // this wave's share of step s has landed once at most (DEPTH-1) younger steps are outstanding; the barrier then
+        // (a) publishes every wave's share and (b) retires all reads of the slot refilled next
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_STEP * (DEPTH - 1)) : "memory");
+        issue(s + DEPTH < s1 ? s + DEPTH : s1 - 1, (slot + DEPTH) & (NS - 1));
+        if (active) {
+            const uint8_t* T = smem + slot * SLOT_B;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
                 U af[WMAX], bf[NMAX];
 #pragma unroll
-                for (int i = 0; i < WMAX; ++i)
-                    if (i < wm) { const int row = (wm_idx * wm + i) * 32 + r; af[i] = lds_unit<P>(A + row * ROW_B + swz(row, chunk)); }
+                for (int i = 0; i < WMAX; ++i) if (i < wm) af[i] = lds_unit<P>(T + off_a[i][kg]);
 #pragma unroll
-                for (int j = 0; j < NMAX; ++j)
-                    if (j < wn) { const int row = (wn_idx * wn + j) * 32 + r; bf[j] = lds_unit<P>(B + row * ROW_B + swz(row, chunk)); }
+                for (int j = 0; j < NMAX; ++j) if (j < wn) bf[j] = lds_unit<P>(T + off_b[j][kg]);
 #pragma unroll
                 for (int i = 0; i < WMAX; ++i)
                     if (i < wm) {
@@ -113,13 +133,11 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
                     }
             }
         }
-        if (more) stage(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail prefetches before the LDS is released
 
     // ---- flush: fp32 atomics, 32 consecutive columns per half-wave instruction ----
-    if (!active) return;
+    if (active) {
 #pragma unroll
     for (int i = 0; i < WMAX; ++i)
         if (i < wm) {
@@ -145,22 +163,26 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
             if (row < job.m_rows) atomicAdd(job.db + row, accb[g]);
         }
     }
+    }
+  }
 }
 
-template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_pad, hipStream_t st) {
-    constexpr int SMEM = 4 * TILE_B;
+template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, hipStream_t st) {
+    constexpr int SMEM = NS * SLOT_B + 16;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<P>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_wgrad<P>), dim3(n_wg), dim3(WG_NT), SMEM, st, jobs, p_pad);
+    hipLaunchKernelGGL((k_wgrad<P>), dim3(n_wg), dim3(WG_NT), SMEM, st, jobs, p_pad, queue);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, bool bf16, hipStream_t st) {
-    return bf16 ? launch<PBf16>(jobs, n_wg, p_pad, st) : launch<PF32>(jobs, n_wg, p_pad, st);
+hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    return bf16 ? launch<PBf16>(jobs, n_wg, p_pad, queue, st) : launch<PF32>(jobs, n_wg, p_pad, queue, st);
 }
