@@ -115,18 +115,23 @@ template <class P, int SLOT_BYTES> struct WStream {
     EO_DEV void start() {
         q = 0; par = 0;
         issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    // call before computing on the resident chunk: prefetch its successor into the other slot
+    // call before computing on the resident chunk: prefetch its successor into the other slot.  The scheduling
+    // barrier pins the LDS-DMA loads BEFORE every store of the chunk's epilogues (advance<> counts on that order).
     EO_DEV void prefetch_next() {
         int nq = q + 1; if (nq == n_chunks) nq = 0;
         issue(nq, par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // call after computing on the resident chunk
-    EO_DEV void advance() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    // call after computing on the resident chunk.  YOUNGER = a lower bound on the vector-memory operations (the
+    // epilogues' slab stores) this wave issued AFTER prefetch_next(): vmcnt retires in issue order, so waiting until
+    // at most YOUNGER operations are outstanding guarantees the prefetch has landed without draining the stores
+    // (a full vmcnt(0) here serialises every chunk behind an HBM write round trip).  Raw s_barrier: __syncthreads()
+    // would add its own vmcnt(0).
+    template <int YOUNGER> EO_DEV void advance() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(YOUNGER > 63 ? 63 : YOUNGER) : "memory");
         q = q + 1; if (q == n_chunks) q = 0;
         par ^= 1;
     }
@@ -163,8 +168,8 @@ EO_DEV void chunk_compute(const uint8_t* chunk, int lane, int h, const BArr& B, 
     }
 }
 
-// A whole layer: MT m-tiles in MT/G chunks.
-template <class P, int SLOT, int KG, int MT, int G, bool BIAS, class BArr, class Epi>
+// A whole layer: MT m-tiles in MT/G chunks.  NST = slab stores every m-tile's epilogue issues (lower bound, 0 = unknown).
+template <class P, int SLOT, int KG, int MT, int G, bool BIAS, int NST = 0, class BArr, class Epi>
 EO_DEV void run_layer(WStream<P, SLOT>& ws, int lane, int h, const BArr& B, Epi&& epi) {
     static_assert(MT % G == 0, "G must divide MT");
     static_assert(G * (KG * 1024 + 128) <= SLOT, "chunk does not fit the LDS slot");
@@ -172,8 +177,66 @@ EO_DEV void run_layer(WStream<P, SLOT>& ws, int lane, int h, const BArr& B, Epi&
     for (int mg = 0; mg < MT / G; ++mg) {
         ws.prefetch_next();
         chunk_compute<P, KG, G, BIAS>(ws.cur(), lane, h, B, mg * G, epi);
-        ws.advance();
+        ws.template advance<G * NST>();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ReLU + pack + 1-bit mask (forward), mask + pack (backward).  One mask dword covers a PAIR of m-tiles (32 regs/lane).
+//   fp32: bit (16*(mt&1) + r) = acc[r] > 0.
+//   bf16: works on the PACKED words (2 elements per VALU op): ReLU = v_pk_max_i16(w, 0) (a negative bf16 is a negative
+//         int16), nonzero test = (w + 0x7fff7fff) & 0x80008000 shifted into the mask; element r = 2i + half of tile mt
+//         ends up at bit 8*(mt&1) + i + 16*half.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+
+EO_DEV Units32<PF32> relu_pack_mask(PF32, const f32x16& acc, int mt, uint32_t& m) {
+    f32x16 v;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const bool pos = acc[r] > 0.f; v[r] = pos ? acc[r] : 0.f; bits |= pos ? (1u << r) : 0u; }
+    m = (mt & 1) ? (m | (bits << 16)) : bits;
+    return pack_units(PF32(), v);
+}
+EO_DEV Units32<PBf16> relu_pack_mask(PBf16, const f32x16& acc, int mt, uint32_t& m) {
+    Units32<PBf16> u = pack_units(PBf16(), acc);
+    if (!(mt & 1)) m = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 w = __builtin_bit_cast(u32x4, u.u[s]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const s16x2 z = {0, 0};
+            const uint32_t wi = w[i];
+            const uint32_t x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wi), z));
+            w[i] = x;
+            m = (m >> 1) | ((x + 0x7fff7fffu) & 0x80008000u);
+        }
+        u.u[s] = __builtin_bit_cast(bf16x8, w);
+    }
+    return u;
+}
+EO_DEV Units32<PF32> mask_pack(PF32, const f32x16& acc, int mt, uint32_t m) {
+    f32x16 v;
+    const uint32_t bits = m >> ((mt & 1) * 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = (bits >> r) & 1u ? acc[r] : 0.f;
+    return pack_units(PF32(), v);
+}
+EO_DEV Units32<PBf16> mask_pack(PBf16, const f32x16& acc, int mt, uint32_t m) {
+    Units32<PBf16> u = pack_units(PBf16(), acc);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 w = __builtin_bit_cast(u32x4, u.u[s]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 8 * (mt & 1) + 4 * s + i;
+            const uint32_t sel = (m >> k) & 0x00010001u;
+            w[i] &= sel * 0xffffu;          // 0x00010001 * 0xffff = 0xffffffff, no carries between the halves
+        }
+        u.u[s] = __builtin_bit_cast(bf16x8, w);
+    }
+    return u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -187,49 +250,75 @@ template <class P> struct Slab {
     static constexpr int TSAMP = SEG_B / P::ACT_BYTES;     // samples per segment
     static constexpr int WAVE_TILES = 32 / TSAMP;          // sample tiles covered by one wave (bf16 1, fp32 2)
 };
-// descriptor of the sample tile(s) of the wave whose first sample is wave_p0
-template <class P> EO_DEV __amdgpu_buffer_rsrc_t slab_rsrc(void* slab, int rows, int wave_p0) {
-    uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)(wave_p0 / Slab<P>::TSAMP) * rows * SEG_B;
-    return __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * SEG_B * Slab<P>::WAVE_TILES, 0x00020000);
-}
-// per-lane byte offsets: `voff` for 32-row accumulator tiles, `voff1` for single elements (row 4h + r)
-template <class P> EO_DEV int slab_voff(int rows, int c, int h) {
-    if constexpr (P::IS_BF16) return (4 * h + (c & 1)) * SEG_B + (c & ~1) * 2;       // see store_tile_T(PBf16)
-    else return (c >> 4) * rows * SEG_B + 4 * h * SEG_B + (c & 15) * 4;
-}
-template <class P> EO_DEV int slab_voff1(int rows, int c, int h) {
-    if constexpr (P::IS_BF16) return 4 * h * SEG_B + c * 2;
-    else return (c >> 4) * rows * SEG_B + 4 * h * SEG_B + (c & 15) * 4;
-}
-// fp32: lane (c,h) stores its value for sample c: 16 lanes -> one 64-B segment per feature row.
-EO_DEV void store_tile_T(PF32, __amdgpu_buffer_rsrc_t rs, int row0, int voff, int, const Units32<PF32>& u) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float x = u.u[r >> 2][r & 3];      // copy first: __builtin_bit_cast on a vector ELEMENT reads element 0
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, (row0 + acc_row(r, 0)) * SEG_B, 0);
+// Writer of one wave's share of a slab.  The wave holds a tile TRANSPOSED to what the slab wants (lane = sample,
+// registers = features), and narrow stores are issue-bound on CDNA4 (~7 B/clk/CU for 8-byte stores), so
+//   bf16: the packed tile goes through a wave-private LDS scratch ([32 samples][32 features], 72-B rows) and comes
+//         back through ds_read_b64_tr_b16 (hardware transpose) as 8 consecutive samples of one feature per lane:
+//         TWO buffer_store_dwordx4 per 32x32 tile instead of eight dword stores + DPP shuffles;
+//   fp32: parity mode, plain dword stores (16 lanes = one 64-B segment per feature row).
+constexpr int TR_STRIDE = 72;                    // scratch row stride: 18 dwords -> conflict-free ds_write_b64
+constexpr int TR_WAVE_B = 32 * TR_STRIDE;        // 2304 B per wave
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <class P> struct SlabWriter;
+
+template <> struct SlabWriter<PF32> {
+    static constexpr int LDS_BYTES = 0;
+    __amdgpu_buffer_rsrc_t rs; int voff;
+    EO_DEV void init(void* slab, int rows, int wave_p0, int lane, uint8_t*) {
+        const int c = lane & 31, h = lane >> 5;
+        uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)(wave_p0 / 16) * rows * SEG_B;
+        rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * SEG_B * 2, 0x00020000);
+        voff = (c >> 4) * rows * SEG_B + 4 * h * SEG_B + (c & 15) * 4;
     }
-}
-// bf16: packed word i holds features (f, f+1) of sample c.  A quad_perm swap with the neighbour lane turns that into
-// (f; samples c,c+1) on even lanes and (f+1; samples c-1,c) on odd lanes: one dword store per lane, 16 lanes = one
-// whole 64-B segment per feature row.
-EO_DEV void store_tile_T(PBf16, __amdgpu_buffer_rsrc_t rs, int row0, int voff, int odd, const Units32<PBf16>& u) {
+    EO_DEV void tile(int row0, const Units32<PF32>& u) const {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const u32x4 words = __builtin_bit_cast(u32x4, u.u[i >> 2]);
-        const uint32_t w = words[i & 3];
-        const uint32_t nb = __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);          // lane ^ 1
-        // even: {own.lo, nb.lo}   odd: {nb.hi, own.hi}   (v_perm_b32 bytes: src0=w -> 4..7, src1=nb -> 0..3)
-        const uint32_t o = odd ? __builtin_amdgcn_perm(w, nb, 0x07060302) : __builtin_amdgcn_perm(w, nb, 0x01000504);
-        __builtin_amdgcn_raw_buffer_store_b32(o, rs, voff, (row0 + acc_row(2 * i, 0)) * SEG_B, 0);
+        for (int r = 0; r < 16; ++r) {
+            const float x = u.u[r >> 2][r & 3];      // copy first: __builtin_bit_cast on a vector ELEMENT reads element 0
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, (row0 + acc_row(r, 0)) * SEG_B, 0);
+        }
     }
-}
-// single element per lane: row (+4h through voff1)
-EO_DEV void store_elem_T(PF32, __amdgpu_buffer_rsrc_t rs, int voff1, int row, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff1, row * SEG_B, 0);
-}
-EO_DEV void store_elem_T(PBf16, __amdgpu_buffer_rsrc_t rs, int voff1, int row, float v) {
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), rs, voff1, row * SEG_B, 0);
-}
+    EO_DEV void elem(int row, float v) const {       // row (+4h through voff)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, row * SEG_B, 0);
+    }
+};
+
+template <> struct SlabWriter<PBf16> {
+    static constexpr int LDS_BYTES = 8 * TR_WAVE_B;
+    __amdgpu_buffer_rsrc_t rs; int voff1, svoff;
+    uint8_t* wptr; const uint8_t* rptr;
+    EO_DEV void init(void* slab, int rows, int wave_p0, int lane, uint8_t* scratch_wave) {
+        const int c = lane & 31, h = lane >> 5;
+        uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)(wave_p0 / 32) * rows * SEG_B;
+        rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * SEG_B, 0x00020000);
+        voff1 = 4 * h * SEG_B + c * 2;
+        // scratch write: row = sample c, columns 8q + 4h .. +3 (natural feature order)
+        wptr = scratch_wave + c * TR_STRIDE + h * 8;
+        // transposed read: 16-lane group g, lane i = 4*qq + p supplies (row 8*octet + 4t + qq, cols 16*(g&1) + 4p..+3),
+        // octet = (g>>1) + 2*pair, and receives feature column 16*(g&1) + i for those four samples
+        const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+        rptr = scratch_wave + (8 * (g >> 1) + qq) * TR_STRIDE + (g & 1) * 32 + pp * 8;
+        svoff = (16 * (g & 1) + i) * SEG_B + (g >> 1) * 16;
+    }
+    EO_DEV void tile(int row0, const Units32<PBf16>& u) const {
+        const u32x4 w0 = __builtin_bit_cast(u32x4, u.u[0]), w1 = __builtin_bit_cast(u32x4, u.u[1]);
+        *reinterpret_cast<u32x2*>(wptr + 0) = u32x2{w0[0], w0[1]};
+        *reinterpret_cast<u32x2*>(wptr + 16) = u32x2{w0[2], w0[3]};
+        *reinterpret_cast<u32x2*>(wptr + 32) = u32x2{w1[0], w1[1]};
+        *reinterpret_cast<u32x2*>(wptr + 48) = u32x2{w1[2], w1[3]};
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            const uint8_t* rp = rptr + pair * 16 * TR_STRIDE;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rp));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rp + 4 * TR_STRIDE));
+            const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], b[0], b[1]}, rs, svoff, row0 * SEG_B + pair * 32, 0);
+        }
+    }
+    EO_DEV void elem(int row, float v) const {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), rs, voff1, row * SEG_B, 0);
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Activation functions (PyTorch semantics: Softplus beta=1 threshold=20; Sigmoid)

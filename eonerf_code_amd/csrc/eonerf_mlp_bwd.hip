@@ -27,6 +27,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef typename P::U U;
     constexpr int HKG = 256 / P::KF, QKG = 128 / P::KF;
+    constexpr int NST = P::IS_BF16 ? 2 : 16;      // slab stores per m-tile epilogue (SlabWriter::tile)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int n_pts = *a.n_pts;
@@ -40,8 +41,8 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         const int p = tile * P::TILE + wave * 32 + c;
         const bool live = p < n_pts;
         constexpr int GROWS = FULL ? GRD_ROWS_FULL : GRD_ROWS_DENSITY;
-        const __amdgpu_buffer_rsrc_t grs = slab_rsrc<P>(a.grd, GROWS, tile * P::TILE + wave * 32);
-        const int voff = slab_voff<P>(GROWS, c, h), voff1 = slab_voff1<P>(GROWS, c, h);
+        SlabWriter<P> sw;                                                   // this wave's sample tile(s) of the gradient slab
+        sw.init(a.grd, GROWS, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * TR_WAVE_B);
         uint32_t mb[4];
 
         auto load_mask = [&](int slot, int nwords) {
@@ -51,22 +52,16 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         };
         // dX tile -> (optional ReLU mask) -> units of the next backward layer + feature-major save for the wgrad GEMM
         auto grad_epi = [&](auto& dst, int grd_row, bool masked, int mt, const f32x16& accv) {
-            f32x16 v = accv;
-            if (masked) {
-                const uint32_t bits = mb[mt >> 1] >> ((mt & 1) * 16);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = (bits >> r) & 1u ? accv[r] : 0.f;
-            }
-            Units32<P> u = pack_units(P(), v);
+            const Units32<P> u = masked ? mask_pack(P(), accv, mt, mb[mt >> 1]) : pack_units(P(), accv);
 #pragma unroll
             for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
-            store_tile_T(P(), grs, grd_row + 32 * mt, voff, c & 1, u);
+            sw.tile(grd_row + 32 * mt, u);
         };
 
         // ---------------- output heads: activation derivatives from the saved forward outputs ----------------
         const float sg = live ? a.sigma[p] : 0.f;
         float dsig[4] = {live ? a.g_sigma[p] * (1.f - expf(-sg)) : 0.f, 0.f, 0.f, 0.f};    // softplus' = 1 - exp(-softplus)
-        store_elem_T(P(), grs, voff1, GRD_ROW_SIG, h == 0 ? dsig[0] : 0.f);
+        sw.elem(GRD_ROW_SIG, h == 0 ? dsig[0] : 0.f);
 
         U D[HKG], N[HKG];
         if constexpr (FULL) {
@@ -82,28 +77,28 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 dtr[1] = a.g_tb[p] * (1.f - expf(-tbv));
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) store_elem_T(P(), grs, voff1, GRD_ROW_T5 + e, h == 0 ? dtr[e] : 0.f);
+            for (int e = 0; e < 2; ++e) sw.elem(GRD_ROW_T5 + e, h == 0 ? dtr[e] : 0.f);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) store_elem_T(P(), grs, voff1, GRD_ROW_A2 + e, h == 0 ? dalb[e] : 0.f);
+            for (int e = 0; e < 3; ++e) sw.elem(GRD_ROW_A2 + e, h == 0 ? dalb[e] : 0.f);
             // ---- transient head backwards: {ts,tb}_pre -> T4 -> T3 -> T2 -> T1 ----
             U TA[QKG], TB[QKG], DA1[QKG];
             const U u_tr = small_unit<P>(dtr, h);
             load_mask(12, 2);
-            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false>(ws, lane, h, [&](int) { return u_tr; },
+            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, lane, h, [&](int) { return u_tr; },
                 [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v); });
             load_mask(11, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false>(ws, lane, h, [&](int kg) { return TA[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TA[kg]; },
                 [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v); });
             load_mask(10, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false>(ws, lane, h, [&](int kg) { return TB[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TB[kg]; },
                 [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v); });
             load_mask(9, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false>(ws, lane, h, [&](int kg) { return TA[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TA[kg]; },
                 [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1, true, mt, v); });        // TB = dY_T1
             // ---- albedo head backwards: albedo_pre -> A1 ----
             const U u_al = small_unit<P>(dalb, h);
             load_mask(8, 2);
-            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false>(ws, lane, h, [&](int) { return u_al; },
+            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, lane, h, [&](int) { return u_al; },
                 [&](int mt, const f32x16& v) { grad_epi(DA1, GRD_ROW_A1, true, mt, v); });
             // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
             run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, lane, h,
@@ -115,13 +110,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
-            run_layer<P, SLOT, HKG + 1, 8, FwdG<P, HKG + 1, 8>::G, false>(ws, lane, h,
+            run_layer<P, SLOT, HKG + 1, 8, FwdG<P, HKG + 1, 8>::G, false, NST>(ws, lane, h,
                 [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
                 [&](int mt, const f32x16& v) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v); });
         } else {
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
-            run_layer<P, SLOT, 1, 8, FwdG<P, 1, 8>::G, false>(ws, lane, h, [&](int) { return u_sg; },
+            run_layer<P, SLOT, 1, 8, FwdG<P, 1, 8>::G, false, NST>(ws, lane, h, [&](int) { return u_sg; },
                 [&](int mt, const f32x16& v) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v); });
         }
 
@@ -129,7 +124,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         f32x16 denc[2];
         auto trunk_step = [&](auto& src, auto& dst, int l) {      // consumes dY_l, produces dY_{l-1}
             load_mask(l - 1, 4);
-            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, false>(ws, lane, h, [&](int kg) { return src[kg]; },
+            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, false, NST>(ws, lane, h, [&](int kg) { return src[kg]; },
                 [&](int mt, const f32x16& v) { grad_epi(dst, GRD_ROW_Y0 + (l - 1) * 256, true, mt, v); });
         };
         trunk_step(D, N, 7);
@@ -185,7 +180,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
 
 template <class P, bool FULL, bool IG>
 hipError_t launch(const MlpBwdArgs& a, int grid, hipStream_t st) {
-    constexpr int SMEM = 2 * FwdSlot<P>::BYTES;
+    constexpr int SMEM = 2 * FwdSlot<P>::BYTES + SlabWriter<P>::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG>),

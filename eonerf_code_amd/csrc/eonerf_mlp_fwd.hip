@@ -46,6 +46,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
     constexpr int HKG = 256 / P::KF;      // k-groups of a 256-wide activation
     constexpr int QKG = 128 / P::KF;      // ... of a 128-wide activation
     constexpr int EKG = ENC_SLOTS / P::KF;
+    constexpr int NST = TRAIN ? (P::IS_BF16 ? 2 : 16) : 0;     // slab stores per m-tile epilogue (SlabWriter::tile)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int n_pts = *a.n_pts;
@@ -61,14 +62,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         const float x = live ? a.px[p] : 0.f, y = live ? a.py[p] : 0.f, z = live ? a.pz[p] : 0.f;
         const EncUnits<P> E = encode_position<P>(x, y, z, h);
         constexpr int AROWS = FULL ? ACT_ROWS_FULL : ACT_ROWS_DENSITY;
-        const int wave_p0 = tile * P::TILE + wave * 32;
-        const __amdgpu_buffer_rsrc_t ars = slab_rsrc<P>(a.act, AROWS, wave_p0);      // this wave's sample tile(s) of the slab
-        const int voff = slab_voff<P>(AROWS, c, h), voff1 = slab_voff1<P>(AROWS, c, h);
-        if constexpr (TRAIN) {   // encoding slots, rows [0,64) of the activation slab
+        SlabWriter<P> sw;                                                   // this wave's sample tile(s) of the activation slab
+        if constexpr (TRAIN) {
+            sw.init(a.act, AROWS, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * TR_WAVE_B);
 #pragma unroll
-            for (int kg = 0; kg < EKG; ++kg)
+            for (int kg = 0; kg < EKG; ++kg)      // encoding slots, rows [0,64)
 #pragma unroll
-                for (int e = 0; e < P::NE; ++e) store_elem_T(P(), ars, voff1, ACT_ROW_ENC + P::feat(kg, 0, e), (float)E.u[kg][e]);
+                for (int e = 0; e < P::NE; ++e) sw.elem(ACT_ROW_ENC + P::feat(kg, 0, e), (float)E.u[kg][e]);
         }
 
         U H[HKG], N[HKG];
@@ -76,19 +76,10 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 
         // ---------------- trunk ----------------
         auto relu_epi = [&](auto& dst, int act_row, int mt, const f32x16& accv) {
-            f32x16 v;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = fmaxf(accv[r], 0.f);
-            Units32<P> u = pack_units(P(), v);
+            const Units32<P> u = relu_pack_mask(P(), accv, mt, mbits[mt >> 1]);
 #pragma unroll
             for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
-            if constexpr (TRAIN) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m |= (accv[r] > 0.f) ? (1u << r) : 0u;
-                if (mt & 1) mbits[mt >> 1] |= m << 16; else mbits[mt >> 1] = m;
-                store_tile_T(P(), ars, act_row + 32 * mt, voff, c & 1, u);
-            }
+            if constexpr (TRAIN) sw.tile(act_row + 32 * mt, u);
         };
         auto save_mask = [&](int mask_slot, int nwords) {
             if constexpr (TRAIN) {
@@ -98,13 +89,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             }
         };
         auto plain_layer = [&](auto& src, auto& dst, int l) {
-            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, true>(ws, lane, h, [&](int kg) { return src[kg]; },
+            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, true, NST>(ws, lane, h, [&](int kg) { return src[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi(dst, ACT_ROW_X1 + 256 * l, mt, v); });
             save_mask(l, 4);
         };
 
         // layer 0: enc(64) -> 256
-        run_layer<P, SLOT, EKG, 8, FwdG<P, EKG, 8>::G, true>(ws, lane, h, [&](int kg) { return E.u[kg]; },
+        run_layer<P, SLOT, EKG, 8, FwdG<P, EKG, 8>::G, true, NST>(ws, lane, h, [&](int kg) { return E.u[kg]; },
             [&](int mt, const f32x16& v) { relu_epi(H, ACT_ROW_X1, mt, v); });
         save_mask(0, 4);
         plain_layer(H, N, 1);
@@ -112,7 +103,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         plain_layer(H, N, 3);
         plain_layer(N, H, 4);
         // layer 5 consumes [h, enc] (skip-concat after layer 4, mlp.py:92-97)
-        run_layer<P, SLOT, HKG + EKG, 8, FwdG<P, HKG + EKG, 8>::G, true>(ws, lane, h,
+        run_layer<P, SLOT, HKG + EKG, 8, FwdG<P, HKG + EKG, 8>::G, true, NST>(ws, lane, h,
             [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : E.u[kg >= HKG ? kg - HKG : 0]; },
             [&](int mt, const f32x16& v) { relu_epi(N, ACT_ROW_X1 + 256 * 5, mt, v); });
         save_mask(5, 4);
@@ -133,13 +124,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                     Units32<P> u = pack_units(P(), v);
 #pragma unroll
                     for (int s = 0; s < P::KG32; ++s) H[(mt - 1) * P::KG32 + s] = u.u[s];
-                    if constexpr (TRAIN) store_tile_T(P(), ars, ACT_ROW_BOTT + 32 * (mt - 1), voff, c & 1, u);
+                    if constexpr (TRAIN) sw.tile(ACT_ROW_BOTT + 32 * (mt - 1), u);
                 });
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
 
             // ---------------- albedo head: 256 -> 128 (ReLU) -> 3 (Sigmoid) ----------------
             U A1[QKG];
-            run_layer<P, SLOT, HKG, 4, FwdG<P, HKG, 4>::G, true>(ws, lane, h, [&](int kg) { return H[kg]; },
+            run_layer<P, SLOT, HKG, 4, FwdG<P, HKG, 4>::G, true, NST>(ws, lane, h, [&](int kg) { return H[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi(A1, ACT_ROW_A1, mt, v); });
             save_mask(8, 2);
             run_layer<P, SLOT, QKG, 1, 1, true>(ws, lane, h, [&](int kg) { return A1[kg]; },
@@ -161,20 +152,20 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             }
             if constexpr (TRAIN) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) store_elem_T(P(), ars, voff1, ACT_ROW_EMB + e, (float)EMB[e]);
+                for (int e = 0; e < 4; ++e) sw.elem(ACT_ROW_EMB + e, (float)EMB[e]);
             }
             U T1[QKG], T2[QKG];
-            run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true>(ws, lane, h,
+            run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true, NST>(ws, lane, h,
                 [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : EMB; },
                 [&](int mt, const f32x16& v) { relu_epi(T1, ACT_ROW_T1, mt, v); });
             save_mask(9, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true>(ws, lane, h, [&](int kg) { return T1[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST>(ws, lane, h, [&](int kg) { return T1[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi(T2, ACT_ROW_T1 + 128, mt, v); });
             save_mask(10, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true>(ws, lane, h, [&](int kg) { return T2[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST>(ws, lane, h, [&](int kg) { return T2[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi(T1, ACT_ROW_T1 + 256, mt, v); });
             save_mask(11, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true>(ws, lane, h, [&](int kg) { return T1[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST>(ws, lane, h, [&](int kg) { return T1[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi(T2, ACT_ROW_T1 + 384, mt, v); });
             save_mask(12, 2);
             run_layer<P, SLOT, QKG, 1, 1, true>(ws, lane, h, [&](int kg) { return T2[kg]; },
@@ -187,7 +178,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 
 template <class P, bool FULL, bool TRAIN>
 hipError_t launch(const MlpFwdArgs& a, int grid, hipStream_t st) {
-    constexpr int SMEM = 2 * FwdSlot<P>::BYTES;
+    constexpr int SMEM = 2 * FwdSlot<P>::BYTES + (TRAIN ? SlabWriter<P>::LDS_BYTES : 0);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, TRAIN>),
