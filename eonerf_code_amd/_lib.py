@@ -13,12 +13,13 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libeonerf_hip.so")
 
 EONERF_FP32, EONERF_BF16 = 0, 1
-F_SHADOWS, F_EVAL, F_TRAIN, F_ONLY_DEPTH = 1, 2, 4, 8
+F_SHADOWS, F_EVAL, F_TRAIN, F_ONLY_DEPTH, F_RGB_LOSS = 1, 2, 4, 8, 16
 
 SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy", "eonerf_param_tensors",
            "eonerf_param_info", "eonerf_param_floats", "eonerf_set_weights", "eonerf_field_workspace_bytes",
            "eonerf_render_workspace_bytes", "eonerf_field_forward", "eonerf_query_density", "eonerf_render_forward",
-           "eonerf_render_backward", "eonerf_adam_step", "eonerf_profile_enable", "eonerf_profile_read"]
+           "eonerf_render_backward", "eonerf_adam_step", "eonerf_profile_enable", "eonerf_profile_read",
+           "eonerf_train_loss"]
 
 
 class EonerfConfig(C.Structure):
@@ -69,6 +70,7 @@ def lib():
     L.eonerf_render_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_render_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp]
+    L.eonerf_train_loss.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
     L.eonerf_profile_enable.argtypes = [vp, i]
     L.eonerf_profile_read.argtypes = [vp, i, C.POINTER(fp), C.POINTER(i)]
     for name in SYMBOLS:

@@ -55,9 +55,10 @@ struct eonerf_ctx {
     bool bf16;
     int n_cu;
     ParamLayout pl;
-    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens;
+    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb;
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
     bool weights_set = false;
+    bool dens_dirty = false;         // density-only streams are re-packed lazily (only the shadow pass reads them)
     // measurement hooks
     int prof_cap = 0;
     std::vector<hipEvent_t> prof_ev[5][2];
@@ -165,7 +166,16 @@ AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
     return AmbientW{flat + pl.t[pl.am1_w].offset, flat + pl.t[pl.am1_b].offset, flat + pl.t[pl.am2_w].offset, flat + pl.t[pl.am2_b].offset};
 }
 
-int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_cap, bool full, bool train, hipStream_t st, int prof_id = -1) {
+int ensure_density_streams(eonerf_ctx* ctx, const float* flat, hipStream_t st) {
+    if (!ctx->dens_dirty) return 0;
+    int rc = pack(ctx->fwd_dens, flat, st);
+    if (!rc) rc = pack(ctx->bwd_dens, flat, st);
+    if (!rc) ctx->dens_dirty = false;
+    return rc;
+}
+
+int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_cap, bool full, int mode, hipStream_t st, int prof_id = -1) {
+    if (!full) { const int rc = ensure_density_streams(ctx, flat, st); if (rc) return rc; }
     const DevStream& ds = full ? ctx->fwd_full : ctx->fwd_dens;
     MlpFwdArgs a;
     a.px = b.px; a.py = b.py; a.pz = b.pz; a.simg = b.simg;
@@ -176,9 +186,9 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     a.act = b.act; a.masks = b.masks;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
-    if (prof_id < 0) return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, train, grid, st);
+    if (prof_id < 0) return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, mode, grid, st);
     ProfScope ps(ctx, prof_id, st);
-    return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, train, grid, st);
+    return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, mode, grid, st);
 }
 
 }  // namespace
@@ -215,6 +225,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     if (!rc) rc = upload(ctx->fwd_dens, build_fwd_stream(ctx->pl, ctx->bf16, false));
     if (!rc) rc = upload(ctx->bwd_full, build_bwd_stream(ctx->pl, ctx->bf16, true, false));
     if (!rc) rc = upload(ctx->bwd_dens, build_bwd_stream(ctx->pl, ctx->bf16, false, true));
+    if (!rc) rc = upload(ctx->bwd_rgb, build_bwd_stream(ctx->pl, ctx->bf16, true, false, false));
     if (!rc) {
         int cm[64];
         for (int s = 0; s < 64; ++s) cm[s] = enc_col_of_slot(ctx->bf16, s);
@@ -256,7 +267,7 @@ int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launc
 int eonerf_destroy(eonerf_ctx* ctx) {
     if (!ctx) return EONERF_E_ARG;
     for (int k = 0; k < 5; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
-    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens);
+    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     delete ctx;
     return EONERF_OK;
@@ -278,10 +289,9 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     if (!ctx || !flat) return EONERF_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     int rc = pack(ctx->fwd_full, flat, st);
-    if (!rc) rc = pack(ctx->fwd_dens, flat, st);
     if (!rc) rc = pack(ctx->bwd_full, flat, st);
-    if (!rc) rc = pack(ctx->bwd_dens, flat, st);
-    if (!rc) ctx->weights_set = true;
+    if (!rc) rc = pack(ctx->bwd_rgb, flat, st);
+    if (!rc) { ctx->weights_set = true; ctx->dens_dirty = true; }
     return rc;
 }
 
@@ -307,7 +317,7 @@ static int field_common(eonerf_ctx* ctx, const float* flat, const float* xyz, co
     Carver c(ws);
     carve_pass(c, b, 1, p_cap, true, false, false, ctx->bf16 ? 2 : 4);
     HIP_TRY(eo_launch_points_to_soa(xyz, img, n, p_cap, b.px, b.py, b.pz, b.simg, b.n_pts, st));
-    return run_mlp_fwd(ctx, b, flat, p_cap, full, false, st);
+    return run_mlp_fwd(ctx, b, flat, p_cap, full, 0, st);
 }
 
 int eonerf_field_forward(eonerf_ctx* ctx, const float* flat, const float* xyz, const float* sun, const int64_t* img, int n,
@@ -363,7 +373,8 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     sa.flags = w.flags; sa.n_pts = w.cam.n_pts;
     sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
     HIP_TRY(eo_launch_sampler(sa, st));
-    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !od, train, st, 0);
+    const bool rgb_loss = train && !shadows && (flags & EONERF_F_RGB_LOSS);
+    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !od, train ? (rgb_loss ? 2 : 1) : 0, st, 0);
     if (rc) return rc;
     CompositeArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -382,7 +393,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
         ss.n_pts = w.sun.n_pts;
         ss.px = w.sun.px; ss.py = w.sun.py; ss.pz = w.sun.pz; ss.tmid = w.sun.tmid; ss.delta = w.sun.delta; ss.simg = w.sun.simg;
         HIP_TRY(eo_launch_sampler(ss, st));
-        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train, st, 3);
+        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train ? 1 : 0, st, 3);
         if (rc) return rc;
         CompositeArgs cs = ca;
         cs.offsets = w.sun.offsets; cs.counts = w.sun.counts; cs.sigma = w.sun.sigma; cs.delta = w.sun.delta; cs.tmid = w.sun.tmid;
@@ -425,6 +436,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     sb.radiometric = ctx->cfg.radiometric ? flat + pl.t[pl.rad].offset : nullptr;
     sb.d_radiometric = ctx->cfg.radiometric ? dptr(pl.rad) : nullptr;
     sb.g_ray = w.g_ray; sb.n_rays = n_rays; sb.use_shadow = shadows ? 1 : 0; sb.eval = (flags & EONERF_F_EVAL) ? 1 : 0;
+    sb.lds_images = ctx->cfg.n_images <= 2048 ? ctx->cfg.n_images : 0;
     HIP_TRY(eo_launch_shade_bwd(sb, st));
 
     CompositeBwdArgs cb;
@@ -443,7 +455,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         ms.stream = ctx->bwd_dens.data; ms.chunks = ctx->bwd_dens.chunks; ms.n_chunks = ctx->bwd_dens.n_chunks;
         ms.sigma = w.sun.sigma; ms.g_sigma = w.sun.g_sigma; ms.masks = w.sun.masks; ms.grd = w.sun.grd;
         ms.px = w.sun.px; ms.py = w.sun.py; ms.pz = w.sun.pz; ms.g_pos = w.sun.g_pos;
-        { ProfScope ps(ctx, 4, st); HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, grid, st)); }
+        { ProfScope ps(ctx, 4, st); HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, false, grid, st)); }
         HIP_TRY(eo_launch_sun_depth_grad(cs, st));
     }
 
@@ -455,11 +467,13 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     MlpBwdArgs mc;
     memset(&mc, 0, sizeof(mc));
     mc.n_pts = w.cam.n_pts; mc.p_pad = p_cap;
-    mc.stream = ctx->bwd_full.data; mc.chunks = ctx->bwd_full.chunks; mc.n_chunks = ctx->bwd_full.n_chunks;
+    const bool transient = shadows || !(flags & EONERF_F_RGB_LOSS);
+    const DevStream& bs = transient ? ctx->bwd_full : ctx->bwd_rgb;
+    mc.stream = bs.data; mc.chunks = bs.chunks; mc.n_chunks = bs.n_chunks;
     mc.sigma = w.cam.sigma; mc.albedo = w.cam.albedo; mc.ts = w.cam.ts; mc.tb = w.cam.tb;
     mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
     mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
-    { ProfScope ps(ctx, 1, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, grid, st)); }
+    { ProfScope ps(ctx, 1, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st)); }
 
     // ---- weight gradients: every layer of both passes in one split-K launch -------------------------------
     WgradJobTable tab;
@@ -490,12 +504,14 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     add(w.cam, GRD_ROW_BOTT, 256, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.bot_w), 256, dptr(pl.bot_b), nullptr, 2, 4, 4, 2);
     add(w.cam, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
     add(w.cam, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
-    add(w.cam, GRD_ROW_T1, 128, ACT_ROW_BOTT, 256, dptr(pl.t_w[0]), 260, dptr(pl.t_b[0]), nullptr, 2, 4, 2, 2);
-    add(w.cam, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
-    for (int l = 1; l < 4; ++l)
-        add(w.cam, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
-    add(w.cam, GRD_ROW_T5, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);
-    add(w.cam, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
+    if (transient) {
+        add(w.cam, GRD_ROW_T1, 128, ACT_ROW_BOTT, 256, dptr(pl.t_w[0]), 260, dptr(pl.t_b[0]), nullptr, 2, 4, 2, 2);
+        add(w.cam, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
+        for (int l = 1; l < 4; ++l)
+            add(w.cam, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
+        add(w.cam, GRD_ROW_T5, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);
+        add(w.cam, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
+    }
     if (shadows) trunk_jobs(w.sun);
     // heaviest jobs first (longest-processing-time order for the work queue)
     std::vector<int> order(tab.n);
@@ -507,14 +523,21 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(sorted, ctx->n_cu, p_cap, w.flags + 2, ctx->bf16, st)); }
 
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
-    EmbGradArgs eg;
-    eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays;
-    HIP_TRY(eo_launch_emb_grad(eg, st));
+    if (transient) {
+        EmbGradArgs eg;
+        eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays;
+        HIP_TRY(eo_launch_emb_grad(eg, st));
+    }
     AmbientBwdArgs ag;
     ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.n_rays = n_rays;
     ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
     HIP_TRY(eo_launch_ambient_bwd(ag, st));
     return EONERF_OK;
+}
+
+int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, int n_rays, int kind, float* d_out, float* loss, void* stream) {
+    if (!ctx || !out || !pixels || !d_out || !loss || n_rays < 1 || (kind != 0 && kind != 1)) return EONERF_E_ARG;
+    return (int)eo_launch_loss(out, pixels, n_rays, kind, d_out, loss, (hipStream_t)stream);
 }
 
 int eonerf_adam_step(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,

@@ -88,8 +88,8 @@ struct WgradJob {
     int gm, gn, wm, wn;   // wave grid and tiles per wave: (gm*wm*32) x (gn*wn*32) >= m_rows x n_rows
 };
 
-hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, bool train, int grid, hipStream_t st);
-hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, int grid, hipStream_t st);
+hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);
+hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st);
 constexpr int WGRAD_MAX_JOBS = 40;
 struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int slices; };   // by value in the kernel-argument segment; jobs sorted heaviest first
 hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st);

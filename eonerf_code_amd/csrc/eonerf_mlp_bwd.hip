@@ -21,7 +21,8 @@ template <class P> EO_DEV typename P::U small_unit(const float (&v)[4], int h) {
     return u;
 }
 
-template <class P, bool FULL, bool IG>
+// TRANS = false: the transient head is outside the autograd graph (see k_mlp_fwd MODE 2): its layers are skipped.
+template <class P, bool FULL, bool IG, bool TRANS>
 __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     constexpr int SLOT = FwdSlot<P>::BYTES;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -72,41 +73,53 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                     const float av = a.albedo[(size_t)k * a.p_pad + p];
                     dalb[k] = a.g_albedo[(size_t)k * a.p_pad + p] * av * (1.f - av);           // sigmoid'
                 }
-                const float tsv = a.ts[p], tbv = a.tb[p];
-                dtr[0] = a.g_ts[p] * tsv * (1.f - tsv);
-                dtr[1] = a.g_tb[p] * (1.f - expf(-tbv));
+                if constexpr (TRANS) {
+                    const float tsv = a.ts[p], tbv = a.tb[p];
+                    dtr[0] = a.g_ts[p] * tsv * (1.f - tsv);
+                    dtr[1] = a.g_tb[p] * (1.f - expf(-tbv));
+                }
+            }
+            if constexpr (TRANS) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) sw.elem(GRD_ROW_T5 + e, h == 0 ? dtr[e] : 0.f);
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) sw.elem(GRD_ROW_T5 + e, h == 0 ? dtr[e] : 0.f);
-#pragma unroll
             for (int e = 0; e < 3; ++e) sw.elem(GRD_ROW_A2 + e, h == 0 ? dalb[e] : 0.f);
-            // ---- transient head backwards: {ts,tb}_pre -> T4 -> T3 -> T2 -> T1 ----
             U TA[QKG], TB[QKG], DA1[QKG];
-            const U u_tr = small_unit<P>(dtr, h);
-            load_mask(12, 2);
-            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, lane, h, [&](int) { return u_tr; },
-                [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v); });
-            load_mask(11, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TA[kg]; },
-                [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v); });
-            load_mask(10, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TB[kg]; },
-                [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v); });
-            load_mask(9, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TA[kg]; },
-                [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1, true, mt, v); });        // TB = dY_T1
+            if constexpr (TRANS) {
+                // ---- transient head backwards: {ts,tb}_pre -> T4 -> T3 -> T2 -> T1 ----
+                const U u_tr = small_unit<P>(dtr, h);
+                load_mask(12, 2);
+                run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, lane, h, [&](int) { return u_tr; },
+                    [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v); });
+                load_mask(11, 2);
+                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TA[kg]; },
+                    [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v); });
+                load_mask(10, 2);
+                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TB[kg]; },
+                    [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v); });
+                load_mask(9, 2);
+                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TA[kg]; },
+                    [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1, true, mt, v); });        // TB = dY_T1
+            }
             // ---- albedo head backwards: albedo_pre -> A1 ----
             const U u_al = small_unit<P>(dalb, h);
             load_mask(8, 2);
             run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, lane, h, [&](int) { return u_al; },
                 [&](int mt, const f32x16& v) { grad_epi(DA1, GRD_ROW_A1, true, mt, v); });
-            // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
-            run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, lane, h,
-                [&](int kg) { return kg < QKG ? DA1[kg < QKG ? kg : 0] : TB[kg >= QKG ? kg - QKG : 0]; },
-                [&](int mt, const f32x16& v) {
-                    if (mt < 8) { grad_epi(N, GRD_ROW_BOTT, false, mt, v); return; }
-                    if (h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
-                });
+            if constexpr (TRANS) {
+                // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
+                run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, lane, h,
+                    [&](int kg) { return kg < QKG ? DA1[kg < QKG ? kg : 0] : TB[kg >= QKG ? kg - QKG : 0]; },
+                    [&](int mt, const f32x16& v) {
+                        if (mt < 8) { grad_epi(N, GRD_ROW_BOTT, false, mt, v); return; }
+                        if (h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
+                    });
+            } else {
+                // ---- dY_A1 -> d bottleneck ----
+                run_layer<P, SLOT, QKG, 8, FwdG<P, QKG, 8>::G, false, NST>(ws, lane, h, [&](int kg) { return DA1[kg]; },
+                    [&](int mt, const f32x16& v) { grad_epi(N, GRD_ROW_BOTT, false, mt, v); });
+            }
             // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
@@ -178,26 +191,30 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     }
 }
 
-template <class P, bool FULL, bool IG>
+template <class P, bool FULL, bool IG, bool TRANS>
 hipError_t launch(const MlpBwdArgs& a, int grid, hipStream_t st) {
     constexpr int SMEM = 2 * FwdSlot<P>::BYTES + SlabWriter<P>::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG, TRANS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_mlp_bwd<P, FULL, IG>), dim3(grid), dim3(P::NT), SMEM, st, a);
+    hipLaunchKernelGGL((k_mlp_bwd<P, FULL, IG, TRANS>), dim3(grid), dim3(P::NT), SMEM, st, a);
     return hipGetLastError();
+}
+
+template <class P> hipError_t dispatch(const MlpBwdArgs& a, bool full, bool transient, int grid, hipStream_t st) {
+    if (!full) return launch<P, false, true, false>(a, grid, st);
+    return transient ? launch<P, true, false, true>(a, grid, st) : launch<P, true, false, false>(a, grid, st);
 }
 
 }  // namespace
 
-// only the two variants the render path needs: camera pass (all heads, no input grad) and shadow pass
-// (density only, with input grad)
-hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, int grid, hipStream_t st) {
+// the variants the render path needs: camera pass (all heads, with / without the transient head in the graph, no input
+// grad) and shadow pass (density only, with input grad)
+hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st) {
     if (full == input_grad) return hipErrorInvalidValue;
-    if (bf16) return full ? launch<PBf16, true, false>(a, grid, st) : launch<PBf16, false, true>(a, grid, st);
-    return full ? launch<PF32, true, false>(a, grid, st) : launch<PF32, false, true>(a, grid, st);
+    return bf16 ? dispatch<PBf16>(a, full, transient, grid, st) : dispatch<PF32>(a, full, transient, grid, st);
 }

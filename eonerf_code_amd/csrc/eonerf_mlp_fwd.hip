@@ -38,8 +38,12 @@ EO_DEV EncUnits<P> encode_position(float x, float y, float z, int h) {
     return E;
 }
 
-template <class P, bool FULL, bool TRAIN>
+// MODE 0: inference.  1: training, everything saved.  2: training with the transient head OUTSIDE the autograd graph
+// (epoch_idx < 2: s = 1 and the loss is MSE on rgb -- train_eonerf.py:139-141, sat_rendering.py:269-272): its forward still
+// runs (ts / beta are outputs) but nothing of it is saved.
+template <class P, bool FULL, int MODE>
 __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
+    constexpr bool TRAIN = MODE != 0, TSAVE = MODE == 1;
     constexpr int SLOT = FwdSlot<P>::BYTES;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef typename P::U U;
@@ -47,6 +51,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
     constexpr int QKG = 128 / P::KF;      // ... of a 128-wide activation
     constexpr int EKG = ENC_SLOTS / P::KF;
     constexpr int NST = TRAIN ? (P::IS_BF16 ? 2 : 16) : 0;     // slab stores per m-tile epilogue (SlabWriter::tile)
+    constexpr int NST_T = TSAVE ? NST : 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
     const int n_pts = *a.n_pts;
@@ -80,6 +85,12 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 #pragma unroll
             for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
             if constexpr (TRAIN) sw.tile(act_row + 32 * mt, u);
+        };
+        auto relu_epi_t = [&](auto& dst, int act_row, int mt, const f32x16& accv) {      // transient head layers
+            const Units32<P> u = relu_pack_mask(P(), accv, mt, mbits[mt >> 1]);
+#pragma unroll
+            for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
+            if constexpr (TSAVE) sw.tile(act_row + 32 * mt, u);
         };
         auto save_mask = [&](int mask_slot, int nwords) {
             if constexpr (TRAIN) {
@@ -150,24 +161,24 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { if constexpr (P::IS_BF16) EMB[e] = (__bf16)ev[e]; else EMB[e] = ev[e]; }
             }
-            if constexpr (TRAIN) {
+            if constexpr (TSAVE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sw.elem(ACT_ROW_EMB + e, (float)EMB[e]);
             }
             U T1[QKG], T2[QKG];
-            run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true, NST>(ws, lane, h,
+            run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true, NST_T>(ws, lane, h,
                 [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : EMB; },
-                [&](int mt, const f32x16& v) { relu_epi(T1, ACT_ROW_T1, mt, v); });
-            save_mask(9, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST>(ws, lane, h, [&](int kg) { return T1[kg]; },
-                [&](int mt, const f32x16& v) { relu_epi(T2, ACT_ROW_T1 + 128, mt, v); });
-            save_mask(10, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST>(ws, lane, h, [&](int kg) { return T2[kg]; },
-                [&](int mt, const f32x16& v) { relu_epi(T1, ACT_ROW_T1 + 256, mt, v); });
-            save_mask(11, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST>(ws, lane, h, [&](int kg) { return T1[kg]; },
-                [&](int mt, const f32x16& v) { relu_epi(T2, ACT_ROW_T1 + 384, mt, v); });
-            save_mask(12, 2);
+                [&](int mt, const f32x16& v) { relu_epi_t(T1, ACT_ROW_T1, mt, v); });
+            if constexpr (TSAVE) save_mask(9, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, lane, h, [&](int kg) { return T1[kg]; },
+                [&](int mt, const f32x16& v) { relu_epi_t(T2, ACT_ROW_T1 + 128, mt, v); });
+            if constexpr (TSAVE) save_mask(10, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, lane, h, [&](int kg) { return T2[kg]; },
+                [&](int mt, const f32x16& v) { relu_epi_t(T1, ACT_ROW_T1 + 256, mt, v); });
+            if constexpr (TSAVE) save_mask(11, 2);
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, lane, h, [&](int kg) { return T1[kg]; },
+                [&](int mt, const f32x16& v) { relu_epi_t(T2, ACT_ROW_T1 + 384, mt, v); });
+            if constexpr (TSAVE) save_mask(12, 2);
             run_layer<P, SLOT, QKG, 1, 1, true>(ws, lane, h, [&](int kg) { return T2[kg]; },
                 [&](int, const f32x16& v) {
                     if (h == 0 && live) { a.ts[p] = sigmoid_f(v[0]); a.tb[p] = softplus_f(v[1]); }
@@ -176,27 +187,28 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
     }
 }
 
-template <class P, bool FULL, bool TRAIN>
+template <class P, bool FULL, int MODE>
 hipError_t launch(const MlpFwdArgs& a, int grid, hipStream_t st) {
-    constexpr int SMEM = 2 * FwdSlot<P>::BYTES + (TRAIN ? SlabWriter<P>::LDS_BYTES : 0);
+    constexpr int SMEM = 2 * FwdSlot<P>::BYTES + (MODE ? SlabWriter<P>::LDS_BYTES : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, TRAIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_mlp_fwd<P, FULL, TRAIN>), dim3(grid), dim3(P::NT), SMEM, st, a);
+    hipLaunchKernelGGL((k_mlp_fwd<P, FULL, MODE>), dim3(grid), dim3(P::NT), SMEM, st, a);
     return hipGetLastError();
+}
+
+template <class P> hipError_t dispatch(const MlpFwdArgs& a, bool full, int mode, int grid, hipStream_t st) {
+    if (full) return mode == 0 ? launch<P, true, 0>(a, grid, st) : (mode == 1 ? launch<P, true, 1>(a, grid, st) : launch<P, true, 2>(a, grid, st));
+    return mode == 0 ? launch<P, false, 0>(a, grid, st) : launch<P, false, 1>(a, grid, st);
 }
 
 }  // namespace
 
-hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, bool train, int grid, hipStream_t st) {
-    if (bf16) {
-        if (full) return train ? launch<PBf16, true, true>(a, grid, st) : launch<PBf16, true, false>(a, grid, st);
-        return train ? launch<PBf16, false, true>(a, grid, st) : launch<PBf16, false, false>(a, grid, st);
-    }
-    if (full) return train ? launch<PF32, true, true>(a, grid, st) : launch<PF32, true, false>(a, grid, st);
-    return train ? launch<PF32, false, true>(a, grid, st) : launch<PF32, false, false>(a, grid, st);
+// mode: 0 inference, 1 training, 2 training with the transient head outside the autograd graph (full variant only)
+hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st) {
+    return bf16 ? dispatch<PBf16>(a, full, mode, grid, st) : dispatch<PF32>(a, full, mode, grid, st);
 }

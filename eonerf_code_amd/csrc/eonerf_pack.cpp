@@ -129,7 +129,7 @@ PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full) {
 }
 
 // Backward chain: dX^T = W^T dY^T.  "row" = INPUT feature of the forward layer, "slot" = OUTPUT feature.
-PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad) {
+PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient) {
     PackedStream s;
     const int KF = bf16 ? 16 : 8;
     const int HKG = 256 / KF, QKG = 128 / KF;
@@ -138,18 +138,24 @@ PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool 
             [=, &pl](int row, int slot) { return (slot < out_rows && row < in_cols) ? pl.at(wi, slot, row) : -1; }, nullptr});
     };
     if (full) {
-        // d{ts_pre, tb_pre} (slots 0,1) -> T4 (128)
-        append_layer(s, bf16, PackLayer{1, 4, false,
-            [&](int row, int slot) { return slot == 0 ? pl.at(pl.tsc_w, 0, row) : (slot == 1 ? pl.at(pl.tbe_w, 0, row) : -1); }, nullptr});
-        for (int l = 3; l >= 1; --l) transposed(pl.t_w[l], 128, 128, QKG, 4);
+        if (transient) {
+            // d{ts_pre, tb_pre} (slots 0,1) -> T4 (128)
+            append_layer(s, bf16, PackLayer{1, 4, false,
+                [&](int row, int slot) { return slot == 0 ? pl.at(pl.tsc_w, 0, row) : (slot == 1 ? pl.at(pl.tbe_w, 0, row) : -1); }, nullptr});
+            for (int l = 3; l >= 1; --l) transposed(pl.t_w[l], 128, 128, QKG, 4);
+        }
         // d albedo_pre (slots 0..2) -> A1 (128)
         transposed(pl.a2_w, 3, 128, 1, 4);
-        // [dY_A1 (slots 0..127), dY_T1 (slots 128..255)] -> bottleneck rows 0..255, embedding rows 256..259
-        append_layer(s, bf16, PackLayer{2 * QKG, 9, false,
-            [&](int row, int slot) {
-                if (slot < 128) return row < 256 ? pl.at(pl.a1_w, slot, row) : -1;
-                return row < 260 ? pl.at(pl.t_w[0], slot - 128, row) : -1;
-            }, nullptr});
+        if (transient) {
+            // [dY_A1 (slots 0..127), dY_T1 (slots 128..255)] -> bottleneck rows 0..255, embedding rows 256..259
+            append_layer(s, bf16, PackLayer{2 * QKG, 9, false,
+                [&](int row, int slot) {
+                    if (slot < 128) return row < 256 ? pl.at(pl.a1_w, slot, row) : -1;
+                    return row < 260 ? pl.at(pl.t_w[0], slot - 128, row) : -1;
+                }, nullptr});
+        } else {
+            transposed(pl.a1_w, 128, 256, QKG, 8);      // dY_A1 -> d bottleneck
+        }
         // [d bottleneck (slots 0..255), d sigma_pre (slot 256)] -> X8
         append_layer(s, bf16, PackLayer{HKG + 1, 8, false,
             [&](int row, int slot) { return slot < 256 ? pl.at(pl.bot_w, slot, row) : (slot == 256 ? pl.at(pl.sig_w, 0, row) : -1); }, nullptr});

@@ -42,5 +42,5 @@ struct PackLayer {
 
 void append_layer(PackedStream& s, bool bf16, const PackLayer& L);
 PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full);
-PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad);
+PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient = true);
 int enc_col_of_slot(bool bf16, int slot);      // reference encoding column (mlp.py:190-208) of an encoding slot, -1 = pad

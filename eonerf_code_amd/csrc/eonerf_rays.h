@@ -52,6 +52,7 @@ struct ShadeBwdArgs {
     float* d_radiometric;       // inside the flat gradient buffer, or nullptr
     float* g_ray;               // [R][RAY_REC] gradient of the per-ray record
     int n_rays, use_shadow, eval;
+    int lds_images;             // > 0: accumulate d_radiometric[n_img][6] in LDS first (n_img <= 2048)
 };
 
 struct CompositeBwdArgs {
@@ -87,6 +88,7 @@ hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st);
+hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st);
 hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
                           float gscale, hipStream_t st);
 hipError_t eo_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);

@@ -8,43 +8,57 @@ namespace {
 
 // ---- shading backward: d out[R,21] -> d ray record, d radiometric table ------------------------------------
 __global__ __launch_bounds__(256) void k_shade_bwd(ShadeBwdArgs a) {
+    extern __shared__ float s_dT[];                    // [n_img][6] block-local radiometric gradient (0 floats if unused)
     const int ray = blockIdx.x * 256 + threadIdx.x;
-    if (ray >= a.n_rays) return;
-    const float* r = a.ray_rec + (size_t)ray * RAY_REC;
-    const float* go = a.d_out + (size_t)ray * 21;
-    float* g = a.g_ray + (size_t)ray * RAY_REC;
-    const float wsum = r[RR_WSUM], ts = r[RR_TS];
-    const float geo = a.use_shadow ? r[RR_GEO] : 1.0f;
-    const float s = a.use_shadow ? geo * ts : 1.0f;
-    const long img = a.eval ? a.img_idx[0] : a.img_idx[ray];
-    const float* T = a.radiometric ? a.radiometric + img * 9 : nullptr;
-    float* dT = a.d_radiometric ? a.d_radiometric + img * 9 : nullptr;
-    float g_s = 0.f, g_wsum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float alb = r[RR_ALB + c], head = r[RR_AMB + c];
-        const float amb = (wsum * head) * 0.2f;
-        const float pre = alb * s + (1.f - s) * (amb * alb);
-        const float A = T ? T[c] : 1.f, b = T ? T[3 + c] : 0.f;
-        const float lin = A * pre + b;
-        const float g_lin = (lin >= 0.f && lin <= 1.f) ? go[c] : 0.f;        // torch.clip backward (inclusive bounds)
-        const float g_shl = go[18 + c];
-        if (dT) {
-            atomicAdd(dT + c, g_lin * pre + g_shl * alb);
-            atomicAdd(dT + 3 + c, g_lin + g_shl);
-        }
-        const float g_pre = g_lin * A;
-        g[RR_ALB + c] = g_pre * (s + (1.f - s) * amb) + go[4 + c] + g_shl * A;
-        const float g_amb = g_pre * (1.f - s) * alb + go[7 + c];
-        g_s += g_pre * (alb - amb * alb);
-        g_wsum += g_amb * 0.2f * head;
-        g[RR_AMB + c] = g_amb * 0.2f * wsum;
+    const bool lds_acc = a.d_radiometric && a.lds_images > 0;
+    if (lds_acc) {
+        for (int i = threadIdx.x; i < a.lds_images * 6; i += 256) s_dT[i] = 0.f;
+        __syncthreads();
     }
-    g[RR_DEPTH] = go[3];
-    g[RR_TS] = (a.use_shadow ? g_s * geo : 0.f) + go[11];
-    g[RR_GEO] = a.use_shadow ? g_s * ts + go[10] : 0.f;
-    g[RR_TB] = go[12];
-    g[RR_WSUM] = g_wsum;
+    if (ray < a.n_rays) {
+        const float* r = a.ray_rec + (size_t)ray * RAY_REC;
+        const float* go = a.d_out + (size_t)ray * 21;
+        float* g = a.g_ray + (size_t)ray * RAY_REC;
+        const float wsum = r[RR_WSUM], ts = r[RR_TS];
+        const float geo = a.use_shadow ? r[RR_GEO] : 1.0f;
+        const float s = a.use_shadow ? geo * ts : 1.0f;
+        const long img = a.eval ? a.img_idx[0] : a.img_idx[ray];
+        const float* T = a.radiometric ? a.radiometric + img * 9 : nullptr;
+        float g_s = 0.f, g_wsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float alb = r[RR_ALB + c], head = r[RR_AMB + c];
+            const float amb = (wsum * head) * 0.2f;
+            const float pre = alb * s + (1.f - s) * (amb * alb);
+            const float A = T ? T[c] : 1.f, b = T ? T[3 + c] : 0.f;
+            const float lin = A * pre + b;
+            const float g_lin = (lin >= 0.f && lin <= 1.f) ? go[c] : 0.f;        // torch.clip backward (inclusive bounds)
+            const float g_shl = go[18 + c];
+            if (a.d_radiometric) {
+                const float dA = g_lin * pre + g_shl * alb, db = g_lin + g_shl;
+                if (lds_acc) { atomicAdd(&s_dT[img * 6 + c], dA); atomicAdd(&s_dT[img * 6 + 3 + c], db); }
+                else { atomicAdd(a.d_radiometric + img * 9 + c, dA); atomicAdd(a.d_radiometric + img * 9 + 3 + c, db); }
+            }
+            const float g_pre = g_lin * A;
+            g[RR_ALB + c] = g_pre * (s + (1.f - s) * amb) + go[4 + c] + g_shl * A;
+            const float g_amb = g_pre * (1.f - s) * alb + go[7 + c];
+            g_s += g_pre * (alb - amb * alb);
+            g_wsum += g_amb * 0.2f * head;
+            g[RR_AMB + c] = g_amb * 0.2f * wsum;
+        }
+        g[RR_DEPTH] = go[3];
+        g[RR_TS] = (a.use_shadow ? g_s * geo : 0.f) + go[11];
+        g[RR_GEO] = a.use_shadow ? g_s * ts + go[10] : 0.f;
+        g[RR_TB] = go[12];
+        g[RR_WSUM] = g_wsum;
+    }
+    if (lds_acc) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.lds_images * 6; i += 256) {
+            const float v = s_dT[i];
+            if (v != 0.f) atomicAdd(a.d_radiometric + (i / 6) * 9 + (i % 6), v);
+        }
+    }
 }
 
 // ---- shadow-ray transmittance backward: geo = exp(-sum_{j<last} sigma_j delta_j) ------------------------------
@@ -128,6 +142,7 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
 
 // ---- ambient head backward (radiance_fields/eonerf.py:132-139): one thread per hidden unit, rays strided over WGs
 __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
+    __shared__ float s_enc[2][32];
     const int j = threadIdx.x;
     float dw1[27], dw2[3] = {0.f, 0.f, 0.f}, db1 = 0.f, db2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -137,12 +152,25 @@ __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
     for (int i = 0; i < 27; ++i) w1[i] = a.w.w1[j * 27 + i];
     const float b1 = a.w.b1[j];
     const float w2[3] = {a.w.w2[j], a.w.w2[128 + j], a.w.w2[256 + j]};
-    for (int ray = blockIdx.x; ray < a.n_rays; ray += gridDim.x) {
+    int buf = 0;
+    for (int ray = blockIdx.x; ray < a.n_rays; ray += gridDim.x, buf ^= 1) {
         const float* r = a.rays + (size_t)ray * 11;
         const float* rec = a.ray_rec + (size_t)ray * RAY_REC;
         const float* g = a.g_ray + (size_t)ray * RAY_REC;
+        if (j < 27) {          // one encoding element per thread (same arithmetic as sun_encoding)
+            float v;
+            if (j < 3) v = r[8 + j];
+            else {
+                const int q = (j - 3) % 12, k = q / 3, d = q % 3;
+                const float xb = r[8 + d] * (float)(1 << k);
+                v = j < 15 ? sinf(xb) : sinf(xb + EO_PI_2_F);
+            }
+            s_enc[buf][j] = v;
+        }
+        __syncthreads();       // double-buffered: the next iteration writes the other buffer
         float enc[27];
-        sun_encoding(r[8], r[9], r[10], enc);
+#pragma unroll
+        for (int i = 0; i < 27; ++i) enc[i] = s_enc[buf][i];
         float hid = b1;
 #pragma unroll
         for (int i = 0; i < 27; ++i) hid = fmaf(w1[i], enc[i], hid);
@@ -194,6 +222,33 @@ __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
     }
 }
 
+// ---- training loss and its gradient on the packed outputs (train_eonerf.py:139-143) ------------------------------
+//   kind 0: F.mse_loss(rgb, gt)                          kind 1: metrics.uncertainty_aware_loss (metrics.py:17-22)
+__global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss) {
+    const int ray = blockIdx.x * 256 + threadIdx.x;
+    float part = 0.f;
+    if (ray < n) {
+        const float* o = out + (size_t)ray * 21;
+        float* d = d_out + (size_t)ray * 21;
+#pragma unroll
+        for (int c = 0; c < 21; ++c) d[c] = 0.f;
+        const float inv = 1.f / (3.f * n);
+        if (kind == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float df = o[c] - gt[(size_t)ray * 3 + c]; part += df * df * inv; d[c] = 2.f * df * inv; }
+        } else {
+            const float beta = o[12], ib2 = 1.f / (beta * beta);
+            float sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float df = o[c] - gt[(size_t)ray * 3 + c]; sq += df * df; d[c] = df * ib2 * inv; }
+            part = 0.5f * sq * ib2 * inv + 0.5f * logf(beta) / n;
+            d[12] = -sq * ib2 / beta * inv + 0.5f / (n * beta);
+        }
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, part);
+}
+
 // ---- torch.optim.Adam (no weight decay, no amsgrad) on the flat buffers --------------------------------------
 __global__ void k_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                        float bc1, float bc2_sqrt, float gscale) {
@@ -210,7 +265,7 @@ __global__ void k_adam(float* p, const float* g, float* m, float* v, size_t n, f
 }  // namespace
 
 hipError_t eo_launch_shade_bwd(const ShadeBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade_bwd, dim3((a.n_rays + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_shade_bwd, dim3((a.n_rays + 255) / 256), dim3(256), (size_t)a.lds_images * 6 * sizeof(float), st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {
@@ -231,6 +286,12 @@ hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st) {
 }
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_emb_grad, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_loss, dim3((n + 255) / 256), dim3(256), 0, st, out, gt, n, kind, d_out, loss);
     return hipGetLastError();
 }
 hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,

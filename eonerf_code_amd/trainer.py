@@ -52,6 +52,7 @@ class FusedTrainer:
         self.out = torch.empty(max_rays, 21, dtype=torch.float32, device=dev)
         self.d_out = torch.zeros(max_rays, 21, dtype=torch.float32, device=dev)
         self.n_samples = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.zsteps = _zsteps(dev)
         if self.world > 1:     # identical replicas: broadcast rank 0's parameters once (train_eonerf.py has one process)
             torch.distributed.broadcast(self.flat, src=0)
@@ -72,26 +73,18 @@ class FusedTrainer:
 
     def loss_grad(self, out, pixels, epoch_idx, d_out):
         """train_eonerf.py:139-143: MSE for epoch < 2, metrics.uncertainty_aware_loss (metrics.py:17-22) afterwards.
-        Writes dL/d out into d_out (only the rgb and beta columns are non-zero); returns the loss (device scalar)."""
+        One kernel writes dL/d out into d_out (only the rgb and beta columns are non-zero) and the loss scalar."""
         n = out.shape[0]
-        diff = out[:, 0:3] - pixels
-        if epoch_idx < 2:
-            loss = (diff * diff).mean()
-            d_out[:n, 0:3] = diff * (2.0 / (3 * n))
-            d_out[:n, 12] = 0
-        else:
-            beta = out[:, 12:13]
-            inv_b2 = 1.0 / (beta * beta)
-            loss = (diff * diff * inv_b2).mean() * 0.5 + (3 + torch.log(beta).mean()) * 0.5
-            d_out[:n, 0:3] = diff * inv_b2 * (1.0 / (3 * n))
-            d_out[:n, 12:13] = -(diff * diff).sum(dim=1, keepdim=True) * inv_b2 / beta * (1.0 / (3 * n)) + 0.5 / (n * beta)
-        return loss
+        kind = 0 if epoch_idx < 2 else 1
+        _lib.check(self.L.eonerf_train_loss(self.ctx, _ptr(out), _ptr(pixels), n, kind, _ptr(d_out), _ptr(self.loss), _stream()))
+        return self.loss if kind == 0 else self.loss + 1.5      # the beta term's constant 3/2
 
     def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False):
         """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar."""
         n = rays.shape[0]
         dev = rays.device
-        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else 0)
+        # epoch < 2: s = 1 and the loss is MSE on rgb, so the transient head is outside the autograd graph (F_RGB_LOSS)
+        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else _lib.F_RGB_LOSS)
         if noise is None:
             u = torch.rand(3 if flags & _lib.F_SHADOWS else 2, n, 128, device=dev)
             u_cam, u_retry, u_sun = u[0], u[1], (u[2] if flags & _lib.F_SHADOWS else None)
@@ -102,7 +95,7 @@ class FusedTrainer:
         _lib.check(self.L.eonerf_render_forward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), _ptr(self.zsteps),
                                                 _ptr(u_cam), _ptr(u_retry), _ptr(u_sun), n, flags, _ptr(self.out), _ptr(self.n_samples),
                                                 _ptr(ws), ws.numel(), st))
-        loss = self.loss_grad(self.out[:n], pixels, epoch_idx, self.d_out)
+        loss = self.loss_grad(self.out[:n], pixels.contiguous(), epoch_idx, self.d_out)
         self.d_flat.zero_()
         _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
                                                  _ptr(self.d_flat), _ptr(ws), ws.numel(), st))

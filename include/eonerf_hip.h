@@ -34,7 +34,11 @@ enum { EONERF_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (pari
 enum { EONERF_F_SHADOWS = 1,     /* epoch_idx >= 2: shadow-ray pass + s = geo_shadow * transient_s (sat_rendering.py:269-276) */
        EONERF_F_EVAL = 2,        /* eval=True: radiometric row of the chunk's first ray (sat_rendering.py:288-291) */
        EONERF_F_TRAIN = 4,       /* keep what eonerf_render_backward needs in the workspace */
-       EONERF_F_ONLY_DEPTH = 8 };/* only_depth=True branch (sat_rendering.py:227-249): out[:,3] only */
+       EONERF_F_ONLY_DEPTH = 8,  /* only_depth=True branch (sat_rendering.py:227-249): out[:,3] only */
+       EONERF_F_RGB_LOSS = 16 }; /* with F_TRAIN and without F_SHADOWS: the caller's loss depends on rgb/depth/albedo only, i.e.
+                                  * d_out[:,11:13] (transient_s, beta) == 0 -- exactly the reference's epoch < 2 graph (s = 1,
+                                  * F.mse_loss on rgb; train_eonerf.py:139-141, sat_rendering.py:269-272), where autograd never
+                                  * visits the transient head.  Its activations are then not saved and its backward is skipped. */
 
 typedef struct eonerf_ctx eonerf_ctx;
 
@@ -93,6 +97,11 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat_params, const float
 int eonerf_render_backward(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
                            int n_rays, int flags, const float* d_out, float* d_flat_params,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* Training loss on the packed outputs and its gradient (train_eonerf.py:139-143): kind 0 = F.mse_loss(rgb, pixels),
+ * kind 1 = metrics.uncertainty_aware_loss(pixels, rgb, beta) (metrics.py:17-22; the constant 3/2 of its beta term is
+ * NOT included in *loss).  Writes d_out[R,21] (zero except the rgb/beta columns) and the scalar *loss (device). */
+int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, int n_rays, int kind, float* d_out, float* loss, void* stream);
 
 /* torch.optim.Adam step on the flat buffers (train_eonerf.py:63,161): lr, betas (0.9,0.999), eps 1e-8, no weight decay.
  * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
