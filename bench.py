@@ -38,6 +38,14 @@ MAC_DENS_FWD = 491008 + 256
 MAC_DENS_BWD = 491008 + 256           # incl. input gradient through layer 0 / skip columns
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP32_TFLOPS = 157.3
+# HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units; see
+# profiles/README.md) on the default workload; null for configurations that were not profiled
+TRAFFIC = {}
+try:
+    with open(os.path.join(REPO, "profiles", "traffic.json")) as _f:
+        TRAFFIC = json.load(_f).get("rgb_bf16", {})
+except OSError:
+    pass
 
 
 def cpu_baseline(workload, n_rays=128, reps=1):
@@ -133,8 +141,24 @@ def main():
             pass   # shadow-pass kernels are reported by --workload full runs through avg_ms only (sample count differs)
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         macs = mac_of[dom]
-        achieved = kernels[dom]["tflops"]
         step_flops = 2.0 * sum(mac_of.values()) * n_cam
+        # HBM bytes each kernel must move per sample (bf16 slabs): rows x 2 B
+        rows_rd_wgrad = (2816 + 2692) if args.workload == "rgb" else (3392 + 3268)
+        bytes_of = {"fwd_chain_camera": (2496 if args.workload == "rgb" else 3040) * 2 + 9 * 32,
+                    "bwd_chain_camera": (2500 if args.workload == "rgb" else 3040) * 2 + 9 * 32,
+                    "wgrad_gemm": rows_rd_wgrad * 2}
+        elt = 2 if args.precision == "bf16" else 4
+        for name in kernels:
+            kernels[name]["hbm_gbps"] = bytes_of[name] * (elt / 2) * n_cam / (kernels[name]["avg_ms"] * 1e-3) / 1e9
+        if dom == "wgrad_gemm":      # 131 FLOP/B: HBM-bound
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["hbm_gbps"], "peak": 8000.0, "unit": "GB/s",
+                        "frac": kernels[dom]["hbm_gbps"] / 8000.0, "traffic": TRAFFIC.get(dom),
+                        "algorithmic_bytes_per_launch": bytes_of[dom] * (elt / 2) * n_cam, "avg_launch_ms": kernels[dom]["avg_ms"],
+                        "mfma_tflops": kernels[dom]["tflops"]}
+        else:
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                        "frac": kernels[dom]["tflops"] / peak, "traffic": TRAFFIC.get(dom),
+                        "algorithmic_flop_per_launch": 2.0 * macs * n_cam, "avg_launch_ms": kernels[dom]["avg_ms"]}
         result = {
             "metric": "train rays/sec on JAX_068 (4096 rays x 128 samples)", "value": world * RAYS * args.steps / dt, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -144,9 +168,7 @@ def main():
                                     "JAX_068-like synthetic rays, full EO-NeRF (shadow-ray pass + uncertainty loss), 4096 rays x 128 samples per GPU"),
                        "rays_per_gpu": RAYS, "n_samples": 128, "n_images": N_IMG, "parallelism": f"dp{world}",
                        "camera_samples_per_step": n_cam, "final_loss": float(loss)},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None,
-                         "algorithmic_flop_per_launch": 2.0 * macs * n_cam, "avg_launch_ms": kernels[dom]["avg_ms"]},
+            "roofline": roofline,
             "kernels": kernels,
             "step_mfma_frac": step_flops / (ms_step * 1e-3) / 1e12 / peak,
         }

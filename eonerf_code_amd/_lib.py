@@ -19,7 +19,7 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_param_info", "eonerf_param_floats", "eonerf_set_weights", "eonerf_field_workspace_bytes",
            "eonerf_render_workspace_bytes", "eonerf_field_forward", "eonerf_query_density", "eonerf_render_forward",
            "eonerf_render_backward", "eonerf_adam_step", "eonerf_profile_enable", "eonerf_profile_read",
-           "eonerf_train_loss"]
+           "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering"]
 
 
 class EonerfConfig(C.Structure):
@@ -71,6 +71,8 @@ def lib():
     L.eonerf_render_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp]
     L.eonerf_train_loss.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
+    L.eonerf_sample_rays.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.eonerf_rendering.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_profile_enable.argtypes = [vp, i]
     L.eonerf_profile_read.argtypes = [vp, i, C.POINTER(fp), C.POINTER(i)]
     for name in SYMBOLS:

@@ -347,6 +347,59 @@ int eonerf_query_density(eonerf_ctx* ctx, const float* flat, const float* xyz, i
     return EONERF_OK;
 }
 
+int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, const float* u, int n_rays,
+                       int64_t* ray_indices, float* t_starts, float* t_ends, float* pts_per_ray, int* n_dev,
+                       void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rays == 0) return EONERF_OK;
+    if (!ctx || !rays || !zsteps || !u || !ray_indices || !t_starts || !t_ends || n_rays < 0 || !ws) return EONERF_E_ARG;
+    RenderWs w = carve_render(ctx, ws, n_rays, EONERF_F_ONLY_DEPTH);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * sizeof(int), st));
+    SampleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.rays = rays; sa.zsteps = zsteps; sa.u = u; sa.n_rays = n_rays;
+    sa.cnt_first = w.cnt_first; sa.cnt_retry = w.cnt_retry; sa.counts = w.cam.counts; sa.offsets = w.cam.offsets;
+    sa.flags = w.flags; sa.n_pts = w.cam.n_pts;
+    sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
+    sa.o_ray = ray_indices; sa.o_ts = t_starts; sa.o_te = t_ends;
+    HIP_TRY(eo_launch_sampler(sa, st));
+    if (n_dev) HIP_TRY(hipMemcpyAsync(n_dev, w.cam.n_pts, sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (pts_per_ray) HIP_TRY(eo_launch_int_to_float(w.cam.counts, n_rays, pts_per_ray, st));
+    return EONERF_OK;
+}
+
+int eonerf_rendering(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
+                     const float* t_starts, const float* t_ends, const int64_t* ray_indices, int n, int n_rays, int depth_only,
+                     float* albedo, float* depth, float* beta, float* transient_s, float* ambient, float* entropy,
+                     void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx || !flat || !rays || !depth || n < 0 || n_rays < 1 || !ws) return EONERF_E_ARG;
+    if (n > 0 && (!t_starts || !t_ends || !ray_indices)) return EONERF_E_ARG;
+    if (!depth_only && (!albedo || !beta || !transient_s || !ambient || !entropy || !img_idx)) return EONERF_E_ARG;
+    if (!ctx->weights_set) return EONERF_E_STATE;
+    if (n > n_rays * 127) return EONERF_E_UNSUPPORTED;           // at most 127 intervals per ray (n_samples = 128)
+    const int flags = depth_only ? EONERF_F_ONLY_DEPTH : 0;
+    RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    const int p_cap = p_cap_of(n_rays);
+    PackedArgs pa;
+    pa.rays = rays; pa.img_idx = img_idx; pa.t_starts = t_starts; pa.t_ends = t_ends; pa.ray_indices = ray_indices;
+    pa.n = n; pa.n_rays = n_rays; pa.counts = w.cam.counts; pa.offsets = w.cam.offsets; pa.n_pts = w.cam.n_pts;
+    pa.px = w.cam.px; pa.py = w.cam.py; pa.pz = w.cam.pz; pa.tmid = w.cam.tmid; pa.delta = w.cam.delta; pa.simg = w.cam.simg;
+    HIP_TRY(eo_launch_from_packed(pa, st));
+    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !depth_only, 0, st);
+    if (rc) return rc;
+    CompositeArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.rays = rays; ca.offsets = w.cam.offsets; ca.counts = w.cam.counts;
+    ca.sigma = w.cam.sigma; ca.delta = w.cam.delta; ca.tmid = w.cam.tmid; ca.albedo = w.cam.albedo; ca.ts = w.cam.ts; ca.tb = w.cam.tb;
+    ca.p_pad = p_cap; ca.n_rays = n_rays; ca.depth_only = depth_only ? 1 : 0; ca.amb = ambient_w(ctx, flat); ca.ray_out = w.ray_rec;
+    HIP_TRY(eo_launch_composite_fwd(ca, st));
+    RenderingOutArgs ro{w.ray_rec, n_rays, depth_only ? nullptr : albedo, depth, beta, transient_s, ambient, entropy};
+    return (int)eo_launch_rendering_out(ro, st);
+}
+
 int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
                           const float* zsteps, const float* u_cam, const float* u_retry, const float* u_sun,
                           int n_rays, int flags, float* out, int* n_samples_dev,

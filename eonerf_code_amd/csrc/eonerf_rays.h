@@ -24,6 +24,8 @@ struct SampleArgs {
     int* n_pts;
     float *px, *py, *pz, *tmid, *delta;   // [p_pad] compact outputs
     int* simg;
+    // optional flattened outputs of satnerf_sampling (sat_rendering.py:82-84): ray_indices, t_starts, t_ends
+    int64_t* o_ray; float *o_ts, *o_te;
 };
 
 struct CompositeArgs {
@@ -81,7 +83,19 @@ struct EmbGradArgs {
     int n_rays;
 };
 
+struct PackedArgs {        // flattened samples handed in by the caller (EONerfMLP.rendering / render_depth)
+    const float* rays; const int64_t* img_idx;
+    const float *t_starts, *t_ends; const int64_t* ray_indices;
+    int n, n_rays;
+    int *counts, *offsets, *n_pts;
+    float *px, *py, *pz, *tmid, *delta; int* simg;
+};
+struct RenderingOutArgs { const float* ray_rec; int n_rays; float *albedo, *depth, *beta, *ts, *ambient, *entropy; };
+
 hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st);
+hipError_t eo_launch_from_packed(const PackedArgs& a, hipStream_t st);
+hipError_t eo_launch_rendering_out(const RenderingOutArgs& a, hipStream_t st);
+hipError_t eo_launch_int_to_float(const int* src, int n, float* dst, hipStream_t st);
 hipError_t eo_launch_shade_bwd(const ShadeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st);

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
         // camera pass: the last interval of every ray ends at 1e10 (radiance_fields/eonerf.py:218-220)
         const float te = (a.patch_last && rank == n - 1) ? 1e10f : s.te[k];
         a.delta[p] = __fsub_rn(te, s.ts[k]);
+        if (a.o_ts) { a.o_ray[p] = ray; a.o_ts[p] = s.ts[k]; a.o_te[p] = s.te[k]; }
     }
 }
 
@@ -234,6 +235,50 @@ __global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
     o[16] = 1.0f; o[17] = 1.0f;                                            // opacity_after_surface, :283
 }
 
+// ---- caller-provided flattened samples (radiance_fields/eonerf.py:196-220: gather, mid points, last t_end := 1e10) ----
+__global__ void k_packed_bounds(PackedArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    const int64_t ray = a.ray_indices[p];
+    if (p == 0 || a.ray_indices[p - 1] != ray) a.offsets[ray] = p;
+    if (p == a.n - 1 || a.ray_indices[p + 1] != ray) a.counts[ray] = p + 1;       // end index, turned into a count below
+}
+__global__ void k_packed_emit(PackedArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) { a.offsets[a.n_rays] = a.n; *a.n_pts = a.n; }
+    if (p >= a.n) return;
+    const int64_t ray = a.ray_indices[p];
+    const float* r = a.rays + (size_t)ray * 11;
+    const float ts = a.t_starts[p], te = a.t_ends[p];
+    const float mid = __fdiv_rn(__fadd_rn(ts, te), 2.0f);
+    a.px[p] = __fadd_rn(r[0], __fmul_rn(r[3], mid));
+    a.py[p] = __fadd_rn(r[1], __fmul_rn(r[4], mid));
+    a.pz[p] = __fadd_rn(r[2], __fmul_rn(r[5], mid));
+    a.tmid[p] = mid;
+    const bool last = p == a.n - 1 || a.ray_indices[p + 1] != ray;
+    a.delta[p] = __fsub_rn(last ? 1e10f : te, ts);
+    a.simg[p] = a.img_idx ? (int)a.img_idx[ray] : 0;
+}
+__global__ void k_packed_counts(PackedArgs a) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= a.n_rays) return;
+    const int end = a.counts[ray];
+    a.counts[ray] = end > 0 ? end - a.offsets[ray] : 0;
+}
+__global__ void k_int_to_float(const int* src, int n, float* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+__global__ void k_rendering_out(RenderingOutArgs a) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= a.n_rays) return;
+    const float* r = a.ray_rec + (size_t)ray * RAY_REC;
+    a.depth[ray] = r[RR_DEPTH];
+    if (!a.albedo) return;
+    for (int c = 0; c < 3; ++c) { a.albedo[3 * ray + c] = r[RR_ALB + c]; a.ambient[3 * ray + c] = r[RR_WSUM] * r[RR_AMB + c]; }
+    a.beta[ray] = r[RR_TB]; a.ts[ray] = r[RR_TS]; a.entropy[ray] = 1.0f;
+}
+
 // ---- small utility kernels ---------------------------------------------------------------------------------
 __global__ void k_points_to_soa(const float* xyz, const int64_t* img, int n, int p_pad, float* px, float* py, float* pz,
                                 int* simg, int* n_pts) {
@@ -267,6 +312,24 @@ hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_from_packed(const PackedArgs& a, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(a.counts, 0, sizeof(int) * a.n_rays, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.offsets, 0, sizeof(int) * (a.n_rays + 1), st);
+    if (e != hipSuccess) return e;
+    const int nb = (a.n + 255) / 256 > 0 ? (a.n + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_packed_bounds, dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_packed_counts, dim3((a.n_rays + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_packed_emit, dim3(nb), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_int_to_float(const int* src, int n, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_int_to_float, dim3((n + 255) / 256), dim3(256), 0, st, src, n, dst);
+    return hipGetLastError();
+}
+hipError_t eo_launch_rendering_out(const RenderingOutArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_rendering_out, dim3((a.n_rays + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {

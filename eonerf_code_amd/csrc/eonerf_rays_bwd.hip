@@ -189,14 +189,15 @@ __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 27; ++i) dw1[i] += ghid * enc[i];
     }
+    // zero contributions are skipped: with the shadow pass off the ambient head is outside the graph (1 - s == 0)
 #pragma unroll
-    for (int i = 0; i < 27; ++i) atomicAdd(a.d_w1 + j * 27 + i, dw1[i]);
-    atomicAdd(a.d_b1 + j, db1);
+    for (int i = 0; i < 27; ++i) if (dw1[i] != 0.f) atomicAdd(a.d_w1 + j * 27 + i, dw1[i]);
+    if (db1 != 0.f) atomicAdd(a.d_b1 + j, db1);
 #pragma unroll
-    for (int o = 0; o < 3; ++o) atomicAdd(a.d_w2 + o * 128 + j, dw2[o]);
+    for (int o = 0; o < 3; ++o) if (dw2[o] != 0.f) atomicAdd(a.d_w2 + o * 128 + j, dw2[o]);
     if (j == 0) {
 #pragma unroll
-        for (int o = 0; o < 3; ++o) atomicAdd(a.d_b2 + o, db2[o]);
+        for (int o = 0; o < 3; ++o) if (db2[o] != 0.f) atomicAdd(a.d_b2 + o, db2[o]);
     }
 }
 
@@ -281,7 +282,7 @@ hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st
     return hipGetLastError();
 }
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_ambient_bwd, dim3(a.n_rays < 256 ? a.n_rays : 256), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_ambient_bwd, dim3(a.n_rays < 64 ? a.n_rays : 64), dim3(128), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {

@@ -167,3 +167,40 @@ class EONerfMLP(nn.Module):
         _lib.check(L.eonerf_field_forward(self._ctx, _ptr(flat), _ptr(xs), _ptr(sun), _ptr(img), n, _ptr(sigma), _ptr(albedo),
                                           _ptr(ambient), _ptr(ts), _ptr(tb), _ptr(ws), ws.numel(), _stream()))
         return sigma.view(n, 1), albedo, ambient, ts.view(n, 1), tb.view(n, 1)
+
+    @torch.no_grad()
+    def _rendering(self, chunk_rays, t_starts, t_ends, ray_indices, depth_only):
+        from ..datasets.satellite import satrays_to_table
+        flat = self._ensure_packed()
+        table, img = satrays_to_table(chunk_rays)
+        n_rays, n = table.shape[0], t_starts.shape[0]
+        dev = table.device
+        ts_, te_ = t_starts.float().contiguous(), t_ends.float().contiguous()
+        ri = ray_indices.to(torch.int64).contiguous()
+        depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+        if depth_only:
+            albedo = beta = tsc = ambient = entropy = None
+        else:
+            albedo, ambient = (torch.empty(n_rays, 3, dtype=torch.float32, device=dev) for _ in range(2))
+            beta, tsc, entropy = (torch.empty(n_rays, 1, dtype=torch.float32, device=dev) for _ in range(3))
+        L = _lib.lib()
+        nb = L.eonerf_render_workspace_bytes(self._ctx, n_rays, _lib.F_ONLY_DEPTH if depth_only else 0)
+        ws = self._workspace("render", nb)
+        _lib.check(L.eonerf_rendering(self._ctx, _ptr(flat), _ptr(table), _ptr(img), _ptr(ts_), _ptr(te_), _ptr(ri), n, n_rays,
+                                      1 if depth_only else 0, _ptr(albedo), _ptr(depth), _ptr(beta), _ptr(tsc), _ptr(ambient),
+                                      _ptr(entropy), _ptr(ws), ws.numel(), _stream()))
+        # the reference patches the caller's t_ends in place (eonerf.py:218-220): last interval of every ray -> 1e10
+        if n > 0:
+            last = torch.ones(n, dtype=torch.bool, device=dev)
+            last[:-1] = ri[1:] != ri[:-1]
+            t_ends[last] = 1e10
+        return albedo, depth, beta, tsc, ambient, entropy
+
+    def render_depth(self, chunk_rays, t_starts, t_ends, ray_indices):
+        """radiance_fields/eonerf.py:172-194: flattened samples -> depth [n_rays, 1]."""
+        return self._rendering(chunk_rays, t_starts, t_ends, ray_indices, True)[1]
+
+    def rendering(self, chunk_rays, t_starts, t_ends, ray_indices, epoch_idx=100):
+        """radiance_fields/eonerf.py:196-248: -> (albedo_rgb_, depth_, transient_beta_, transient_scalar_, ambient_rgb_, entropy_).
+        Inference entry point; render_image fuses this with sampling, the shadow pass and autograd."""
+        return self._rendering(chunk_rays, t_starts, t_ends, ray_indices, False)

@@ -31,6 +31,54 @@ def _zsteps(device):
     return z
 
 
+def count_number_of_pts_per_nerfacc_ray(rays, ray_indices):
+    """sat_rendering.py:10-16: fp32 number of samples of every ray (0 for rays without samples)."""
+    n_rays = rays.origins.shape[0]
+    return torch.bincount(ray_indices, minlength=n_rays).to(rays.origins.dtype)
+
+
+@torch.no_grad()
+def satnerf_sampling(origins, viewdirs, sampling_args, near=None, far=None, perturb=True, noise=None, radiance_field=None):
+    """sat_rendering.py:56-84: (ray_indices, t_starts, t_ends) of the cube-filtered stratified samples.
+    `far` is ignored exactly as in the reference (far = near + 2); noise [R,128] replaces the rand_like draw."""
+    if not perturb:
+        raise NotImplementedError("the reference never calls the sampler with perturb=False")
+    if int(2 / sampling_args["render_step_size"]) != 128:
+        raise ValueError("the HIP sampler supports 128 samples per ray (run_JAX_RGB.sh:11)")
+    n, dev = origins.shape[0], origins.device
+    table = torch.zeros(n, 11, dtype=torch.float32, device=dev)
+    table[:, 0:3], table[:, 3:6] = origins, viewdirs
+    if near is not None:
+        table[:, 6:7] = near.reshape(n, 1)
+    u = torch.rand(n, 128, device=dev) if noise is None else noise.to(dev, torch.float32).contiguous()
+    cap = max(n * 127, 1)
+    ri = torch.empty(cap, dtype=torch.int64, device=dev)
+    ts_, te_ = torch.empty(cap, dtype=torch.float32, device=dev), torch.empty(cap, dtype=torch.float32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    field = radiance_field if radiance_field is not None else _any_field(dev)
+    nb = L.eonerf_render_workspace_bytes(field._ctx, n, _lib.F_ONLY_DEPTH)
+    ws = field._workspace("render", nb)
+    _lib.check(L.eonerf_sample_rays(field._ctx, _ptr(table), _ptr(_zsteps(dev)), _ptr(u), n, _ptr(ri), _ptr(ts_), _ptr(te_), None,
+                                    _ptr(cnt), _ptr(ws), ws.numel(), _stream()))
+    k = int(cnt.item())
+    return ri[:k], ts_[:k], te_[:k]
+
+
+_FIELD_FOR_SAMPLING = {}
+
+
+def _any_field(dev):
+    """The sampler needs a library context (workspace carving) but no weights: keep one tiny module per device."""
+    f = _FIELD_FOR_SAMPLING.get(dev)
+    if f is None:
+        from .radiance_fields.eonerf import EONerfMLP
+        f = EONerfMLP(1).to(dev)
+        f._ensure_packed()
+        _FIELD_FOR_SAMPLING[dev] = f
+    return f
+
+
 class _RenderChunk(torch.autograd.Function):
     """One chunk of render_image as a differentiable op; the parameters are inputs so autograd routes their grads."""
 

@@ -78,6 +78,22 @@ int eonerf_field_forward(eonerf_ctx* ctx, const float* flat_params, const float*
 int eonerf_query_density(eonerf_ctx* ctx, const float* flat_params, const float* xyz, int n, float* sigma,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* sat_rendering.satnerf_sampling (sat_rendering.py:56-84) + count_number_of_pts_per_nerfacc_ray (:10-16):
+ * rays[R,11] (origin, dir and near columns are used), u[R,128] jitter -> flattened, cube-filtered samples
+ * ray_indices[n] (int64), t_starts[n], t_ends[n] (capacity R*127 each), pts_per_ray[R] (fp32) and *n_dev = n. */
+int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, const float* u, int n_rays,
+                       int64_t* ray_indices, float* t_starts, float* t_ends, float* pts_per_ray, int* n_dev,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* EONerfMLP.rendering / render_depth on caller-provided flattened samples (radiance_fields/eonerf.py:172-248):
+ * ray_indices must be sorted (as satnerf_sampling returns them).  depth_only != 0 -> only depth[R] is written.
+ * Outputs per ray: albedo[R,3], depth[R], beta[R] (incl. +beta_min), transient_s[R], ambient[R,3] (before the x0.2 of
+ * render_image), entropy[R] (ones).  Inference entry point (no saved state for backward). */
+int eonerf_rendering(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
+                     const float* t_starts, const float* t_ends, const int64_t* ray_indices, int n, int n_rays, int depth_only,
+                     float* albedo, float* depth, float* beta, float* transient_s, float* ambient, float* entropy,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* One chunk of sat_rendering.render_image (sat_rendering.py:252-312) = satnerf_sampling + EONerfMLP.rendering +
  * compute_geometric_shadows + irradiance/radiometric model + output packing.
  *   rays[R,11] fp32 (o3 d3 near far sun3), img_idx[R] int64, zsteps[128] = linspace(0,1,128),
