@@ -19,7 +19,14 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_param_info", "eonerf_param_floats", "eonerf_set_weights", "eonerf_field_workspace_bytes",
            "eonerf_render_workspace_bytes", "eonerf_field_forward", "eonerf_query_density", "eonerf_render_forward",
            "eonerf_render_backward", "eonerf_adam_step", "eonerf_profile_enable", "eonerf_profile_read",
-           "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering"]
+           "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering", "eonerf_generate_rays"]
+
+
+class EonerfRpc(C.Structure):
+    _fields_ = [("col_num", C.c_double * 20), ("col_den", C.c_double * 20), ("row_num", C.c_double * 20), ("row_den", C.c_double * 20),
+                ("row_offset", C.c_double), ("col_offset", C.c_double), ("lat_offset", C.c_double), ("lon_offset", C.c_double),
+                ("alt_offset", C.c_double), ("row_scale", C.c_double), ("col_scale", C.c_double), ("lat_scale", C.c_double),
+                ("lon_scale", C.c_double), ("alt_scale", C.c_double)]
 
 
 class EonerfConfig(C.Structure):
@@ -71,6 +78,8 @@ def lib():
     L.eonerf_render_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp]
     L.eonerf_train_loss.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
+    L.eonerf_generate_rays.argtypes = [C.POINTER(EonerfRpc), vp, vp, C.c_long, i, C.c_double, C.c_double, i, i, C.c_double, C.c_double,
+                                       C.POINTER(fp), C.POINTER(fp), vp, vp, vp]
     L.eonerf_sample_rays.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_rendering.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_profile_enable.argtypes = [vp, i]

@@ -10,6 +10,8 @@
 #include "eonerf_kernels.h"
 #include "eonerf_pack.h"
 #include "eonerf_rays.h"
+#include "eonerf_raygen.h"
+#include <math.h>
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -345,6 +347,39 @@ int eonerf_query_density(eonerf_ctx* ctx, const float* flat, const float* xyz, i
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(sigma, b.sigma, n * sizeof(float), hipMemcpyDeviceToDevice, st));
     return EONERF_OK;
+}
+
+int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double* rows, long n, int width,
+                         double min_alt, double max_alt, int utm_zone, int south,
+                         double sun_elevation_deg, double sun_azimuth_deg, const float offset[3], const float scale[3],
+                         float* raw8, float* rays, void* stream) {
+    if (!rpc || n < 0 || (!raw8 && !rays) || (!cols != !rows) || (!cols && width < 1) || utm_zone < 1 || utm_zone > 60) return EONERF_E_ARG;
+    if (rays && (!offset || !scale)) return EONERF_E_ARG;
+    if (n == 0) return EONERF_OK;
+    static_assert(sizeof(eonerf_rpc) == sizeof(RpcModel), "RPC struct mismatch");
+    RayGenArgs a;
+    memcpy(&a.rpc, rpc, sizeof(RpcModel));
+    // WGS84, Krueger series coefficients (Karney 2011, eq. 35) -- what PROJ's etmerc evaluates
+    const double f = 1.0 / 298.257223563, nn = f / (2.0 - f);
+    const double n2 = nn * nn, n3 = n2 * nn, n4 = n3 * nn, n5 = n4 * nn, n6 = n5 * nn;
+    a.utm.lon0_deg = utm_zone * 6.0 - 183.0;
+    a.utm.e = sqrt(f * (2.0 - f));
+    a.utm.k0A = 0.9996 * 6378137.0 / (1.0 + nn) * (1.0 + n2 / 4 + n4 / 64 + n6 / 256);
+    a.utm.false_north = south ? 10000000.0 : 0.0;
+    a.utm.alpha[0] = nn / 2 - 2 * n2 / 3 + 5 * n3 / 16 + 41 * n4 / 180 - 127 * n5 / 288 + 7891 * n6 / 37800;
+    a.utm.alpha[1] = 13 * n2 / 48 - 3 * n3 / 5 + 557 * n4 / 1440 + 281 * n5 / 630 - 1983433 * n6 / 1935360;
+    a.utm.alpha[2] = 61 * n3 / 240 - 103 * n4 / 140 + 15061 * n5 / 26880 + 167603 * n6 / 181440;
+    a.utm.alpha[3] = 49561 * n4 / 161280 - 179 * n5 / 168 + 6601661 * n6 / 7257600;
+    a.utm.alpha[4] = 34729 * n5 / 80640 - 3418889 * n6 / 1995840;
+    a.utm.alpha[5] = 212378941 * n6 / 319334400;
+    a.cols = cols; a.rows = rows; a.n = n; a.width = width; a.min_alt = min_alt; a.max_alt = max_alt;
+    // get_sun_dirs(90 - elevation, azimuth) -> get_dir_vec_from_el_az (datasets/satellite.py:457,57-63)
+    const double d2r = 0.017453292519943295;
+    const double el = (90.0 - (90.0 - sun_elevation_deg)) * d2r, az = sun_azimuth_deg * d2r;
+    a.sun[0] = -1.0 * (sin(az) * cos(el)); a.sun[1] = -1.0 * (cos(az) * cos(el)); a.sun[2] = -1.0 * sin(el);
+    for (int k = 0; k < 3; ++k) { a.offset[k] = offset ? offset[k] : 0.f; a.scale[k] = scale ? scale[k] : 1.f; }
+    a.raw8 = raw8; a.rays = rays;
+    return (int)eo_launch_raygen(a, (hipStream_t)stream);
 }
 
 int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, const float* u, int n_rays,

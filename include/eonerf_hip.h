@@ -78,6 +78,25 @@ int eonerf_field_forward(eonerf_ctx* ctx, const float* flat_params, const float*
 int eonerf_query_density(eonerf_ctx* ctx, const float* flat_params, const float* xyz, int n, float* sigma,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* RPC camera model in rpcm's dict format (the "rpc" entry of the dataset JSON files, datasets/satellite.py:52-55). */
+typedef struct {
+    double col_num[20], col_den[20], row_num[20], row_den[20];
+    double row_offset, col_offset, lat_offset, lon_offset, alt_offset;
+    double row_scale, col_scale, lat_scale, lon_scale, alt_scale;
+} eonerf_rpc;
+
+/* datasets/satellite.py get_rays (:65-121, utm branch) + get_sun_dirs (:486-500) + normalize_rays (:124-139) for one image:
+ * pixels (cols[n], rows[n] fp64 device arrays, or NULL/NULL for the full width x height grid in row-major order) ->
+ * raw8[n,8] fp32 (origin UTM/alt, unit dir, near=0, far; the payload of the reference's ray cache files, may be NULL) and
+ * rays[n,11] fp32 normalised rays incl. the sun direction (may be NULL).  utm_zone/south select "+proj=utm +zone=.. [+south]"
+ * (sat_utils.py:99-116); sun_elevation_deg/sun_azimuth_deg are the JSON's values (the 90-elevation flip of :457 happens
+ * inside); offset/scale are scene.loc_utm's X/Y/Z values.  RPC localisation (rpcm) and the UTM projection (PROJ) are
+ * re-implemented from their published algorithms in fp64. */
+int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double* rows, long n, int width,
+                         double min_alt, double max_alt, int utm_zone, int south,
+                         double sun_elevation_deg, double sun_azimuth_deg, const float offset[3], const float scale[3],
+                         float* raw8, float* rays, void* stream);
+
 /* sat_rendering.satnerf_sampling (sat_rendering.py:56-84) + count_number_of_pts_per_nerfacc_ray (:10-16):
  * rays[R,11] (origin, dir and near columns are used), u[R,128] jitter -> flattened, cube-filtered samples
  * ray_indices[n] (int64), t_starts[n], t_ends[n] (capacity R*127 each), pts_per_ray[R] (fp32) and *n_dev = n. */

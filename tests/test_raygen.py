@@ -1,0 +1,86 @@
+"""H1 / N2: RPC ray generation.  CPU part: the oracle's own consistency (projection o localisation = identity, the UTM series
+against closed-form anchors).  GPU part: the HIP kernel against the oracle.
+
+Parity status: UNPINNED w.r.t. rpcm / pyproj (un-vendored; oracle/raygen_oracle.py docstring).  Tolerance on the GPU path:
+the reference casts UTM coordinates to fp32 (datasets/satellite.py:119-120; northing ~3.3e6 m -> 0.25 m quantum) BEFORE
+normalising, so a 1e-9-relative difference between two fp64 evaluations can flip that rounding: values either agree to 1e-6
+(normalised units) or differ by exactly one fp32 quantum of the raw value; the test allows < 0.1 % such flips."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raygen_oracle as rg
+
+
+def test_projection_of_localization_is_identity():
+    rpc = rg.synthetic_rpc(seed=1)
+    g = np.random.default_rng(0)
+    cols, rows = g.uniform(0, 2048, 500), g.uniform(0, 2048, 500)
+    for alt in (-20.0, 20.0, 90.0):
+        lon, lat = rg.localization(rpc, cols, rows, alt * np.ones(500))
+        c2, r2 = rg.projection(rpc, lon, lat, alt)
+        assert np.abs(c2 - cols).max() < 1e-5 and np.abs(r2 - rows).max() < 1e-5
+
+
+def test_utm_series_anchors():
+    # on the central meridian east = 500000 exactly; the equator maps to north = 0; scale k0 at the central meridian
+    e, n = rg.utm_forward(np.array([0.0, 30.0]), np.array([-81.0, -81.0]), 17)
+    assert abs(e[0] - 500000.0) < 1e-9 and abs(n[0]) < 1e-9 and abs(e[1] - 500000.0) < 1e-9
+    # meridian arc length from the equator to 30 deg N on WGS84 = 3 320 113.398 m (geodesy tables) -> x k0
+    assert abs(n[1] - 0.9996 * 3320113.398) < 2e-3
+    assert rg.utm_zone_number(30.33, -81.66) == 17 and rg.utm_zone_number(60.0, 5.0) == 32
+    # symmetric about the central meridian
+    e1, n1 = rg.utm_forward(np.array([30.0]), np.array([-80.0]), 17)
+    e2, n2 = rg.utm_forward(np.array([30.0]), np.array([-82.0]), 17)
+    assert abs((e1 - 500000) + (e2 - 500000)) < 1e-8 and abs(n1 - n2) < 1e-8
+
+
+def _scene(rpc, h, w, zone):
+    corners_c, corners_r = np.array(2 * [0, w - 1, w - 1, 0]), np.array(2 * [0, 0, h - 1, h - 1])
+    raw = rg.get_rays(corners_c, corners_r, rpc, -20.0, 90.0, zone).astype(np.float64)
+    pts = np.vstack([raw[:, :3], raw[:, :3] + raw[:, 7:8] * raw[:, 3:6]])
+    scale = (pts.max(0) - pts.min(0)) / 2
+    return (pts.min(0) + scale).astype(np.float32), scale.astype(np.float32)     # rpc_scaling_params, sat_utils.py:31-38
+
+
+def test_oracle_image_rays_shape_and_unit_vectors():
+    rpc = rg.synthetic_rpc(seed=2)
+    zone = rg.utm_zone_number(rpc["lat_offset"], rpc["lon_offset"])
+    off, sc = _scene(rpc, 64, 48, zone)
+    rays, raw = rg.image_rays(rpc, 64, 48, -20.0, 90.0, 55.0, 140.0, off, sc, zone)
+    assert rays.shape == (64 * 48, 11) and rays.dtype == np.float32 and raw.shape == (64 * 48, 8)
+    assert np.abs(np.linalg.norm(rays[:, 3:6], axis=1) - 1).max() < 1e-6
+    assert np.abs(np.linalg.norm(rays[:, 8:11], axis=1) - 1).max() < 1e-6
+    assert (np.abs(rays[:, :3]) <= 1.0 + 1e-3).all() and (rays[:, 6] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,downscale", [(3, 1.0), (4, 2.0)])
+def test_hip_ray_generation_matches_oracle(seed, downscale):
+    from eonerf_code_amd.datasets.satellite import generate_rays, get_rays, utm_zone_from_lonlat
+    rpc = rg.synthetic_rpc(seed=seed)
+    h, w = int(96 // downscale), int(80 // downscale)
+    rpc_s = rg.rescale_rpc(rpc, 1.0 / downscale)
+    zone, south = utm_zone_from_lonlat(rpc["lon_offset"], rpc["lat_offset"])
+    assert zone == rg.utm_zone_number(rpc["lat_offset"], rpc["lon_offset"])
+    off, sc = _scene(rpc_s, h, w, zone)
+    ref, ref_raw = rg.image_rays(rpc_s, h, w, -20.0, 90.0, 55.0, 140.0, off, sc, zone)
+    rays, raw = generate_rays(rpc, -20.0, 90.0, h=h, w=w, img_downscale=downscale, sun_elevation_deg=55.0, sun_azimuth_deg=140.0,
+                              scene_offset=off, scene_scale=sc, want_raw=True)
+    rays, raw = rays.cpu().numpy(), raw.cpu().numpy()
+    # raw rays: equal or one fp32 quantum apart
+    quantum = np.spacing(np.abs(ref_raw).astype(np.float32))
+    d_raw = np.abs(raw.astype(np.float64) - ref_raw.astype(np.float64))
+    assert (d_raw <= 1.01 * quantum).all()
+    assert (d_raw > 0).mean() < 1e-3
+    # normalised rays: 1e-6, except where a raw flip moved them by quantum/scale
+    d = np.abs(rays.astype(np.float64) - ref.astype(np.float64))
+    assert (d > 2e-6).mean() < 1e-3
+    assert d[:, :3].max() <= 1.01 * (quantum[:, :3].max(0) / sc).max() + 2e-6
+    assert d[:, 8:11].max() < 1e-6 and d[:, 3:6].max() < 1e-5
+    # explicit pixel lists (get_rays signature) agree with the grid
+    cols, rows = np.meshgrid(np.arange(w), np.arange(h))
+    raw2 = get_rays(cols.flatten(), rows.flatten(), rpc_s, -20.0, 90.0).cpu().numpy()
+    assert np.array_equal(raw2, raw)
