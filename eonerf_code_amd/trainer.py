@@ -118,3 +118,29 @@ class FusedTrainer:
             _lib.check(self.L.eonerf_profile_read(self.ctx, k, C.byref(ms), C.byref(cnt)))
             res[name] = (ms.value, cnt.value)
         return res
+
+
+class RayTable:
+    """GPU-resident ray table + on-device batch gather, replacing the reference's per-item DataLoader
+    (datasets/satellite.py:806-811, train_eonerf.py:70,99-109: ~1000 __getitem__ calls and one H2D copy per step).
+    Every rank holds the full table and walks its own slice of ONE shared per-epoch permutation (same seed everywhere) --
+    what DataLoader(shuffle=True) does on a single GPU, sharded like a DistributedSampler."""
+
+    def __init__(self, rays, img_idx, rgbs, device, seed=42, rank=0, world=1):
+        self.rays = rays.to(device, torch.float32).contiguous()
+        self.img = img_idx.reshape(-1).to(device, torch.int64).contiguous()
+        self.rgbs = rgbs.to(device, torch.float32).contiguous()
+        self.n, self.seed, self.rank, self.world = self.rays.shape[0], seed, rank, world
+        self._perm_epoch, self._perm = None, None
+
+    def steps_per_epoch(self, batch_per_rank):
+        return self.n // (batch_per_rank * self.world)
+
+    def batch(self, epoch, step, batch_per_rank):
+        if self._perm_epoch != epoch:
+            g = torch.Generator(device="cpu").manual_seed(self.seed + epoch)
+            self._perm = torch.randperm(self.n, generator=g).to(self.rays.device)
+            self._perm_epoch = epoch
+        lo = (step * self.world + self.rank) * batch_per_rank
+        idx = self._perm[lo:lo + batch_per_rank]
+        return self.rays.index_select(0, idx), self.img.index_select(0, idx), self.rgbs.index_select(0, idx)
