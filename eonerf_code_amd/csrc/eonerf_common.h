@@ -89,6 +89,7 @@ EO_DEV Units32<PF32> pack_units(PF32, const f32x16& v) {
 // chunk = G m-tiles; per m-tile KG x 1 KiB A units in fragment order, then G x 128 B of fp32 bias.
 // ------------------------------------------------------------------------------------------------
 struct ChunkDesc { uint32_t off, bytes; };
+template <class P> struct SlabWriter;
 
 template <class P, int SLOT_BYTES> struct WStream {
     const uint8_t* g;            // packed stream (global)
@@ -156,28 +157,47 @@ EO_DEV f32x16 bias_init(const uint8_t* bias32, int h) {
 EO_DEV f32x16 zero_acc() { f32x16 a; for (int i = 0; i < 16; ++i) a[i] = 0.f; return a; }
 
 // One chunk group of a layer:  for g in [0,G):  acc = bias + sum_kg A[g][kg] * B[kg];  epi(m0+g, acc)
-template <class P, int KG, int G, bool BIAS, class BArr, class Epi>
-EO_DEV void chunk_compute(const uint8_t* chunk, int lane, int h, const BArr& B, int m0, Epi&& epi) {
+// The A operands of the whole chunk form ONE stream of G*KG 1-KiB units; a rotating window of PF units is kept in
+// flight ahead of the MFMA that consumes them (ds_read -> wait -> mfma per unit would expose the full LDS latency
+// to every MFMA), across m-tile boundaries, and the next tile's bias is fetched while the current tile multiplies.
+template <class P, int KG, int G, bool BIAS, class BArr, class Epi, class Mid>
+EO_DEV void chunk_compute(const uint8_t* chunk, int lane, int h, const BArr& B, int m0, Epi&& epi, Mid&& mid) {
+    constexpr int MIDK = KG > 4 ? 3 : KG - 1;        // where the previous tile's deferred slab flush is issued
+    constexpr int NF = G * KG;
+    constexpr int PF = NF < 4 ? NF : 4;
+    const uint8_t* a = chunk + lane * 16;
+    typename P::U fr[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fr[d] = lds_unit<P>(a + d * 1024);
+    f32x16 acc = BIAS ? bias_init(chunk + NF * 1024, h) : zero_acc();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        f32x16 acc = BIAS ? bias_init(chunk + G * KG * 1024 + g * 128, h) : zero_acc();
-        const uint8_t* a = chunk + g * KG * 1024 + lane * 16;
+        f32x16 nxt = zero_acc();
+        if (BIAS && g + 1 < G) nxt = bias_init(chunk + NF * 1024 + (g + 1) * 128, h);
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) acc = P::mma(lds_unit<P>(a + kg * 1024), B(kg), acc);
+        for (int kg = 0; kg < KG; ++kg) {
+            const int f = g * KG + kg;
+            acc = P::mma(fr[f % PF], B(kg), acc);
+            if (f + PF < NF) fr[f % PF] = lds_unit<P>(a + (f + PF) * 1024);
+            if (kg == MIDK) mid();
+            __builtin_amdgcn_sched_barrier(0);      // keep the window: the scheduler would otherwise re-serialise read/wait/mfma
+        }
         epi(m0 + g, acc);
+        acc = nxt;
     }
 }
 
 // A whole layer: MT m-tiles in MT/G chunks.  NST = slab stores every m-tile's epilogue issues (lower bound, 0 = unknown).
-template <class P, int SLOT, int KG, int MT, int G, bool BIAS, int NST = 0, class BArr, class Epi>
-EO_DEV void run_layer(WStream<P, SLOT>& ws, int lane, int h, const BArr& B, Epi&& epi) {
+// `mid` is called once per m-tile a few MFMAs in: the deferred slab flush of the PREVIOUS tile (or a no-op).
+template <class P, int SLOT, int KG, int MT, int G, bool BIAS, int NST = 0, class Mid, class BArr, class Epi>
+EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BArr& B, Epi&& epi) {
     static_assert(MT % G == 0, "G must divide MT");
     static_assert(G * (KG * 1024 + 128) <= SLOT, "chunk does not fit the LDS slot");
 #pragma unroll
     for (int mg = 0; mg < MT / G; ++mg) {
         ws.prefetch_next();
-        chunk_compute<P, KG, G, BIAS>(ws.cur(), lane, h, B, mg * G, epi);
-        ws.template advance<G * NST>();
+        chunk_compute<P, KG, G, BIAS>(ws.cur(), lane, h, B, mg * G, epi, mid);
+        ws.template advance<(P::IS_BF16 ? (G - 1) : G) * NST>();
     }
 }
 
@@ -264,7 +284,9 @@ template <class P> struct SlabWriter;
 
 template <> struct SlabWriter<PF32> {
     static constexpr int LDS_BYTES = 0;
+    static constexpr int FLUSH_STORES = 0;          // tile() stores at once, flush_pending() is a no-op
     __amdgpu_buffer_rsrc_t rs; int voff;
+    EO_DEV void flush_pending() {}
     EO_DEV void init(void* slab, int rows, int wave_p0, int lane, uint8_t*) {
         const int c = lane & 31, h = lane >> 5;
         uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)(wave_p0 / 16) * rows * SEG_B;
@@ -284,36 +306,53 @@ template <> struct SlabWriter<PF32> {
 };
 
 template <> struct SlabWriter<PBf16> {
-    static constexpr int LDS_BYTES = 8 * TR_WAVE_B;
+    // tile() only STAGES the tile in the scratch (4 ds_write_b64); the transposed read-back + the two dwordx4 stores
+    // happen in flush_pending(), which the chain calls a few MFMAs into the NEXT tile so that the LDS round trip
+    // (write -> transposed read -> store) is covered by matrix work instead of stalling between tiles.  Two scratch
+    // buffers per wave alternate.
+    static constexpr int LDS_BYTES = 8 * 2 * TR_WAVE_B;
+    static constexpr int FLUSH_STORES = 2;
     __amdgpu_buffer_rsrc_t rs; int voff1, svoff;
     uint8_t* wptr; const uint8_t* rptr;
+    int pend_row = -1, buf = 0;
     EO_DEV void init(void* slab, int rows, int wave_p0, int lane, uint8_t* scratch_wave) {
         const int c = lane & 31, h = lane >> 5;
         uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)(wave_p0 / 32) * rows * SEG_B;
         rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * SEG_B, 0x00020000);
         voff1 = 4 * h * SEG_B + c * 2;
         // scratch write: row = sample c, columns 8q + 4h .. +3 (natural feature order)
+        pend_row = -1; buf = 0;
         wptr = scratch_wave + c * TR_STRIDE + h * 8;
-        // transposed read: 16-lane group g, lane i = 4*qq + p supplies (row 8*octet + 4t + qq, cols 16*(g&1) + 4p..+3),
-        // octet = (g>>1) + 2*pair, and receives feature column 16*(g&1) + i for those four samples
+        // transposed read: 16-lane group g = sample octet g; lane i = 4*qq + pp supplies (row 8g + 4t + qq, cols 16*pair +
+        // 4pp..+3) and receives feature column 16*pair + i for those four samples.  Store `pair` therefore writes 16
+        // features x 4 octets = 16 WHOLE 64-B segments (8 full 128-B lines) per instruction.
         const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
-        rptr = scratch_wave + (8 * (g >> 1) + qq) * TR_STRIDE + (g & 1) * 32 + pp * 8;
-        svoff = (16 * (g & 1) + i) * SEG_B + (g >> 1) * 16;
+        rptr = scratch_wave + (8 * g + qq) * TR_STRIDE + pp * 8;
+        svoff = i * SEG_B + g * 16;
     }
-    EO_DEV void tile(int row0, const Units32<PBf16>& u) const {
-        const u32x4 w0 = __builtin_bit_cast(u32x4, u.u[0]), w1 = __builtin_bit_cast(u32x4, u.u[1]);
-        *reinterpret_cast<u32x2*>(wptr + 0) = u32x2{w0[0], w0[1]};
-        *reinterpret_cast<u32x2*>(wptr + 16) = u32x2{w0[2], w0[3]};
-        *reinterpret_cast<u32x2*>(wptr + 32) = u32x2{w1[0], w1[1]};
-        *reinterpret_cast<u32x2*>(wptr + 48) = u32x2{w1[2], w1[3]};
+    EO_DEV void flush_pending() {
+        if (pend_row < 0) return;
+        const uint8_t* rb = rptr + (buf ^ 1) * TR_WAVE_B;          // the buffer staged last
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair) {
-            const uint8_t* rp = rptr + pair * 16 * TR_STRIDE;
+            const uint8_t* rp = rb + pair * 32;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rp));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rp + 4 * TR_STRIDE));
             const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], b[0], b[1]}, rs, svoff, row0 * SEG_B + pair * 32, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], b[0], b[1]}, rs, svoff, (pend_row + 16 * pair) * SEG_B, 0);
         }
+        pend_row = -1;
+    }
+    EO_DEV void tile(int row0, const Units32<PBf16>& u) {
+        flush_pending();                                             // normally already done by the chain (no-op)
+        const u32x4 w0 = __builtin_bit_cast(u32x4, u.u[0]), w1 = __builtin_bit_cast(u32x4, u.u[1]);
+        uint8_t* wp = wptr + buf * TR_WAVE_B;
+        *reinterpret_cast<u32x2*>(wp + 0) = u32x2{w0[0], w0[1]};
+        *reinterpret_cast<u32x2*>(wp + 16) = u32x2{w0[2], w0[3]};
+        *reinterpret_cast<u32x2*>(wp + 32) = u32x2{w1[0], w1[1]};
+        *reinterpret_cast<u32x2*>(wp + 48) = u32x2{w1[2], w1[3]};
+        pend_row = row0;
+        buf ^= 1;
     }
     EO_DEV void elem(int row, float v) const {
         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), rs, voff1, row * SEG_B, 0);

@@ -43,8 +43,9 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         const bool live = p < n_pts;
         constexpr int GROWS = FULL ? GRD_ROWS_FULL : GRD_ROWS_DENSITY;
         SlabWriter<P> sw;                                                   // this wave's sample tile(s) of the gradient slab
-        sw.init(a.grd, GROWS, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * TR_WAVE_B);
+        sw.init(a.grd, GROWS, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
         uint32_t mb[4];
+        auto mid = [&]() { sw.flush_pending(); };
 
         auto load_mask = [&](int slot, int nwords) {
             const uint32_t* mp = a.masks + ((size_t)slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4;
@@ -90,26 +91,26 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 // ---- transient head backwards: {ts,tb}_pre -> T4 -> T3 -> T2 -> T1 ----
                 const U u_tr = small_unit<P>(dtr, h);
                 load_mask(12, 2);
-                run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, lane, h, [&](int) { return u_tr; },
+                run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_tr; },
                     [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v); });
                 load_mask(11, 2);
-                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TA[kg]; },
+                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
                     [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v); });
                 load_mask(10, 2);
-                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TB[kg]; },
+                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
                     [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v); });
                 load_mask(9, 2);
-                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, lane, h, [&](int kg) { return TA[kg]; },
+                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
                     [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1, true, mt, v); });        // TB = dY_T1
             }
             // ---- albedo head backwards: albedo_pre -> A1 ----
             const U u_al = small_unit<P>(dalb, h);
             load_mask(8, 2);
-            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, lane, h, [&](int) { return u_al; },
+            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_al; },
                 [&](int mt, const f32x16& v) { grad_epi(DA1, GRD_ROW_A1, true, mt, v); });
             if constexpr (TRANS) {
                 // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
-                run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, lane, h,
+                run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, mid, lane, h,
                     [&](int kg) { return kg < QKG ? DA1[kg < QKG ? kg : 0] : TB[kg >= QKG ? kg - QKG : 0]; },
                     [&](int mt, const f32x16& v) {
                         if (mt < 8) { grad_epi(N, GRD_ROW_BOTT, false, mt, v); return; }
@@ -117,19 +118,19 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                     });
             } else {
                 // ---- dY_A1 -> d bottleneck ----
-                run_layer<P, SLOT, QKG, 8, FwdG<P, QKG, 8>::G, false, NST>(ws, lane, h, [&](int kg) { return DA1[kg]; },
+                run_layer<P, SLOT, QKG, 8, FwdG<P, QKG, 8>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return DA1[kg]; },
                     [&](int mt, const f32x16& v) { grad_epi(N, GRD_ROW_BOTT, false, mt, v); });
             }
             // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
-            run_layer<P, SLOT, HKG + 1, 8, FwdG<P, HKG + 1, 8>::G, false, NST>(ws, lane, h,
+            run_layer<P, SLOT, HKG + 1, 8, FwdG<P, HKG + 1, 8>::G, false, NST>(ws, mid, lane, h,
                 [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
                 [&](int mt, const f32x16& v) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v); });
         } else {
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
-            run_layer<P, SLOT, 1, 8, FwdG<P, 1, 8>::G, false, NST>(ws, lane, h, [&](int) { return u_sg; },
+            run_layer<P, SLOT, 1, 8, FwdG<P, 1, 8>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_sg; },
                 [&](int mt, const f32x16& v) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v); });
         }
 
@@ -137,14 +138,14 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         f32x16 denc[2];
         auto trunk_step = [&](auto& src, auto& dst, int l) {      // consumes dY_l, produces dY_{l-1}
             load_mask(l - 1, 4);
-            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, false, NST>(ws, lane, h, [&](int kg) { return src[kg]; },
+            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
                 [&](int mt, const f32x16& v) { grad_epi(dst, GRD_ROW_Y0 + (l - 1) * 256, true, mt, v); });
         };
         trunk_step(D, N, 7);
         trunk_step(N, D, 6);
         // layer 5 consumed [h, enc]: rows 0..255 go on down the trunk, rows 256..319 are d enc (skip path)
         load_mask(4, 4);
-        run_layer<P, SLOT, HKG, IG ? 10 : 8, FwdG<P, HKG, IG ? 10 : 8>::G, false>(ws, lane, h, [&](int kg) { return D[kg]; },
+        run_layer<P, SLOT, HKG, IG ? 10 : 8, FwdG<P, HKG, IG ? 10 : 8>::G, false>(ws, mid, lane, h, [&](int kg) { return D[kg]; },
             [&](int mt, const f32x16& v) {
                 if (mt < 8) { grad_epi(N, GRD_ROW_Y0 + 4 * 256, true, mt, v); return; }
                 if constexpr (IG) denc[mt == 8 ? 0 : 1] = v;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         trunk_step(D, N, 1);                                        // N = dY_0
 
         if constexpr (IG) {
-            run_layer<P, SLOT, HKG, 2, FwdG<P, HKG, 2>::G, false>(ws, lane, h, [&](int kg) { return N[kg]; },
+            run_layer<P, SLOT, HKG, 2, FwdG<P, HKG, 2>::G, false>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
                 [&](int mt, const f32x16& v) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) denc[mt == 0 ? 0 : 1][r] += v[r];
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 a.g_pos[p] = gp[0]; a.g_pos[(size_t)a.p_pad + p] = gp[1]; a.g_pos[2 * (size_t)a.p_pad + p] = gp[2];
             }
         }
+        sw.flush_pending();
     }
 }
 

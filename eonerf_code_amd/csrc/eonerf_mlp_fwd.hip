@@ -69,13 +69,14 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         constexpr int AROWS = FULL ? ACT_ROWS_FULL : ACT_ROWS_DENSITY;
         SlabWriter<P> sw;                                                   // this wave's sample tile(s) of the activation slab
         if constexpr (TRAIN) {
-            sw.init(a.act, AROWS, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * TR_WAVE_B);
+            sw.init(a.act, AROWS, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
 #pragma unroll
             for (int kg = 0; kg < EKG; ++kg)      // encoding slots, rows [0,64)
 #pragma unroll
                 for (int e = 0; e < P::NE; ++e) sw.elem(ACT_ROW_ENC + P::feat(kg, 0, e), (float)E.u[kg][e]);
         }
 
+        auto mid = [&]() { if constexpr (TRAIN) sw.flush_pending(); };
         U H[HKG], N[HKG];
         uint32_t mbits[4];
 
@@ -100,13 +101,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             }
         };
         auto plain_layer = [&](auto& src, auto& dst, int l) {
-            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, true, NST>(ws, lane, h, [&](int kg) { return src[kg]; },
+            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi(dst, ACT_ROW_X1 + 256 * l, mt, v); });
             save_mask(l, 4);
         };
 
         // layer 0: enc(64) -> 256
-        run_layer<P, SLOT, EKG, 8, FwdG<P, EKG, 8>::G, true, NST>(ws, lane, h, [&](int kg) { return E.u[kg]; },
+        run_layer<P, SLOT, EKG, 8, FwdG<P, EKG, 8>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return E.u[kg]; },
             [&](int mt, const f32x16& v) { relu_epi(H, ACT_ROW_X1, mt, v); });
         save_mask(0, 4);
         plain_layer(H, N, 1);
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         plain_layer(H, N, 3);
         plain_layer(N, H, 4);
         // layer 5 consumes [h, enc] (skip-concat after layer 4, mlp.py:92-97)
-        run_layer<P, SLOT, HKG + EKG, 8, FwdG<P, HKG + EKG, 8>::G, true, NST>(ws, lane, h,
+        run_layer<P, SLOT, HKG + EKG, 8, FwdG<P, HKG + EKG, 8>::G, true, NST>(ws, mid, lane, h,
             [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : E.u[kg >= HKG ? kg - HKG : 0]; },
             [&](int mt, const f32x16& v) { relu_epi(N, ACT_ROW_X1 + 256 * 5, mt, v); });
         save_mask(5, 4);
@@ -124,12 +125,12 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         // ---------------- sigma (+ bottleneck) ----------------
         float sigma_raw = 0.f;
         if constexpr (!FULL) {
-            run_layer<P, SLOT, HKG, 1, 1, true>(ws, lane, h, [&](int kg) { return N[kg]; },
+            run_layer<P, SLOT, HKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
                 [&](int, const f32x16& v) { sigma_raw = v[0]; });
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
         } else {
             // m-tile 0 = sigma row, m-tiles 1..8 = bottleneck (identity activation) -> H
-            run_layer<P, SLOT, HKG, 9, FwdG<P, HKG, 9>::G, true>(ws, lane, h, [&](int kg) { return N[kg]; },
+            run_layer<P, SLOT, HKG, 9, FwdG<P, HKG, 9>::G, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
                 [&](int mt, const f32x16& v) {
                     if (mt == 0) { sigma_raw = v[0]; return; }
                     Units32<P> u = pack_units(P(), v);
@@ -141,10 +142,10 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 
             // ---------------- albedo head: 256 -> 128 (ReLU) -> 3 (Sigmoid) ----------------
             U A1[QKG];
-            run_layer<P, SLOT, HKG, 4, FwdG<P, HKG, 4>::G, true, NST>(ws, lane, h, [&](int kg) { return H[kg]; },
+            run_layer<P, SLOT, HKG, 4, FwdG<P, HKG, 4>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return H[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi(A1, ACT_ROW_A1, mt, v); });
             save_mask(8, 2);
-            run_layer<P, SLOT, QKG, 1, 1, true>(ws, lane, h, [&](int kg) { return A1[kg]; },
+            run_layer<P, SLOT, QKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return A1[kg]; },
                 [&](int, const f32x16& v) {
                     if (h == 0 && live) {
                         a.albedo[p] = sigmoid_f(v[0]);
@@ -166,24 +167,25 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                 for (int e = 0; e < 4; ++e) sw.elem(ACT_ROW_EMB + e, (float)EMB[e]);
             }
             U T1[QKG], T2[QKG];
-            run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true, NST_T>(ws, lane, h,
+            run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true, NST_T>(ws, mid, lane, h,
                 [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : EMB; },
                 [&](int mt, const f32x16& v) { relu_epi_t(T1, ACT_ROW_T1, mt, v); });
             if constexpr (TSAVE) save_mask(9, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, lane, h, [&](int kg) { return T1[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi_t(T2, ACT_ROW_T1 + 128, mt, v); });
             if constexpr (TSAVE) save_mask(10, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, lane, h, [&](int kg) { return T2[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T2[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi_t(T1, ACT_ROW_T1 + 256, mt, v); });
             if constexpr (TSAVE) save_mask(11, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, lane, h, [&](int kg) { return T1[kg]; },
+            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },
                 [&](int mt, const f32x16& v) { relu_epi_t(T2, ACT_ROW_T1 + 384, mt, v); });
             if constexpr (TSAVE) save_mask(12, 2);
-            run_layer<P, SLOT, QKG, 1, 1, true>(ws, lane, h, [&](int kg) { return T2[kg]; },
+            run_layer<P, SLOT, QKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return T2[kg]; },
                 [&](int, const f32x16& v) {
                     if (h == 0 && live) { a.ts[p] = sigmoid_f(v[0]); a.tb[p] = softplus_f(v[1]); }
                 });
         }
+        if constexpr (TRAIN) sw.flush_pending();
     }
 }
 

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
             const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.b)) + (size_t)step * job.b_stride, 0, job.n_rows * SEG_B, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(base + 16 * j * ROW_B), 16, voff_a[j], 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(base + OPND_B + 16 * j * ROW_B), 16, voff_b[j], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(base + 16 * j * ROW_B), 16, voff_a[j], 0, 0, 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(base + OPND_B + 16 * j * ROW_B), 16, voff_b[j], 0, 0, 2);
         }
     };
 
