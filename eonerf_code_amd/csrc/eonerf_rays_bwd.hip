@@ -157,6 +157,7 @@ __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
         const float* r = a.rays + (size_t)ray * 11;
         const float* rec = a.ray_rec + (size_t)ray * RAY_REC;
         const float* g = a.g_ray + (size_t)ray * RAY_REC;
+        if (g[RR_AMB] == 0.f && g[RR_AMB + 1] == 0.f && g[RR_AMB + 2] == 0.f) { buf ^= 1; continue; }   // outside the graph (s == 1)
         if (j < 27) {          // one encoding element per thread (same arithmetic as sun_encoding)
             float v;
             if (j < 3) v = r[8 + j];
