@@ -45,7 +45,7 @@ struct PassBuffers {       // one MLP pass (camera or sun) over up to p_cap samp
 
 struct RenderWs {
     int *cnt_first, *cnt_retry, *flags;
-    float* ray_rec; float* g_ray;
+    float* ray_rec; float* g_ray; float* amb_save;
     PassBuffers cam, sun;
     size_t bytes;
 };
@@ -157,6 +157,7 @@ RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) 
     w.cnt_first = c.take<int>(n_rays); w.cnt_retry = c.take<int>(n_rays); w.flags = c.take<int>(4);
     w.ray_rec = c.take<float>((size_t)n_rays * RAY_REC);
     w.g_ray = train ? c.take<float>((size_t)n_rays * RAY_REC) : nullptr;
+    w.amb_save = train ? c.take<float>((size_t)n_rays * 160) : nullptr;
     carve_pass(c, w.cam, n_rays, p_cap, !od, train, false, ab);
     if (shadows && !od) carve_pass(c, w.sun, n_rays, p_cap, false, train, true, ab); else memset(&w.sun, 0, sizeof(w.sun));
     w.bytes = c.off + 256;
@@ -469,7 +470,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     ca.rays = rays; ca.offsets = w.cam.offsets; ca.counts = w.cam.counts;
     ca.sigma = w.cam.sigma; ca.delta = w.cam.delta; ca.tmid = w.cam.tmid; ca.albedo = w.cam.albedo; ca.ts = w.cam.ts; ca.tb = w.cam.tb;
     ca.p_pad = p_cap; ca.n_rays = n_rays; ca.shadow_only = 0; ca.depth_only = od ? 1 : 0;
-    ca.amb = ambient_w(ctx, flat); ca.ray_out = w.ray_rec;
+    ca.amb = ambient_w(ctx, flat); ca.ray_out = w.ray_rec; ca.amb_save = w.amb_save;
     HIP_TRY(eo_launch_composite_fwd(ca, st));
 
     // ---- sun pass: shadow rays from the rendered surface toward the sun -----------------------------------
@@ -613,11 +614,11 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
     if (transient) {
         EmbGradArgs eg;
-        eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays;
+        eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays; eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0;
         HIP_TRY(eo_launch_emb_grad(eg, st));
     }
     AmbientBwdArgs ag;
-    ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.n_rays = n_rays;
+    ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
     ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
     HIP_TRY(eo_launch_ambient_bwd(ag, st));
     return EONERF_OK;

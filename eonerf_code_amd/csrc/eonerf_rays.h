@@ -36,6 +36,7 @@ struct CompositeArgs {
     int shadow_only, depth_only;
     AmbientW amb;
     float* ray_out;           // [R][RAY_REC]
+    float* amb_save;          // training: [R][160] = sun encoding (27, padded to 32) + hidden activations (128) of the ambient head
 };
 
 struct ShadeArgs {
@@ -70,7 +71,7 @@ struct CompositeBwdArgs {
 
 struct AmbientBwdArgs {
     AmbientW w;
-    const float *rays, *ray_rec, *g_ray;
+    const float *rays, *ray_rec, *g_ray, *amb_save;
     int n_rays;
     float *d_w1, *d_b1, *d_w2, *d_b2;
 };
@@ -81,6 +82,7 @@ struct EmbGradArgs {
     const float* g_emb;      // [p_pad][4]
     float* d_emb;            // [n_img][4] inside the flat gradient buffer
     int n_rays;
+    int lds_images;          // > 0: accumulate per block in LDS first
 };
 
 struct PackedArgs {        // flattened samples handed in by the caller (EONerfMLP.rendering / render_depth)

@@ -188,6 +188,15 @@ __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
         const float* r = a.rays + (size_t)ray * 11;
         const AmbientRay ar = ambient_forward(a.amb, r[8], r[9], r[10], lane);
         amb[0] = ar.out[0]; amb[1] = ar.out[1]; amb[2] = ar.out[2];
+        if (a.amb_save) {
+            float* sv = a.amb_save + (size_t)ray * 160;
+            float ev = 0.f;
+#pragma unroll
+            for (int i = 0; i < 27; ++i) ev = lane == i ? ar.enc[i] : ev;
+            if (lane < 27) sv[lane] = ev;
+            sv[32 + lane] = ar.hid[0];
+            sv[96 + lane] = ar.hid[1];
+        }
     }
     if (lane == 0) {
         float* o = a.ray_out + (size_t)ray * RAY_REC;

@@ -142,40 +142,17 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
 
 // ---- ambient head backward (radiance_fields/eonerf.py:132-139): one thread per hidden unit, rays strided over WGs
 __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
-    __shared__ float s_enc[2][32];
     const int j = threadIdx.x;
     float dw1[27], dw2[3] = {0.f, 0.f, 0.f}, db1 = 0.f, db2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 27; ++i) dw1[i] = 0.f;
-    float w1[27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) w1[i] = a.w.w1[j * 27 + i];
-    const float b1 = a.w.b1[j];
     const float w2[3] = {a.w.w2[j], a.w.w2[128 + j], a.w.w2[256 + j]};
-    int buf = 0;
-    for (int ray = blockIdx.x; ray < a.n_rays; ray += gridDim.x, buf ^= 1) {
-        const float* r = a.rays + (size_t)ray * 11;
+    for (int ray = blockIdx.x; ray < a.n_rays; ray += gridDim.x) {
         const float* rec = a.ray_rec + (size_t)ray * RAY_REC;
         const float* g = a.g_ray + (size_t)ray * RAY_REC;
-        if (g[RR_AMB] == 0.f && g[RR_AMB + 1] == 0.f && g[RR_AMB + 2] == 0.f) { buf ^= 1; continue; }   // outside the graph (s == 1)
-        if (j < 27) {          // one encoding element per thread (same arithmetic as sun_encoding)
-            float v;
-            if (j < 3) v = r[8 + j];
-            else {
-                const int q = (j - 3) % 12, k = q / 3, d = q % 3;
-                const float xb = r[8 + d] * (float)(1 << k);
-                v = j < 15 ? sinf(xb) : sinf(xb + EO_PI_2_F);
-            }
-            s_enc[buf][j] = v;
-        }
-        __syncthreads();       // double-buffered: the next iteration writes the other buffer
-        float enc[27];
-#pragma unroll
-        for (int i = 0; i < 27; ++i) enc[i] = s_enc[buf][i];
-        float hid = b1;
-#pragma unroll
-        for (int i = 0; i < 27; ++i) hid = fmaf(w1[i], enc[i], hid);
-        hid = fmaxf(hid, 0.f);
+        if (g[RR_AMB] == 0.f && g[RR_AMB + 1] == 0.f && g[RR_AMB + 2] == 0.f) continue;      // outside the graph (s == 1)
+        const float* sv = a.amb_save + (size_t)ray * 160;       // sun encoding and hidden activations saved by the forward
+        const float hid = sv[32 + j];
         float gpre[3], ghid = 0.f;
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
@@ -188,7 +165,7 @@ __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
         if (hid <= 0.f) ghid = 0.f;
         db1 += ghid;
 #pragma unroll
-        for (int i = 0; i < 27; ++i) dw1[i] += ghid * enc[i];
+        for (int i = 0; i < 27; ++i) dw1[i] += ghid * sv[i];
     }
     // zero contributions are skipped: with the shadow pass off the ambient head is outside the graph (1 - s == 0)
 #pragma unroll
@@ -204,23 +181,37 @@ __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
 
 // ---- transient embedding gradient: per-sample d emb (from the backward chain) summed per ray, added per image ---
 __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
-    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
-    if (ray >= a.n_rays) return;
-    const int off = a.offsets[ray], n = a.counts[ray];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    extern __shared__ float s_de[];                     // [n_img][4] block-local accumulation (0 floats if unused)
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK * 8 + (threadIdx.x >> 6);
+    const bool lds_acc = a.lds_images > 0;
+    if (lds_acc) {
+        for (int i = threadIdx.x; i < a.lds_images * 4; i += 256) s_de[i] = 0.f;
+        __syncthreads();
+    }
+    for (int k8 = 0; k8 < 8; ++k8) {                    // 32 rays per block
+        const int rr = ray + 4 * k8;
+        if (rr >= a.n_rays) break;
+        const int off = a.offsets[rr], n = a.counts[rr];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = lane + 64 * k;
-        if (i < n) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(a.g_emb + 4 * (size_t)(off + i));
-            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        for (int k = 0; k < 2; ++k) {
+            const int i = lane + 64 * k;
+            if (i < n) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.g_emb + 4 * (size_t)(off + i));
+                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = wave_sum(acc[e]);
+        if (lane < 4) {
+            const float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+            if (lds_acc) atomicAdd(&s_de[a.img_idx[rr] * 4 + lane], v);
+            else atomicAdd(a.d_emb + a.img_idx[rr] * 4 + lane, v);
         }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = wave_sum(acc[e]);
-    if (lane < 4) {
-        const float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
-        atomicAdd(a.d_emb + a.img_idx[ray] * 4 + lane, v);
+    if (lds_acc) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.lds_images * 4; i += 256) { const float v = s_de[i]; if (v != 0.f) atomicAdd(a.d_emb + i, v); }
     }
 }
 
@@ -287,7 +278,7 @@ hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_emb_grad, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_emb_grad, dim3((a.n_rays + 31) / 32), dim3(256), (size_t)a.lds_images * 4 * sizeof(float), st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st) {

@@ -48,9 +48,25 @@ EO_DEV void sun_encoding(float sx, float sy, float sz, float* enc) {   // mlp.py
         }
 }
 
+// one encoding element per lane (lanes 0..26), broadcast with shuffles: same arithmetic as sun_encoding
+EO_DEV void sun_encoding_wave(float sx, float sy, float sz, int lane, float* enc) {
+    float v = 0.f;
+    if (lane < 27) {
+        if (lane < 3) v = lane == 0 ? sx : (lane == 1 ? sy : sz);
+        else {
+            const int q = (lane - 3) % 12, k = q / 3, d = q % 3;
+            const float c = d == 0 ? sx : (d == 1 ? sy : sz);
+            const float xb = c * (float)(1 << k);
+            v = lane < 15 ? sinf(xb) : sinf(xb + EO_PI_2_F);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) enc[i] = __shfl(v, i, 64);
+}
+
 EO_DEV AmbientRay ambient_forward(const AmbientW& w, float sx, float sy, float sz, int lane) {
     AmbientRay r;
-    sun_encoding(sx, sy, sz, r.enc);
+    sun_encoding_wave(sx, sy, sz, lane, r.enc);
     float part[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {

@@ -181,7 +181,9 @@ def test_training_reduces_loss_bf16():
 
 
 def test_fused_trainer_matches_autograd_path_and_oracle():
-    """FusedTrainer.step (direct C calls + fused loss kernel) == autograd path: same loss, same post-Adam parameters."""
+    # FusedTrainer.step (direct C calls, fused loss kernel, EONERF_F_RGB_LOSS graph pruning for epoch < 2) computes the same
+    # loss and the same gradients as the autograd path.  Gradients are compared, not post-Adam weights: Adam's first step is
+    # lr*g/(|g|+eps), which turns atomic-order noise on |g| ~ eps into O(lr) differences.
     from eonerf_code_amd.trainer import FusedTrainer
     n_img, R = 4, 128
     sd = orc.random_state_dict(n_img, seed=91, bias_scale=0.05)
@@ -189,11 +191,13 @@ def test_fused_trainer_matches_autograd_path_and_oracle():
     rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R, n_img, seed=92)
     for epoch in (0, 3):
         f1, f2 = make_field(sd, n_img, "fp32"), make_field(sd, n_img, "fp32")
-        opt = torch.optim.Adam(f1.parameters(), lr=5e-4)
         loss1, _ = hip_step(f1, rays, ts, rgbs, (u_cam, None, u_sun), epoch)
-        opt.step()
         tr = FusedTrainer(f2, lr=5e-4, max_rays=R)
+        before = f2.flat_params().clone()
         loss2 = tr.step(rays.cuda(), ts.reshape(-1).cuda(), rgbs.cuda(), epoch, noise=(u_cam.cuda(), None, u_sun.cuda()))
         assert abs(loss1.item() - float(loss2)) < 1e-5
-        for (n1, p1), (n2, p2) in zip(f1.named_parameters(), f2.named_parameters()):
-            assert (p1 - p2).abs().max().item() < 2e-4 * 5e-4 + 1e-6, (epoch, n1)      # Adam moves each weight by <= lr
+        for (name, p1), g2 in zip(f1.named_parameters(), f2.grad_views(tr.d_flat)):
+            g1 = p1.grad if p1.grad is not None else torch.zeros_like(p1)
+            assert (g1 - g2).norm().item() <= 1e-4 * g1.norm().item() + 1e-9, (epoch, name)
+        moved = (f2.flat_params() - before).abs().max().item()
+        assert 0 < moved <= 5e-4 * 1.001                              # one Adam step moves a weight by at most lr
