@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libeonerf_hip.so")
+LIB_PATH = os.environ.get("EONERF_LIB") or os.path.join(CSRC, "libeonerf_hip.so")   # EONERF_LIB: A/B builds of the same ABI
 
 EONERF_FP32, EONERF_BF16 = 0, 1
 F_SHADOWS, F_EVAL, F_TRAIN, F_ONLY_DEPTH, F_RGB_LOSS = 1, 2, 4, 8, 16

@@ -22,6 +22,13 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define EO_DEV __device__ __forceinline__
 
+// Diagnostic builds only (scripts/ablate.sh): EO_ABL bit 0 drops the per-chunk s_barrier, bit 1 the A-operand LDS re-reads,
+// bit 2 the ReLU/mask work of the epilogues, bit 3 the weight prefetch.  Results are WRONG with any bit set; the shipped
+// library is built with EO_ABL == 0.
+#ifndef EO_ABL
+#define EO_ABL 0
+#endif
+
 // row of the 32x32 accumulator tile held in register r by a lane of half h (cdna guide, C/D map)
 EO_DEV constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -101,7 +108,10 @@ template <class P, int SLOT_BYTES> struct WStream {
     int tid;
 
     EO_DEV void issue(int qi, uint32_t slot) {
-        const ChunkDesc d = tab[qi];
+        // constant address space: the table is read-only for the whole launch, so this is an s_load (a generic-pointer load
+        // becomes a VECTOR load + s_waitcnt vmcnt(0), which drains every outstanding slab store once per chunk)
+        const auto* t4 = reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(tab));
+        const ChunkDesc d = {t4[2 * qi], t4[2 * qi + 1]};
         const uint8_t* src = g + d.off;
         uint8_t* dst = lds + slot * SLOT_BYTES;
         const int wave_off = (tid & ~63) * 16;
@@ -122,7 +132,7 @@ template <class P, int SLOT_BYTES> struct WStream {
     // barrier pins the LDS-DMA loads BEFORE every store of the chunk's epilogues (advance<> counts on that order).
     EO_DEV void prefetch_next() {
         int nq = q + 1; if (nq == n_chunks) nq = 0;
-        issue(nq, par ^ 1);
+        if (!(EO_ABL & 8)) issue(nq, par ^ 1);
         __builtin_amdgcn_sched_barrier(0);
     }
     // call after computing on the resident chunk.  YOUNGER = a lower bound on the vector-memory operations (the
@@ -132,7 +142,8 @@ template <class P, int SLOT_BYTES> struct WStream {
     // would add its own vmcnt(0).
     template <int YOUNGER> EO_DEV void advance() {
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(YOUNGER > 63 ? 63 : YOUNGER) : "memory");
+        if (EO_ABL & 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER > 63 ? 63 : YOUNGER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(YOUNGER > 63 ? 63 : YOUNGER) : "memory");
         q = q + 1; if (q == n_chunks) q = 0;
         par ^= 1;
     }
@@ -178,7 +189,7 @@ EO_DEV void chunk_compute(const uint8_t* chunk, int lane, int h, const BArr& B, 
         for (int kg = 0; kg < KG; ++kg) {
             const int f = g * KG + kg;
             acc = P::mma(fr[f % PF], B(kg), acc);
-            if (f + PF < NF) fr[f % PF] = lds_unit<P>(a + (f + PF) * 1024);
+            if (!(EO_ABL & 2) && f + PF < NF) fr[f % PF] = lds_unit<P>(a + (f + PF) * 1024);
             if (kg == MIDK) mid();
             __builtin_amdgcn_sched_barrier(0);      // keep the window: the scheduler would otherwise re-serialise read/wait/mfma
         }
@@ -220,6 +231,7 @@ EO_DEV Units32<PF32> relu_pack_mask(PF32, const f32x16& acc, int mt, uint32_t& m
 }
 EO_DEV Units32<PBf16> relu_pack_mask(PBf16, const f32x16& acc, int mt, uint32_t& m) {
     Units32<PBf16> u = pack_units(PBf16(), acc);
+    if (EO_ABL & 4) return u;
     if (!(mt & 1)) m = 0;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -289,6 +301,7 @@ template <> struct SlabWriter<PF32> {
     EO_DEV void flush_pending() {}
     EO_DEV void init(void* slab, int rows, int wave_p0, int lane, uint8_t*) {
         const int c = lane & 31, h = lane >> 5;
+        wave_p0 = __builtin_amdgcn_readfirstlane(wave_p0);          // wave-uniform: keeps the descriptor in SGPRs (no waterfall loop)
         uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)(wave_p0 / 16) * rows * SEG_B;
         rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * SEG_B * 2, 0x00020000);
         voff = (c >> 4) * rows * SEG_B + 4 * h * SEG_B + (c & 15) * 4;
@@ -317,6 +330,7 @@ template <> struct SlabWriter<PBf16> {
     int pend_row = -1, buf = 0;
     EO_DEV void init(void* slab, int rows, int wave_p0, int lane, uint8_t* scratch_wave) {
         const int c = lane & 31, h = lane >> 5;
+        wave_p0 = __builtin_amdgcn_readfirstlane(wave_p0);          // wave-uniform: keeps the descriptor in SGPRs (no waterfall loop)
         uint8_t* base = reinterpret_cast<uint8_t*>(slab) + (size_t)(wave_p0 / 32) * rows * SEG_B;
         rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * SEG_B, 0x00020000);
         voff1 = 4 * h * SEG_B + c * 2;
@@ -332,15 +346,21 @@ template <> struct SlabWriter<PBf16> {
     }
     EO_DEV void flush_pending() {
         if (pend_row < 0) return;
-        const uint8_t* rb = rptr + (buf ^ 1) * TR_WAVE_B;          // the buffer staged last
-#pragma unroll
-        for (int pair = 0; pair < 2; ++pair) {
-            const uint8_t* rp = rb + pair * 32;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rp));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rp + 4 * TR_STRIDE));
-            const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], b[0], b[1]}, rs, svoff, (pend_row + 16 * pair) * SEG_B, 0);
-        }
+        // Inline asm on purpose: for the ds_read_tr intrinsic the compiler's wait-count pass assumes the read may alias the
+        // in-flight LDS-DMA weight prefetch and puts s_waitcnt vmcnt(0) in front of it -- a full drain of the prefetch AND of
+        // the previous tile's slab stores (an HBM write round trip) once per m-tile.  The scratch is wave-private and never
+        // written by LDS-DMA.
+        const uint32_t ra = (uint32_t)(uintptr_t)(rptr + (buf ^ 1) * TR_WAVE_B);        // low 32 bits of a generic LDS address = LDS offset
+        u32x2 a0, b0, a1, b1;
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                     "ds_read_b64_tr_b16 %1, %4 offset:288\n\t"
+                     "ds_read_b64_tr_b16 %2, %4 offset:32\n\t"
+                     "ds_read_b64_tr_b16 %3, %4 offset:320\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1) : "v"(ra) : "memory");
+        static_assert(4 * TR_STRIDE == 288, "asm offsets");
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], b0[0], b0[1]}, rs, svoff, pend_row * SEG_B, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a1[0], a1[1], b1[0], b1[1]}, rs, svoff, (pend_row + 16) * SEG_B, 0);
         pend_row = -1;
     }
     EO_DEV void tile(int row0, const Units32<PBf16>& u) {
