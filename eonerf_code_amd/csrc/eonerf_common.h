@@ -107,34 +107,44 @@ template <class P, int SLOT_BYTES> struct WStream {
     uint32_t par;                // slot parity of the resident chunk
     int tid;
 
-    EO_DEV void issue(int qi, uint32_t slot) {
-        // constant address space: the table is read-only for the whole launch, so this is an s_load (a generic-pointer load
-        // becomes a VECTOR load + s_waitcnt vmcnt(0), which drains every outstanding slab store once per chunk)
+    // descriptor of chunk qi.  Constant address space: the table is read-only for the whole launch, so this is an s_load
+    // (a generic-pointer load becomes a VECTOR load + s_waitcnt vmcnt(0), which drains every outstanding slab store).
+    EO_DEV ChunkDesc desc(int qi) const {
         const auto* t4 = reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(tab));
-        const ChunkDesc d = {t4[2 * qi], t4[2 * qi + 1]};
-        const uint8_t* src = g + d.off;
-        uint8_t* dst = lds + slot * SLOT_BYTES;
-        const int wave_off = (tid & ~63) * 16;
-        for (uint32_t base = 0; base < d.bytes; base += P::NT * 16) {
-            uint32_t o = base + tid * 16;
-            if (o < d.bytes)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + o),
-                                                 (__attribute__((address_space(3))) void*)(dst + base + wave_off), 16, 0, 0);
-        }
+        return ChunkDesc{t4[2 * qi], t4[2 * qi + 1]};
+    }
+    // one ROUND of the copy of a chunk = one 16-byte LDS-DMA piece per thread (NT * 16 bytes)
+    static constexpr uint32_t ROUND_B = P::NT * 16;
+    static constexpr int MAX_ROUNDS = (SLOT_BYTES + ROUND_B - 1) / ROUND_B;
+    uint32_t pf_off, pf_bytes, pf_base, pf_slot;     // prefetch in progress (wave-uniform)
+    EO_DEV void round() {
+        const uint32_t o = pf_base + tid * 16;
+        if (o < pf_bytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + pf_off + o),
+                                             (__attribute__((address_space(3))) void*)(lds + pf_slot * SLOT_BYTES + pf_base + (tid & ~63) * 16),
+                                             16, 0, 0);
+        pf_base += ROUND_B;
     }
     // first chunk of the launch
     EO_DEV void start() {
         q = 0; par = 0;
-        issue(0, 0);
+        const ChunkDesc d = desc(0);
+        pf_off = d.off; pf_bytes = d.bytes; pf_base = 0; pf_slot = 0;
+        while (pf_base < pf_bytes) round();
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    // call before computing on the resident chunk: prefetch its successor into the other slot.  The scheduling
-    // barrier pins the LDS-DMA loads BEFORE every store of the chunk's epilogues (advance<> counts on that order).
+    // call before computing on the resident chunk: starts the prefetch of its successor into the other slot.  The copy
+    // itself is issued by pump()/pump_rest() BETWEEN the MFMAs of the chunk's first m-tile (chunk_compute): issued in one
+    // burst right after the barrier, every wave of the workgroup stalls on LDS-DMA issue at the same time with no matrix
+    // work in flight.  All rounds are issued before the first m-tile's epilogue, i.e. before every slab store that
+    // advance<> counts as younger.
     EO_DEV void prefetch_next() {
         int nq = q + 1; if (nq == n_chunks) nq = 0;
-        if (!(EO_ABL & 8)) issue(nq, par ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
+        const ChunkDesc d = desc(nq);
+        pf_off = d.off; pf_bytes = (EO_ABL & 8) ? 0u : d.bytes; pf_base = 0; pf_slot = par ^ 1;
     }
+    EO_DEV void pump() { if (pf_base < pf_bytes) round(); }
+    EO_DEV void pump_rest() { while (pf_base < pf_bytes) round(); }
     // call after computing on the resident chunk.  YOUNGER = a lower bound on the vector-memory operations (the
     // epilogues' slab stores) this wave issued AFTER prefetch_next(): vmcnt retires in issue order, so waiting until
     // at most YOUNGER operations are outstanding guarantees the prefetch has landed without draining the stores
@@ -171,9 +181,15 @@ EO_DEV f32x16 zero_acc() { f32x16 a; for (int i = 0; i < 16; ++i) a[i] = 0.f; re
 // The A operands of the whole chunk form ONE stream of G*KG 1-KiB units; a rotating window of PF units is kept in
 // flight ahead of the MFMA that consumes them (ds_read -> wait -> mfma per unit would expose the full LDS latency
 // to every MFMA), across m-tile boundaries, and the next tile's bias is fetched while the current tile multiplies.
-template <class P, int KG, int G, bool BIAS, class BArr, class Epi, class Mid>
-EO_DEV void chunk_compute(const uint8_t* chunk, int lane, int h, const BArr& B, int m0, Epi&& epi, Mid&& mid) {
-    constexpr int MIDK = KG > 4 ? 3 : KG - 1;        // where the previous tile's deferred slab flush is issued
+template <class P, int KG, int G, bool BIAS, class WS, class BArr, class Epi, class Mid>
+EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& epi, Mid&& mid) {
+    const uint8_t* chunk = ws.cur();
+    // prefetch rounds are issued after MFMAs 0, 1, 2, ... of the first m-tile (early: the copy has to land within the chunk);
+    // the last position takes what is left
+    constexpr int PLAST = WS::MAX_ROUNDS - 1 < KG ? WS::MAX_ROUNDS - 1 : KG - 1;
+    constexpr int MIDK = KG > 4 ? 3 : KG - 1;        // where the previous tile's deferred slab flush is issued ...
+    constexpr int MID0 = PLAST > MIDK ? PLAST : MIDK; // ... in the first m-tile: after the last prefetch round (the flush's stores
+                                                      // must stay YOUNGER than the copy, see WStream::advance)
     constexpr int NF = G * KG;
     constexpr int PF = NF < 4 ? NF : 4;
     const uint8_t* a = chunk + lane * 16;
@@ -190,7 +206,11 @@ EO_DEV void chunk_compute(const uint8_t* chunk, int lane, int h, const BArr& B, 
             const int f = g * KG + kg;
             acc = P::mma(fr[f % PF], B(kg), acc);
             if (!(EO_ABL & 2) && f + PF < NF) fr[f % PF] = lds_unit<P>(a + (f + PF) * 1024);
-            if (kg == MIDK) mid();
+            if (g == 0) {
+                if (kg == PLAST) ws.pump_rest();
+                else if (kg < PLAST) ws.pump();
+            }
+            if (kg == (g == 0 ? MID0 : MIDK)) mid();
             __builtin_amdgcn_sched_barrier(0);      // keep the window: the scheduler would otherwise re-serialise read/wait/mfma
         }
         epi(m0 + g, acc);
@@ -207,7 +227,7 @@ EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BA
 #pragma unroll
     for (int mg = 0; mg < MT / G; ++mg) {
         ws.prefetch_next();
-        chunk_compute<P, KG, G, BIAS>(ws.cur(), lane, h, B, mg * G, epi, mid);
+        chunk_compute<P, KG, G, BIAS>(ws, lane, h, B, mg * G, epi, mid);
         ws.template advance<(P::IS_BF16 ? (G - 1) : G) * NST>();
     }
 }
