@@ -56,6 +56,7 @@ struct eonerf_ctx {
     eonerf_config cfg;
     bool bf16;
     int n_cu;
+    int wgrad_items;      // target number of weight-gradient work items per launch (EONERF_WGRAD_ITEMS, default 48 per job)
     ParamLayout pl;
     DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb;
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
@@ -223,6 +224,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete ctx; return (int)hipErrorNoDevice; }
     ctx->n_cu = prop.multiProcessorCount;
+    { const char* e = getenv("EONERF_WGRAD_ITEMS"); ctx->wgrad_items = e && atoi(e) > 0 ? atoi(e) : 0; }
     ctx->pl.build(cfg->n_images);
     int rc = upload(ctx->fwd_full, build_fwd_stream(ctx->pl, ctx->bf16, true));
     if (!rc) rc = upload(ctx->fwd_dens, build_fwd_stream(ctx->pl, ctx->bf16, false));
@@ -568,16 +570,19 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     WgradJobTable tab;
     tab.n = 0;
     std::vector<int> weight;
-    auto rows = [&](const void* slab, int row) { return reinterpret_cast<const uint8_t*>(slab) + (size_t)row * SEG_B; };
+    const size_t n_tiles = (size_t)p_cap / (ctx->bf16 ? 32 : 16);      // sample tiles of the slabs (block-major layout, eonerf_common.h)
+    auto seg0 = [&](const void* slab, SlabBlk blk, int row) {           // (row, sample tile 0)
+        return reinterpret_cast<const uint8_t*>(slab) + ((size_t)blk.s * n_tiles + (row - blk.s)) * SEG_B;
+    };
     auto add = [&](const PassBuffers& b, int grd_row, int m_rows, int act_row, int n_rows, float* dw, int dw_ld, float* db,
                    const int* cmap, int gm, int gn, int wm, int wn) {
         WgradJob& j = tab.j[tab.n++];
-        const bool full = &b == &w.cam;
-        j.a = rows(b.grd, grd_row); j.b = rows(b.act, act_row); j.dw = dw; j.db = db; j.col_map = cmap; j.n_pts = b.n_pts;
-        j.a_stride = (uint32_t)((full ? GRD_ROWS_FULL : GRD_ROWS_DENSITY) * SEG_B);
-        j.b_stride = (uint32_t)((full ? ACT_ROWS_FULL : ACT_ROWS_DENSITY) * SEG_B);
+        const SlabBlk ba = GrdMap::block(grd_row), bb = ActMap::block(act_row);
+        j.a = seg0(b.grd, ba, grd_row); j.b = seg0(b.act, bb, act_row); j.dw = dw; j.db = db; j.col_map = cmap; j.n_pts = b.n_pts;
+        j.a_stride = (uint32_t)(ba.r * SEG_B);       // consecutive sample tiles of a block are contiguous
+        j.b_stride = (uint32_t)(bb.r * SEG_B);
         j.m_rows = m_rows; j.n_rows = n_rows; j.dw_ld = dw_ld; j.gm = gm; j.gn = gn; j.wm = wm; j.wn = wn;
-        weight.push_back(wm * wn + 1);
+        weight.push_back(1);      // measured: a K step costs about the same for every job shape (the loop is latency-bound), so equal slices          // ~ cost of one K step: operand rows fetched + a fixed part
     };
     auto trunk_jobs = [&](const PassBuffers& b) {
         add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
@@ -606,9 +611,19 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     std::vector<int> order(tab.n);
     for (int k = 0; k < tab.n; ++k) order[k] = k;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+    // every work item = one slice of one job's sample range; slices in proportion to the job's cost per K step
     WgradJobTable sorted;
-    sorted.n = tab.n; sorted.slices = 48;
-    for (int k = 0; k < tab.n; ++k) sorted.j[k] = tab.j[order[k]];
+    sorted.n = tab.n; sorted.items = 0;
+    long long total = 0;
+    for (int k = 0; k < tab.n; ++k) total += weight[k];
+    for (int k = 0; k < tab.n; ++k) {
+        WgradJob& j = sorted.j[k];
+        j = tab.j[order[k]];
+        int sl = ctx->wgrad_items ? (int)(((long long)ctx->wgrad_items * weight[order[k]] + total / 2) / total) : 48;
+        j.slices = sl < 1 ? 1 : sl;
+        j.item0 = sorted.items;
+        sorted.items += j.slices;
+    }
     { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(sorted, ctx->n_cu, p_cap, w.flags + 2, ctx->bf16, st)); }
 
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------

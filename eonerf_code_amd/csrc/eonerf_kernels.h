@@ -25,6 +25,26 @@ constexpr int GRD_ROW_T5 = GRD_ROW_T1 + 512;        // 3008: d {ts_pre, tb_pre} 
 constexpr int GRD_ROWS_FULL = GRD_ROW_T5 + 32;      // 3040
 constexpr int GRD_ROWS_DENSITY = GRD_ROW_SIG + 32;  // 2336
 
+// row blocks of the two slabs (block-major layout, see eonerf_common.h): the operand units of the weight-gradient jobs
+struct ActMap {
+    __host__ __device__ static constexpr SlabBlk block(int row) {
+        if (row < ACT_ROW_X1) return SlabBlk{ACT_ROW_ENC, 64};
+        if (row < ACT_ROW_A1) return SlabBlk{ACT_ROW_X1 + (row - ACT_ROW_X1) / 256 * 256, 256};     // X1..X8, bottleneck
+        if (row < ACT_ROW_EMB) return SlabBlk{ACT_ROW_A1 + (row - ACT_ROW_A1) / 128 * 128, 128};    // A1, T1..T4
+        return SlabBlk{ACT_ROW_EMB, 32};
+    }
+};
+struct GrdMap {
+    __host__ __device__ static constexpr SlabBlk block(int row) {
+        if (row < GRD_ROW_SIG) return SlabBlk{row / 256 * 256, 256};                                 // dY0..dY7, d bottleneck
+        if (row < GRD_ROW_A1) return SlabBlk{GRD_ROW_SIG, 32};
+        if (row < GRD_ROW_A2) return SlabBlk{GRD_ROW_A1, 128};
+        if (row < GRD_ROW_T1) return SlabBlk{GRD_ROW_A2, 32};
+        if (row < GRD_ROW_T5) return SlabBlk{GRD_ROW_T1 + (row - GRD_ROW_T1) / 128 * 128, 128};      // dY T1..T4
+        return SlabBlk{GRD_ROW_T5, 32};
+    }
+};
+
 constexpr int MASK_SLOTS_FULL = 13;                 // trunk 0..7, A1, T1..T4
 constexpr int MASK_SLOTS_DENSITY = 8;
 
@@ -86,10 +106,11 @@ struct WgradJob {
     int m_rows, n_rows;   // valid rows of a / b
     int dw_ld;            // row stride of dw
     int gm, gn, wm, wn;   // wave grid and tiles per wave: (gm*wm*32) x (gn*wn*32) >= m_rows x n_rows
+    int item0, slices;    // work items [item0, item0 + slices) = equal slices of this job's K range
 };
 
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st);
 constexpr int WGRAD_MAX_JOBS = 40;
-struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int slices; };   // by value in the kernel-argument segment; jobs sorted heaviest first
+struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int items; };   // by value in the kernel-argument segment; jobs sorted heaviest first
 hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st);

@@ -41,9 +41,8 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     for (int tile = blockIdx.x; tile * P::TILE < n_pts; tile += gridDim.x) {
         const int p = tile * P::TILE + wave * 32 + c;
         const bool live = p < n_pts;
-        constexpr int GROWS = FULL ? GRD_ROWS_FULL : GRD_ROWS_DENSITY;
-        SlabWriter<P> sw;                                                   // this wave's sample tile(s) of the gradient slab
-        sw.init(a.grd, GROWS, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
+        SlabWriter<P, GrdMap> sw;                                                   // this wave's sample tile(s) of the gradient slab
+        sw.init(a.grd, a.p_pad / Slab<P>::TSAMP, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
         uint32_t mb[4];
         auto mid = [&]() { sw.flush_pending(); };
 
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
 
 template <class P, bool FULL, bool IG, bool TRANS>
 hipError_t launch(const MlpBwdArgs& a, int grid, hipStream_t st) {
-    constexpr int SMEM = 2 * FwdSlot<P>::BYTES + SlabWriter<P>::LDS_BYTES;
+    constexpr int SMEM = 2 * FwdSlot<P>::BYTES + SlabWriter<P, GrdMap>::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG, TRANS>),

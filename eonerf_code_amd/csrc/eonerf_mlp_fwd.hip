@@ -66,10 +66,9 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         const bool live = p < n_pts;
         const float x = live ? a.px[p] : 0.f, y = live ? a.py[p] : 0.f, z = live ? a.pz[p] : 0.f;
         const EncUnits<P> E = encode_position<P>(x, y, z, h);
-        constexpr int AROWS = FULL ? ACT_ROWS_FULL : ACT_ROWS_DENSITY;
-        SlabWriter<P> sw;                                                   // this wave's sample tile(s) of the activation slab
+        SlabWriter<P, ActMap> sw;                                                   // this wave's sample tile(s) of the activation slab
         if constexpr (TRAIN) {
-            sw.init(a.act, AROWS, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
+            sw.init(a.act, a.p_pad / Slab<P>::TSAMP, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
 #pragma unroll
             for (int kg = 0; kg < EKG; ++kg)      // encoding slots, rows [0,64)
 #pragma unroll
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 
 template <class P, bool FULL, int MODE>
 hipError_t launch(const MlpFwdArgs& a, int grid, hipStream_t st) {
-    constexpr int SMEM = 2 * FwdSlot<P>::BYTES + (MODE ? SlabWriter<P>::LDS_BYTES : 0);
+    constexpr int SMEM = 2 * FwdSlot<P>::BYTES + (MODE ? SlabWriter<P, ActMap>::LDS_BYTES : 0);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, MODE>),

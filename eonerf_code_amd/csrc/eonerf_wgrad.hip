@@ -11,6 +11,7 @@
 // bank-conflict free.
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -22,7 +23,6 @@ constexpr int SLOT_B = 2 * OPND_B;               // A + B
 constexpr int NS = 4;                            // ring slots (128 KiB)
 constexpr int DEPTH = NS - 1;                    // K steps in flight ahead of the one being multiplied
 constexpr int WMAX = 4, NMAX = 2;
-constexpr int GLDS_PER_STEP = 4;                 // per wave: 2 x 16 rows of A, 2 x 16 rows of B
 
 // 16-B chunk c of row `row` lives at chunk position c ^ ((row >> 2) & 3): a ds_read_b128 lane group (16 rows, one
 // chunk) then covers all 64 banks exactly once
@@ -43,13 +43,15 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
     if (tid == 0) *lds_item = atomicAdd(queue, 1);
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(*lds_item);
-    if (item >= tab.n * tab.slices) return;
-    const WgradJob job = tab.j[item / tab.slices];
-    const int w = item % tab.slices;
+    if (item >= tab.items) return;
+    int ji = 0;
+    while (ji + 1 < tab.n && item >= tab.j[ji + 1].item0) ++ji;      // <= 40 jobs, uniform scalar scan
+    const WgradJob job = tab.j[ji];
+    const int w = item - job.item0, n_slices = job.slices;
     const int n_pts = *job.n_pts;
     const int n_pad = (n_pts + P::TILE - 1) / P::TILE * P::TILE;
     const int steps = n_pad / BK;
-    const int s0 = (int)((long long)w * steps / tab.slices), s1 = (int)((long long)(w + 1) * steps / tab.slices);
+    const int s0 = (int)((long long)w * steps / n_slices), s1 = (int)((long long)(w + 1) * steps / n_slices);
     if (s0 >= s1) continue;
 
     const int wm = job.wm, wn = job.wn, gn = job.gn;
@@ -61,6 +63,8 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
     //      they only feed output rows/columns that are never flushed, and every wave issues the same number of loads
     //      per step, which is what the counted vmcnt below relies on. ----
     int voff_a[2], voff_b[2];
+    bool on_a[2], on_b[2];          // wave-uniform: this wave's 16-row half-blocks that hold valid rows (the others are never fetched:
+    int n_dma = 0;                  // they only feed output rows / columns that are never flushed)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = 32 * wid + 16 * j + (lane >> 2);
@@ -68,6 +72,9 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
         const int ra = row < job.m_rows ? row : job.m_rows - 1, rb = row < job.n_rows ? row : job.n_rows - 1;
         voff_a[j] = ra * SEG_B + chunk * 16;
         voff_b[j] = rb * SEG_B + chunk * 16;
+        on_a[j] = 32 * wid + 16 * j < job.m_rows;
+        on_b[j] = 32 * wid + 16 * j < job.n_rows;
+        n_dma += (on_a[j] ? 1 : 0) + (on_b[j] ? 1 : 0);
     }
     // K step s = sample tile s of the slabs: one contiguous rows x 64 B region per operand
     auto issue = [&](int step, int slot) {
@@ -78,8 +85,8 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
             const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.b)) + (size_t)step * job.b_stride, 0, job.n_rows * SEG_B, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(base + 16 * j * ROW_B), 16, voff_a[j], 0, 0, 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(base + OPND_B + 16 * j * ROW_B), 16, voff_b[j], 0, 0, 2);
+            if (on_a[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(base + 16 * j * ROW_B), 16, voff_a[j], 0, 0, 2);
+            if (on_b[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(base + OPND_B + 16 * j * ROW_B), 16, voff_b[j], 0, 0, 2);
         }
     };
 
@@ -108,31 +115,43 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
 
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) issue(s0 + d < s1 ? s0 + d : s1 - 1, d);
-    for (int s = s0; s < s1; ++s) {
-        const int slot = (s - s0) & (NS - 1);
-        // this wave's share of step s has landed once at most (DEPTH-1) younger steps are outstanding; the barrier then
-        // (a) publishes every wave's share and (b) retires all reads of the slot refilled next
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GLDS_PER_STEP * (DEPTH - 1)) : "memory");
-        issue(s + DEPTH < s1 ? s + DEPTH : s1 - 1, (slot + DEPTH) & (NS - 1));
-        if (active) {
-            const uint8_t* T = smem + slot * SLOT_B;
+    // the loop is instantiated per number of LDS-DMA pieces this wave issues per step (the counted vmcnt needs an immediate);
+    // waves of one workgroup may run different instantiations, they all meet at the same s_barrier once per step
+    auto k_loop = [&](auto n_dma_c) {
+        constexpr int N_DMA = decltype(n_dma_c)::value;
+        for (int s = s0; s < s1; ++s) {
+            const int slot = (s - s0) & (NS - 1);
+            // this wave's share of step s has landed once at most (DEPTH-1) younger steps are outstanding; the barrier then
+            // (a) publishes every wave's share and (b) retires all reads of the slot refilled next
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_DMA * (DEPTH - 1)) : "memory");
+            issue(s + DEPTH < s1 ? s + DEPTH : s1 - 1, (slot + DEPTH) & (NS - 1));
+            if (active) {
+                const uint8_t* T = smem + slot * SLOT_B;
 #pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                U af[WMAX], bf[NMAX];
+                for (int kg = 0; kg < 2; ++kg) {
+                    U af[WMAX], bf[NMAX];
 #pragma unroll
-                for (int i = 0; i < WMAX; ++i) if (i < wm) af[i] = lds_unit<P>(T + off_a[i][kg]);
+                    for (int i = 0; i < WMAX; ++i) if (i < wm) af[i] = lds_unit<P>(T + off_a[i][kg]);
 #pragma unroll
-                for (int j = 0; j < NMAX; ++j) if (j < wn) bf[j] = lds_unit<P>(T + off_b[j][kg]);
+                    for (int j = 0; j < NMAX; ++j) if (j < wn) bf[j] = lds_unit<P>(T + off_b[j][kg]);
 #pragma unroll
-                for (int i = 0; i < WMAX; ++i)
-                    if (i < wm) {
+                    for (int i = 0; i < WMAX; ++i)
+                        if (i < wm) {
 #pragma unroll
-                        for (int j = 0; j < NMAX; ++j)
-                            if (j < wn) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
-                        if (do_bias && i == wn_idx) accb = P::mma(af[i], ones, accb);
-                    }
+                            for (int j = 0; j < NMAX; ++j)
+                                if (j < wn) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
+                            if (do_bias && i == wn_idx) accb = P::mma(af[i], ones, accb);
+                        }
+                }
             }
         }
+    };
+    switch (n_dma) {
+        case 0: k_loop(std::integral_constant<int, 0>()); break;
+        case 1: k_loop(std::integral_constant<int, 1>()); break;
+        case 2: k_loop(std::integral_constant<int, 2>()); break;
+        case 3: k_loop(std::integral_constant<int, 3>()); break;
+        default: k_loop(std::integral_constant<int, 4>()); break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail prefetches before the LDS is released
 
