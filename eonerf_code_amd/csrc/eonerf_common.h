@@ -74,12 +74,23 @@ struct PF32 {
 // accumulator tile -> the KG32 B-operand units of the next layer (same feature order, no permutation)
 template <class P> struct Units32 { typename P::U u[P::KG32]; };
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// two fp32 -> one packed bf16 word (round to nearest even): the pair form compiles to ONE v_cvt_pk_bf16_f32
+EO_DEV uint32_t cvt_pk_bf16(float lo, float hi) {
+    const f32x2 p = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(p, bf16x2));
+}
 EO_DEV Units32<PBf16> pack_units(PBf16, const f32x16& v) {
     Units32<PBf16> o;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+        u32x4 w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o.u[s][j] = (__bf16)v[8 * s + j];
+        for (int i = 0; i < 4; ++i) w[i] = cvt_pk_bf16(v[8 * s + 2 * i], v[8 * s + 2 * i + 1]);
+        o.u[s] = __builtin_bit_cast(bf16x8, w);
+
+    }
     return o;
 }
 EO_DEV Units32<PF32> pack_units(PF32, const f32x16& v) {
@@ -234,8 +245,8 @@ EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BA
 // ReLU + pack + 1-bit mask (forward), mask + pack (backward).  One mask dword covers a PAIR of m-tiles (32 regs/lane).
 //   fp32: bit (16*(mt&1) + r) = acc[r] > 0.
 //   bf16: works on the PACKED words (2 elements per VALU op): ReLU = v_pk_max_i16(w, 0) (a negative bf16 is a negative
-//         int16), nonzero test = (w + 0x7fff7fff) & 0x80008000 shifted into the mask; element r = 2i + half of tile mt
-//         ends up at bit 8*(mt&1) + i + 16*half.
+//         int16), nonzero flags = v_pk_min_u16(w, 1), shifted into the mask with one v_lshl_or_b32 per word: word k
+//         (elements 2k, 2k+1) of tile mt ends up at bit 8*(mt&1) + 7 - k, + 16 for the odd element.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 
@@ -248,22 +259,26 @@ EO_DEV Units32<PF32> relu_pack_mask(PF32, const f32x16& acc, int mt, uint32_t& m
     return pack_units(PF32(), v);
 }
 EO_DEV Units32<PBf16> relu_pack_mask(PBf16, const f32x16& acc, int mt, uint32_t& m) {
-    Units32<PBf16> u = pack_units(PBf16(), acc);
-    if (EO_ABL & 4) return u;
-    if (!(mt & 1)) m = 0;
+    Units32<PBf16> u;
+    uint32_t bits = 0;
+    const uint32_t ones = 0x00010001u;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        u32x4 w = __builtin_bit_cast(u32x4, u.u[s]);
+        u32x4 w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const s16x2 z = {0, 0};
-            const uint32_t wi = w[i];
+            const uint32_t wi = cvt_pk_bf16(acc[8 * s + 2 * i], acc[8 * s + 2 * i + 1]);
+            if (EO_ABL & 4) { w[i] = wi; continue; }
             const uint32_t x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wi), z));
+            uint32_t t;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(x), "v"(ones));      // 1 where the element is > 0 (x is >= 0 here)
+            bits = (bits << 1) | t;
             w[i] = x;
-            m = (m >> 1) | ((x + 0x7fff7fffu) & 0x80008000u);
         }
         u.u[s] = __builtin_bit_cast(bf16x8, w);
     }
+    m = (mt & 1) ? (m | (bits << 8)) : bits;
     return u;
 }
 EO_DEV Units32<PF32> mask_pack(PF32, const f32x16& acc, int mt, uint32_t m) {
@@ -274,15 +289,18 @@ EO_DEV Units32<PF32> mask_pack(PF32, const f32x16& acc, int mt, uint32_t m) {
     return pack_units(PF32(), v);
 }
 EO_DEV Units32<PBf16> mask_pack(PBf16, const f32x16& acc, int mt, uint32_t m) {
-    Units32<PBf16> u = pack_units(PBf16(), acc);
+    Units32<PBf16> u;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        u32x4 w = __builtin_bit_cast(u32x4, u.u[s]);
+        u32x4 w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = 8 * (mt & 1) + 4 * s + i;
-            const uint32_t sel = (m >> k) & 0x00010001u;
-            w[i] &= sel * 0xffffu;          // 0x00010001 * 0xffff = 0xffffffff, no carries between the halves
+            const int pos = 8 * (mt & 1) + 7 - (4 * s + i);
+            const uint32_t sel = (m >> pos) & 0x00010001u;
+            const uint32_t wi = cvt_pk_bf16(acc[8 * s + 2 * i], acc[8 * s + 2 * i + 1]);
+            uint32_t r;
+            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(wi), "v"(sel));      // x * {0,1} per element
+            w[i] = r;
         }
         u.u[s] = __builtin_bit_cast(bf16x8, w);
     }
@@ -397,6 +415,10 @@ template <class Map> struct SlabWriter<PBf16, Map> : SlabWriterBase {
         static_assert(4 * TR_STRIDE == 288, "asm offsets");
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], b0[0], b0[1]}, pend_rs, svoff, pend_off, 0);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{a1[0], a1[1], b1[0], b1[1]}, pend_rs, svoff, pend_off + 16 * SEG_B, 0);
+        // A 128-bit store reads its data VGPRs a couple of cycles after issue.  The compiler only guards that window when the
+        // store has no SGPR soffset; measured on gfx950 it exists with one too (a VALU write to the first data register right
+        // behind the store reached memory instead of the tile: garbage in rows 28..31 of a 32x32 tile).
+        asm volatile("s_nop 1" ::: "memory");
         pend = 0;
     }
     EO_DEV void tile(int row0, const Units32<PBf16>& u) {
