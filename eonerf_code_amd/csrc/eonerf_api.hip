@@ -92,22 +92,29 @@ void release(DevStream& d) {
     d = DevStream();
 }
 
-__global__ void k_pack16(const float* flat, const PackEntry* e, int n, uint8_t* stream) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PackEntry pe = e[i];
-    const float v = pe.src < 0 ? 0.f : flat[pe.src];
-    *reinterpret_cast<__bf16*>(stream + pe.dst) = (__bf16)v;
+// (re)packs the fp32 master weights into up to PACK_MAX_JOBS packed streams in ONE launch (blockIdx.y = job): after every
+// optimizer step three streams x {bf16, fp32} entries are rewritten, and six ~5 us launches cost more than the copies
+constexpr int PACK_MAX_JOBS = 8;
+struct PackJob { const PackEntry* e; int n; uint8_t* data; int is16; };
+struct PackJobs { PackJob j[PACK_MAX_JOBS]; };
+__global__ void k_pack(const float* flat, PackJobs jobs) {
+    const PackJob jb = jobs.j[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
+        const PackEntry pe = jb.e[i];
+        const float v = pe.src < 0 ? 0.f : flat[pe.src];
+        if (jb.is16) *reinterpret_cast<__bf16*>(jb.data + pe.dst) = (__bf16)v;
+        else *reinterpret_cast<float*>(jb.data + pe.dst) = v;
+    }
 }
-__global__ void k_pack32(const float* flat, const PackEntry* e, int n, uint8_t* stream) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PackEntry pe = e[i];
-    *reinterpret_cast<float*>(stream + pe.dst) = pe.src < 0 ? 0.f : flat[pe.src];
-}
-int pack(const DevStream& d, const float* flat, hipStream_t st) {
-    if (d.n16) hipLaunchKernelGGL(k_pack16, dim3((d.n16 + 255) / 256), dim3(256), 0, st, flat, d.e16, d.n16, d.data);
-    hipLaunchKernelGGL(k_pack32, dim3((d.n32 + 255) / 256), dim3(256), 0, st, flat, d.e32, d.n32, d.data);
+int pack(std::initializer_list<const DevStream*> streams, const float* flat, hipStream_t st) {
+    PackJobs jobs;
+    int n = 0, most = 1;
+    for (const DevStream* d : streams) {
+        if (d->n16) jobs.j[n++] = PackJob{d->e16, d->n16, d->data, 1};
+        jobs.j[n++] = PackJob{d->e32, d->n32, d->data, 0};
+        most = std::max(most, std::max(d->n16, d->n32));
+    }
+    hipLaunchKernelGGL(k_pack, dim3(std::min((most + 255) / 256, 1024), n), dim3(256), 0, st, flat, jobs);
     return (int)hipGetLastError();
 }
 
@@ -172,8 +179,7 @@ AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
 
 int ensure_density_streams(eonerf_ctx* ctx, const float* flat, hipStream_t st) {
     if (!ctx->dens_dirty) return 0;
-    int rc = pack(ctx->fwd_dens, flat, st);
-    if (!rc) rc = pack(ctx->bwd_dens, flat, st);
+    const int rc = pack({&ctx->fwd_dens, &ctx->bwd_dens}, flat, st);
     if (!rc) ctx->dens_dirty = false;
     return rc;
 }
@@ -293,9 +299,7 @@ int eonerf_param_info(const eonerf_ctx* ctx, int index, const char** name, size_
 int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     if (!ctx || !flat) return EONERF_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int rc = pack(ctx->fwd_full, flat, st);
-    if (!rc) rc = pack(ctx->bwd_full, flat, st);
-    if (!rc) rc = pack(ctx->bwd_rgb, flat, st);
+    const int rc = pack({&ctx->fwd_full, &ctx->bwd_full, &ctx->bwd_rgb}, flat, st);
     if (!rc) { ctx->weights_set = true; ctx->dens_dirty = true; }
     return rc;
 }
@@ -632,6 +636,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays; eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0;
         HIP_TRY(eo_launch_emb_grad(eg, st));
     }
+    if (!shadows) return EONERF_OK;      // s == 1: rgb = albedo, the ambient head is outside the graph (sat_rendering.py:269-276,294)
     AmbientBwdArgs ag;
     ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
     ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);

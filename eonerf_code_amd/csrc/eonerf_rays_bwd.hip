@@ -274,7 +274,7 @@ hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st
     return hipGetLastError();
 }
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_ambient_bwd, dim3(a.n_rays < 64 ? a.n_rays : 64), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_ambient_bwd, dim3(a.n_rays < 256 ? a.n_rays : 256), dim3(128), 0, st, a);      // the ray loop is a chain of dependent loads: keep it short
     return hipGetLastError();
 }
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
