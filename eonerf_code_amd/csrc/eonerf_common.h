@@ -186,17 +186,27 @@ EO_DEV f32x16 bias_init(const uint8_t* bias32, int h) {
 }
 EO_DEV f32x16 zero_acc() { f32x16 a; for (int i = 0; i < 16; ++i) a[i] = 0.f; return a; }
 
-// One chunk group of a layer:  for g in [0,G):  acc = bias + sum_kg A[g][kg] * B[kg];  epi(m0+g, acc)
+// One chunk group of a layer:  for g in [0,G):  acc = bias + sum_kg A[g][kg] * B[kg];  epilogue of tile m0+g
 // The A operands of the whole chunk form ONE stream of G*KG 1-KiB units; a rotating window of PF units is kept in
 // flight ahead of the MFMA that consumes them (ds_read -> wait -> mfma per unit would expose the full LDS latency
 // to every MFMA), across m-tile boundaries, and the next tile's bias is fetched while the current tile multiplies.
+//
+// Epilogues are SLICED and DEFERRED: epi(mt, acc, s) does slice s in [0, EPI_SLICES) of the epilogue of m-tile mt
+// (accumulator registers 2s, 2s+1: convert, activation / mask, hand to the next layer, stage for the slab), and the
+// slices of tile g run BETWEEN the MFMAs of tile g+1 of the same chunk -- a few VALU operations per MFMA gap instead of
+// a block of ~50 behind the last MFMA of every tile (with the s_nop the matrix pipeline needs before its result can be
+// read), during which this wave has no matrix work in flight.  The last tile of a chunk is finished before the chunk
+// barrier.
+constexpr int EPI_SLICES = 8;
+template <int KG> EO_DEV constexpr int slice_pos(int s) { return KG >= 14 ? 5 + s : (s * KG) / EPI_SLICES; }
+
 template <class P, int KG, int G, bool BIAS, class WS, class BArr, class Epi, class Mid>
 EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& epi, Mid&& mid) {
     const uint8_t* chunk = ws.cur();
     // prefetch rounds are issued after MFMAs 0, 1, 2, ... of the first m-tile (early: the copy has to land within the chunk);
     // the last position takes what is left
     constexpr int PLAST = WS::MAX_ROUNDS - 1 < KG ? WS::MAX_ROUNDS - 1 : KG - 1;
-    constexpr int MIDK = KG > 4 ? 3 : KG - 1;        // where the previous tile's deferred slab flush is issued ...
+    constexpr int MIDK = KG > 4 ? 3 : KG - 1;        // where the oldest staged tile's slab flush is issued ...
     constexpr int MID0 = PLAST > MIDK ? PLAST : MIDK; // ... in the first m-tile: after the last prefetch round (the flush's stores
                                                       // must stay YOUNGER than the copy, see WStream::advance)
     constexpr int NF = G * KG;
@@ -206,13 +216,17 @@ EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& 
 #pragma unroll
     for (int d = 0; d < PF; ++d) fr[d] = lds_unit<P>(a + d * 1024);
     f32x16 acc = BIAS ? bias_init(chunk + NF * 1024, h) : zero_acc();
+    f32x16 pend = zero_acc();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         f32x16 nxt = zero_acc();
-        if (BIAS && g + 1 < G) nxt = bias_init(chunk + NF * 1024 + (g + 1) * 128, h);
+        // the next tile's bias is fetched late in this tile, once the pending tile's slices are done: its registers are then
+        // free again (three live accumulator-sized sets would not fit 256 VGPRs)
+        constexpr int BPOS = KG >= 15 ? 13 : KG - 1;
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             const int f = g * KG + kg;
+            if (BIAS && g + 1 < G && kg == BPOS) nxt = bias_init(chunk + NF * 1024 + (g + 1) * 128, h);
             acc = P::mma(fr[f % PF], B(kg), acc);
             if (!(EO_ABL & 2) && f + PF < NF) fr[f % PF] = lds_unit<P>(a + (f + PF) * 1024);
             if (g == 0) {
@@ -220,15 +234,25 @@ EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& 
                 else if (kg < PLAST) ws.pump();
             }
             if (kg == (g == 0 ? MID0 : MIDK)) mid();
+            if (g > 0) {
+#pragma unroll
+                for (int sl = 0; sl < EPI_SLICES; ++sl)
+                    if (slice_pos<KG>(sl) == kg) epi(m0 + g - 1, pend, sl);
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep the window: the scheduler would otherwise re-serialise read/wait/mfma
         }
-        epi(m0 + g, acc);
+        if (g == G - 1) {
+#pragma unroll
+            for (int sl = 0; sl < EPI_SLICES; ++sl) epi(m0 + g, acc, sl);
+        } else {
+            pend = acc;
+        }
         acc = nxt;
     }
 }
 
 // A whole layer: MT m-tiles in MT/G chunks.  NST = slab stores every m-tile's epilogue issues (lower bound, 0 = unknown).
-// `mid` is called once per m-tile a few MFMAs in: the deferred slab flush of the PREVIOUS tile (or a no-op).
+// `mid` is called once per m-tile a few MFMAs in: the slab flush of the oldest staged tile (or a no-op).
 template <class P, int SLOT, int KG, int MT, int G, bool BIAS, int NST = 0, class Mid, class BArr, class Epi>
 EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BArr& B, Epi&& epi) {
     static_assert(MT % G == 0, "G must divide MT");
@@ -237,7 +261,11 @@ EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BA
     for (int mg = 0; mg < MT / G; ++mg) {
         ws.prefetch_next();
         chunk_compute<P, KG, G, BIAS>(ws, lane, h, B, mg * G, epi, mid);
-        ws.template advance<(P::IS_BF16 ? (G - 1) : G) * NST>();
+        // stores younger than the copy (LOWER bound, see WStream::advance).  bf16: one flush (NST = 2 stores) per m-tile once the
+        // staging queue runs: always from the layer's third tile on, and in every tile after the first of a later chunk.  fp32
+        // stores inside the slices, interleaved with the copy: not counted.
+        if (mg == 0) ws.template advance<(P::IS_BF16 ? (G >= 2 ? G - 2 : 0) * NST : 0)>();
+        else ws.template advance<(P::IS_BF16 ? (G - 1) * NST : 0)>();
     }
 }
 
@@ -250,61 +278,59 @@ EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BA
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 
-EO_DEV Units32<PF32> relu_pack_mask(PF32, const f32x16& acc, int mt, uint32_t& m) {
-    f32x16 v;
-    uint32_t bits = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { const bool pos = acc[r] > 0.f; v[r] = pos ? acc[r] : 0.f; bits |= pos ? (1u << r) : 0u; }
-    m = (mt & 1) ? (m | (bits << 16)) : bits;
-    return pack_units(PF32(), v);
-}
-EO_DEV Units32<PBf16> relu_pack_mask(PBf16, const f32x16& acc, int mt, uint32_t& m) {
-    Units32<PBf16> u;
-    uint32_t bits = 0;
+// what one epilogue slice hands on: bf16 one packed word (elements 2s, 2s+1), fp32 the two values
+template <class P> struct Sl;
+template <> struct Sl<PBf16> { uint32_t w; };
+template <> struct Sl<PF32> { float v0, v1; };
+
+// forward: ReLU + mask bits of slice s; `bits` collects the tile's flags (reset by slice 0)
+EO_DEV Sl<PBf16> relu_slice(PBf16, const f32x16& acc, int s, uint32_t& bits) {
+    const s16x2 z = {0, 0};
     const uint32_t ones = 0x00010001u;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u32x4 w;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const s16x2 z = {0, 0};
-            const uint32_t wi = cvt_pk_bf16(acc[8 * s + 2 * i], acc[8 * s + 2 * i + 1]);
-            if (EO_ABL & 4) { w[i] = wi; continue; }
-            const uint32_t x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wi), z));
-            uint32_t t;
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(x), "v"(ones));      // 1 where the element is > 0 (x is >= 0 here)
-            bits = (bits << 1) | t;
-            w[i] = x;
-        }
-        u.u[s] = __builtin_bit_cast(bf16x8, w);
-    }
-    m = (mt & 1) ? (m | (bits << 8)) : bits;
-    return u;
+    const uint32_t wi = cvt_pk_bf16(acc[2 * s], acc[2 * s + 1]);
+    if (EO_ABL & 4) return Sl<PBf16>{wi};
+    const uint32_t x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wi), z));
+    uint32_t t;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(x), "v"(ones));      // 1 where the element is > 0 (x is >= 0 here)
+    bits = s == 0 ? t : ((bits << 1) | t);
+    return Sl<PBf16>{x};
 }
-EO_DEV Units32<PF32> mask_pack(PF32, const f32x16& acc, int mt, uint32_t m) {
-    f32x16 v;
-    const uint32_t bits = m >> ((mt & 1) * 16);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = (bits >> r) & 1u ? acc[r] : 0.f;
-    return pack_units(PF32(), v);
+EO_DEV Sl<PF32> relu_slice(PF32, const f32x16& acc, int s, uint32_t& bits) {
+    const float a0 = acc[2 * s], a1 = acc[2 * s + 1];
+    const bool p0 = a0 > 0.f, p1 = a1 > 0.f;
+    const uint32_t t = (p0 ? (1u << (2 * s)) : 0u) | (p1 ? (2u << (2 * s)) : 0u);
+    bits = s == 0 ? t : (bits | t);
+    return Sl<PF32>{p0 ? a0 : 0.f, p1 ? a1 : 0.f};
 }
-EO_DEV Units32<PBf16> mask_pack(PBf16, const f32x16& acc, int mt, uint32_t m) {
-    Units32<PBf16> u;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u32x4 w;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pos = 8 * (mt & 1) + 7 - (4 * s + i);
-            const uint32_t sel = (m >> pos) & 0x00010001u;
-            const uint32_t wi = cvt_pk_bf16(acc[8 * s + 2 * i], acc[8 * s + 2 * i + 1]);
-            uint32_t r;
-            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(wi), "v"(sel));      // x * {0,1} per element
-            w[i] = r;
-        }
-        u.u[s] = __builtin_bit_cast(bf16x8, w);
-    }
-    return u;
+// after the last slice: fold the tile's flags into the mask dword of its tile PAIR
+EO_DEV void mask_commit(PBf16, int mt, uint32_t bits, uint32_t& m) { m = (mt & 1) ? (m | (bits << 8)) : bits; }
+EO_DEV void mask_commit(PF32, int mt, uint32_t bits, uint32_t& m) { m = (mt & 1) ? (m | (bits << 16)) : bits; }
+// backward: slice s of (mask .* acc)
+EO_DEV Sl<PBf16> mask_slice(PBf16, const f32x16& acc, int s, int mt, uint32_t m) {
+    const int pos = 8 * (mt & 1) + 7 - s;
+    const uint32_t sel = (m >> pos) & 0x00010001u;
+    const uint32_t wi = cvt_pk_bf16(acc[2 * s], acc[2 * s + 1]);
+    uint32_t r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(wi), "v"(sel));      // x * {0,1} per element
+    return Sl<PBf16>{r};
+}
+EO_DEV Sl<PF32> mask_slice(PF32, const f32x16& acc, int s, int mt, uint32_t m) {
+    const uint32_t bits = m >> ((mt & 1) * 16 + 2 * s);
+    const float a0 = acc[2 * s], a1 = acc[2 * s + 1];
+    return Sl<PF32>{(bits & 1u) ? a0 : 0.f, (bits & 2u) ? a1 : 0.f};
+}
+// identity activation
+EO_DEV Sl<PBf16> pack_slice(PBf16, const f32x16& acc, int s) { return Sl<PBf16>{cvt_pk_bf16(acc[2 * s], acc[2 * s + 1])}; }
+EO_DEV Sl<PF32> pack_slice(PF32, const f32x16& acc, int s) { const float a0 = acc[2 * s], a1 = acc[2 * s + 1]; return Sl<PF32>{a0, a1}; }
+// slice s of m-tile mt -> its place in the next layer's B-operand units (same feature order, no permutation)
+EO_DEV void put_slice(PBf16, bf16x8* arr, int mt, int s, const Sl<PBf16>& v) {
+    u32x4 t = __builtin_bit_cast(u32x4, arr[2 * mt + (s >> 2)]);
+    t[s & 3] = v.w;
+    arr[2 * mt + (s >> 2)] = __builtin_bit_cast(bf16x8, t);
+}
+EO_DEV void put_slice(PF32, f32x4* arr, int mt, int s, const Sl<PF32>& v) {
+    arr[4 * mt + (s >> 1)][2 * (s & 1)] = v.v0;
+    arr[4 * mt + (s >> 1)][2 * (s & 1) + 1] = v.v1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,6 +374,7 @@ template <class Map> struct SlabWriter<PF32, Map> : SlabWriterBase {
     static constexpr int FLUSH_STORES = 0;          // tile() stores at once, flush_pending() is a no-op
     int c, h;
     EO_DEV void flush_pending() {}
+    EO_DEV void drain() {}
     EO_DEV void init(void* slab_, int n_tiles, int wave_p0, int lane, uint8_t*) {
         c = lane & 31; h = lane >> 5;
         slab = reinterpret_cast<uint8_t*>(slab_); nt = n_tiles;
@@ -355,16 +382,14 @@ template <class Map> struct SlabWriter<PF32, Map> : SlabWriterBase {
     }
     // lanes c >= 16 hold the samples of the wave's second sample tile: r x 64 B further on inside the block
     EO_DEV int voff(SlabBlk b) const { return (c >> 4) * b.r * SEG_B + 4 * h * SEG_B + (c & 15) * 4; }
-    EO_DEV void tile(int row0, const Units32<PF32>& u) const {
+    // slice s of the 32-row tile starting at row0: accumulator registers 2s, 2s+1
+    EO_DEV void stage(int row0, int s, const Sl<PF32>& v) const {
         const SlabBlk b = Map::block(row0);
         const __amdgpu_buffer_rsrc_t rs = block_rs(b);
         const int vo = voff(b);
         const uint32_t so = block_off(b, row0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float x = u.u[r >> 2][r & 3];      // copy first: __builtin_bit_cast on a vector ELEMENT reads element 0
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, vo, so + acc_row(r, 0) * SEG_B, 0);
-        }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.v0), rs, vo, so + acc_row(2 * s, 0) * SEG_B, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.v1), rs, vo, so + acc_row(2 * s + 1, 0) * SEG_B, 0);
     }
     EO_DEV void elem(int row, float v) const {       // row (+4h through voff)
         const SlabBlk b = Map::block(row);
@@ -373,23 +398,24 @@ template <class Map> struct SlabWriter<PF32, Map> : SlabWriterBase {
 };
 
 template <class Map> struct SlabWriter<PBf16, Map> : SlabWriterBase {
-    // tile() only STAGES the tile in the scratch (4 ds_write_b64); the transposed read-back + the two dwordx4 stores
-    // happen in flush_pending(), which the chain calls a few MFMAs into the NEXT tile so that the LDS round trip
-    // (write -> transposed read -> store) is covered by matrix work instead of stalling between tiles.  Two scratch
-    // buffers per wave alternate.
+    // stage() writes the slices of a tile into a wave-private scratch buffer as they are produced (one ds_write_b64 per two
+    // slices) and queues the tile when its last slice is in; flush_pending() -- called by the chain a few MFMAs into every
+    // m-tile -- takes the OLDEST queued tile back through the transposing read and issues its two dwordx4 stores, so that the
+    // LDS round trip (write -> transposed read -> store) is covered by matrix work.  Two scratch buffers, queue depth 2.
     static constexpr int LDS_BYTES = 8 * 2 * TR_WAVE_B;
     static constexpr int FLUSH_STORES = 2;
-    __amdgpu_buffer_rsrc_t pend_rs; uint32_t pend_off;      // where the staged tile goes (SGPRs)
+    __amdgpu_buffer_rsrc_t qa_rs, qb_rs; uint32_t qa_off, qb_off; int qa_buf, qb_buf;      // queued tiles: a = oldest (SGPRs)
+    int n_pend = 0, buf = 0;
+    uint32_t wprev;
     int voff1, svoff;
     uint8_t* wptr; const uint8_t* rptr;
-    int pend = 0, buf = 0;
     EO_DEV void init(void* slab_, int n_tiles, int wave_p0, int lane, uint8_t* scratch_wave) {
         const int c = lane & 31, h = lane >> 5;
         slab = reinterpret_cast<uint8_t*>(slab_); nt = n_tiles;
         tile0 = __builtin_amdgcn_readfirstlane(wave_p0) / 32;       // wave-uniform: keeps the descriptors in SGPRs (no waterfall loop)
         voff1 = 4 * h * SEG_B + c * 2;
         // scratch write: row = sample c, columns 8q + 4h .. +3 (natural feature order)
-        pend = 0; buf = 0;
+        n_pend = 0; buf = 0;
         wptr = scratch_wave + c * TR_STRIDE + h * 8;
         // transposed read: 16-lane group g = sample octet g; lane i = 4*qq + pp supplies (row 8g + 4t + qq, cols 16*pair +
         // 4pp..+3) and receives feature column 16*pair + i for those four samples.  Store `pair` therefore writes 16
@@ -399,12 +425,12 @@ template <class Map> struct SlabWriter<PBf16, Map> : SlabWriterBase {
         svoff = i * SEG_B + g * 16;
     }
     EO_DEV void flush_pending() {
-        if (!pend) return;
+        if (!n_pend) return;
         // Inline asm on purpose: for the ds_read_tr intrinsic the compiler's wait-count pass assumes the read may alias the
         // in-flight LDS-DMA weight prefetch and puts s_waitcnt vmcnt(0) in front of it -- a full drain of the prefetch AND of
         // the previous tile's slab stores (an HBM write round trip) once per m-tile.  The scratch is wave-private and never
         // written by LDS-DMA.
-        const uint32_t ra = (uint32_t)(uintptr_t)(rptr + (buf ^ 1) * TR_WAVE_B);        // low 32 bits of a generic LDS address = LDS offset
+        const uint32_t ra = (uint32_t)(uintptr_t)(rptr + qa_buf * TR_WAVE_B);        // low 32 bits of a generic LDS address = LDS offset
         u32x2 a0, b0, a1, b1;
         asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
                      "ds_read_b64_tr_b16 %1, %4 offset:288\n\t"
@@ -413,27 +439,29 @@ template <class Map> struct SlabWriter<PBf16, Map> : SlabWriterBase {
                      "s_waitcnt lgkmcnt(0)"
                      : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1) : "v"(ra) : "memory");
         static_assert(4 * TR_STRIDE == 288, "asm offsets");
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], b0[0], b0[1]}, pend_rs, svoff, pend_off, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a1[0], a1[1], b1[0], b1[1]}, pend_rs, svoff, pend_off + 16 * SEG_B, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], b0[0], b0[1]}, qa_rs, svoff, qa_off, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a1[0], a1[1], b1[0], b1[1]}, qa_rs, svoff, qa_off + 16 * SEG_B, 0);
         // A 128-bit store reads its data VGPRs a couple of cycles after issue.  The compiler only guards that window when the
         // store has no SGPR soffset; measured on gfx950 it exists with one too (a VALU write to the first data register right
         // behind the store reached memory instead of the tile: garbage in rows 28..31 of a 32x32 tile).
         asm volatile("s_nop 1" ::: "memory");
-        pend = 0;
+        qa_rs = qb_rs; qa_off = qb_off; qa_buf = qb_buf;
+        --n_pend;
     }
-    EO_DEV void tile(int row0, const Units32<PBf16>& u) {
-        flush_pending();                                             // normally already done by the chain (no-op)
-        const u32x4 w0 = __builtin_bit_cast(u32x4, u.u[0]), w1 = __builtin_bit_cast(u32x4, u.u[1]);
-        uint8_t* wp = wptr + buf * TR_WAVE_B;
-        *reinterpret_cast<u32x2*>(wp + 0) = u32x2{w0[0], w0[1]};
-        *reinterpret_cast<u32x2*>(wp + 16) = u32x2{w0[2], w0[3]};
-        *reinterpret_cast<u32x2*>(wp + 32) = u32x2{w1[0], w1[1]};
-        *reinterpret_cast<u32x2*>(wp + 48) = u32x2{w1[2], w1[3]};
-        const SlabBlk b = Map::block(row0);
-        pend_rs = block_rs(b); pend_off = block_off(b, row0);
-        pend = 1;
-        buf ^= 1;
+    // slice s (one packed word = accumulator registers 2s, 2s+1) of the 32-row tile starting at row0
+    EO_DEV void stage(int row0, int s, const Sl<PBf16>& v) {
+        if (s == 0 && n_pend == 2) flush_pending();                 // both buffers queued: not in the regular schedule
+        if (s & 1) *reinterpret_cast<u32x2*>(wptr + buf * TR_WAVE_B + 16 * (s >> 1)) = u32x2{wprev, v.w};
+        else wprev = v.w;
+        if (s == EPI_SLICES - 1) {
+            const SlabBlk b = Map::block(row0);
+            if (n_pend == 0) { qa_rs = block_rs(b); qa_off = block_off(b, row0); qa_buf = buf; }
+            else { qb_rs = block_rs(b); qb_off = block_off(b, row0); qb_buf = buf; }
+            ++n_pend;
+            buf ^= 1;
+        }
     }
+    EO_DEV void drain() { flush_pending(); flush_pending(); }
     EO_DEV void elem(int row, float v) const {
         const SlabBlk b = Map::block(row);
         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), block_rs(b), voff1, block_off(b, row), 0);

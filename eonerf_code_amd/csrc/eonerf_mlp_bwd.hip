@@ -52,11 +52,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             else { const u32x2 v = *reinterpret_cast<const u32x2*>(mp); mb[0] = v[0]; mb[1] = v[1]; }
         };
         // dX tile -> (optional ReLU mask) -> units of the next backward layer + feature-major save for the wgrad GEMM
-        auto grad_epi = [&](auto& dst, int grd_row, bool masked, int mt, const f32x16& accv) {
-            const Units32<P> u = masked ? mask_pack(P(), accv, mt, mb[mt >> 1]) : pack_units(P(), accv);
-#pragma unroll
-            for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
-            sw.tile(grd_row + 32 * mt, u);
+        // (slice s of the epilogue of m-tile mt, see chunk_compute)
+        auto grad_epi = [&](U* dst, int grd_row, bool masked, int mt, const f32x16& accv, int s) {
+            const Sl<P> v = masked ? mask_slice(P(), accv, s, mt, mb[mt >> 1]) : pack_slice(P(), accv, s);
+            put_slice(P(), dst, mt, s, v);
+            sw.stage(grd_row + 32 * mt, s, v);
         };
 
         // ---------------- output heads: activation derivatives from the saved forward outputs ----------------
@@ -91,63 +91,63 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 const U u_tr = small_unit<P>(dtr, h);
                 load_mask(12, 2);
                 run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_tr; },
-                    [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v); });
+                    [&](int mt, const f32x16& v, int s) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v, s); });
                 load_mask(11, 2);
                 run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
-                    [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v); });
+                    [&](int mt, const f32x16& v, int s) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v, s); });
                 load_mask(10, 2);
                 run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
-                    [&](int mt, const f32x16& v) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v); });
+                    [&](int mt, const f32x16& v, int s) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v, s); });
                 load_mask(9, 2);
                 run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
-                    [&](int mt, const f32x16& v) { grad_epi(TB, GRD_ROW_T1, true, mt, v); });        // TB = dY_T1
+                    [&](int mt, const f32x16& v, int s) { grad_epi(TB, GRD_ROW_T1, true, mt, v, s); });        // TB = dY_T1
             }
             // ---- albedo head backwards: albedo_pre -> A1 ----
             const U u_al = small_unit<P>(dalb, h);
             load_mask(8, 2);
             run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_al; },
-                [&](int mt, const f32x16& v) { grad_epi(DA1, GRD_ROW_A1, true, mt, v); });
+                [&](int mt, const f32x16& v, int s) { grad_epi(DA1, GRD_ROW_A1, true, mt, v, s); });
             if constexpr (TRANS) {
                 // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
                 run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, mid, lane, h,
                     [&](int kg) { return kg < QKG ? DA1[kg < QKG ? kg : 0] : TB[kg >= QKG ? kg - QKG : 0]; },
-                    [&](int mt, const f32x16& v) {
-                        if (mt < 8) { grad_epi(N, GRD_ROW_BOTT, false, mt, v); return; }
-                        if (h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
+                    [&](int mt, const f32x16& v, int s) {
+                        if (mt < 8) { grad_epi(N, GRD_ROW_BOTT, false, mt, v, s); return; }
+                        if (s == 0 && h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
                     });
             } else {
                 // ---- dY_A1 -> d bottleneck ----
                 run_layer<P, SLOT, QKG, 8, FwdG<P, QKG, 8>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return DA1[kg]; },
-                    [&](int mt, const f32x16& v) { grad_epi(N, GRD_ROW_BOTT, false, mt, v); });
+                    [&](int mt, const f32x16& v, int s) { grad_epi(N, GRD_ROW_BOTT, false, mt, v, s); });
             }
             // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
             run_layer<P, SLOT, HKG + 1, 8, FwdG<P, HKG + 1, 8>::G, false, NST>(ws, mid, lane, h,
                 [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
-                [&](int mt, const f32x16& v) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v); });
+                [&](int mt, const f32x16& v, int s) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v, s); });
         } else {
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
             run_layer<P, SLOT, 1, 8, FwdG<P, 1, 8>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_sg; },
-                [&](int mt, const f32x16& v) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v); });
+                [&](int mt, const f32x16& v, int s) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v, s); });
         }
 
         // ---------------- trunk backwards: dY_l -> dX_l -> mask(layer l-1) -> dY_{l-1} ----------------
         f32x16 denc[2];
-        auto trunk_step = [&](auto& src, auto& dst, int l) {      // consumes dY_l, produces dY_{l-1}
+        auto trunk_step = [&](U* src, U* dst, int l) {      // consumes dY_l, produces dY_{l-1}
             load_mask(l - 1, 4);
             run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
-                [&](int mt, const f32x16& v) { grad_epi(dst, GRD_ROW_Y0 + (l - 1) * 256, true, mt, v); });
+                [&](int mt, const f32x16& v, int s) { grad_epi(dst, GRD_ROW_Y0 + (l - 1) * 256, true, mt, v, s); });
         };
         trunk_step(D, N, 7);
         trunk_step(N, D, 6);
         // layer 5 consumed [h, enc]: rows 0..255 go on down the trunk, rows 256..319 are d enc (skip path)
         load_mask(4, 4);
         run_layer<P, SLOT, HKG, IG ? 10 : 8, FwdG<P, HKG, IG ? 10 : 8>::G, false>(ws, mid, lane, h, [&](int kg) { return D[kg]; },
-            [&](int mt, const f32x16& v) {
-                if (mt < 8) { grad_epi(N, GRD_ROW_Y0 + 4 * 256, true, mt, v); return; }
-                if constexpr (IG) denc[mt == 8 ? 0 : 1] = v;
+            [&](int mt, const f32x16& v, int s) {
+                if (mt < 8) { grad_epi(N, GRD_ROW_Y0 + 4 * 256, true, mt, v, s); return; }
+                if constexpr (IG) { if (s == 0) denc[mt == 8 ? 0 : 1] = v; }
             });
         trunk_step(N, D, 4);
         trunk_step(D, N, 3);
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
 
         if constexpr (IG) {
             run_layer<P, SLOT, HKG, 2, FwdG<P, HKG, 2>::G, false>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
-                [&](int mt, const f32x16& v) {
+                [&](int mt, const f32x16& v, int s) {
+                    if (s != 0) return;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) denc[mt == 0 ? 0 : 1][r] += v[r];
                 });
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 a.g_pos[p] = gp[0]; a.g_pos[(size_t)a.p_pad + p] = gp[1]; a.g_pos[2 * (size_t)a.p_pad + p] = gp[2];
             }
         }
-        sw.flush_pending();
+        sw.drain();
     }
 }
 

@@ -78,19 +78,21 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         auto mid = [&]() { if constexpr (TRAIN) sw.flush_pending(); };
         U H[HKG], N[HKG];
         uint32_t mbits[4];
+        uint32_t tbits = 0;      // ReLU flags of the tile whose epilogue is in progress
 
         // ---------------- trunk ----------------
-        auto relu_epi = [&](auto& dst, int act_row, int mt, const f32x16& accv) {
-            const Units32<P> u = relu_pack_mask(P(), accv, mt, mbits[mt >> 1]);
-#pragma unroll
-            for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
-            if constexpr (TRAIN) sw.tile(act_row + 32 * mt, u);
+        // slice s of the epilogue of m-tile mt (see chunk_compute): ReLU, mask flags, next layer's operand, slab staging
+        auto relu_epi = [&](U* dst, int act_row, int mt, const f32x16& accv, int s) {
+            const Sl<P> v = relu_slice(P(), accv, s, tbits);
+            put_slice(P(), dst, mt, s, v);
+            if (s == EPI_SLICES - 1) mask_commit(P(), mt, tbits, mbits[mt >> 1]);
+            if constexpr (TRAIN) sw.stage(act_row + 32 * mt, s, v);
         };
-        auto relu_epi_t = [&](auto& dst, int act_row, int mt, const f32x16& accv) {      // transient head layers
-            const Units32<P> u = relu_pack_mask(P(), accv, mt, mbits[mt >> 1]);
-#pragma unroll
-            for (int s = 0; s < P::KG32; ++s) dst[mt * P::KG32 + s] = u.u[s];
-            if constexpr (TSAVE) sw.tile(act_row + 32 * mt, u);
+        auto relu_epi_t = [&](U* dst, int act_row, int mt, const f32x16& accv, int s) {      // transient head layers
+            const Sl<P> v = relu_slice(P(), accv, s, tbits);
+            put_slice(P(), dst, mt, s, v);
+            if (s == EPI_SLICES - 1) mask_commit(P(), mt, tbits, mbits[mt >> 1]);
+            if constexpr (TSAVE) sw.stage(act_row + 32 * mt, s, v);
         };
         auto save_mask = [&](int mask_slot, int nwords) {
             if constexpr (TRAIN) {
@@ -99,15 +101,15 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                 else *reinterpret_cast<u32x2*>(mp) = u32x2{mbits[0], mbits[1]};
             }
         };
-        auto plain_layer = [&](auto& src, auto& dst, int l) {
+        auto plain_layer = [&](U* src, U* dst, int l) {
             run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
-                [&](int mt, const f32x16& v) { relu_epi(dst, ACT_ROW_X1 + 256 * l, mt, v); });
+                [&](int mt, const f32x16& v, int s) { relu_epi(dst, ACT_ROW_X1 + 256 * l, mt, v, s); });
             save_mask(l, 4);
         };
 
         // layer 0: enc(64) -> 256
         run_layer<P, SLOT, EKG, 8, FwdG<P, EKG, 8>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return E.u[kg]; },
-            [&](int mt, const f32x16& v) { relu_epi(H, ACT_ROW_X1, mt, v); });
+            [&](int mt, const f32x16& v, int s) { relu_epi(H, ACT_ROW_X1, mt, v, s); });
         save_mask(0, 4);
         plain_layer(H, N, 1);
         plain_layer(N, H, 2);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         // layer 5 consumes [h, enc] (skip-concat after layer 4, mlp.py:92-97)
         run_layer<P, SLOT, HKG + EKG, 8, FwdG<P, HKG + EKG, 8>::G, true, NST>(ws, mid, lane, h,
             [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : E.u[kg >= HKG ? kg - HKG : 0]; },
-            [&](int mt, const f32x16& v) { relu_epi(N, ACT_ROW_X1 + 256 * 5, mt, v); });
+            [&](int mt, const f32x16& v, int s) { relu_epi(N, ACT_ROW_X1 + 256 * 5, mt, v, s); });
         save_mask(5, 4);
         plain_layer(N, H, 6);
         plain_layer(H, N, 7);
@@ -125,28 +127,27 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         float sigma_raw = 0.f;
         if constexpr (!FULL) {
             run_layer<P, SLOT, HKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
-                [&](int, const f32x16& v) { sigma_raw = v[0]; });
+                [&](int, const f32x16& v, int s) { if (s == 0) sigma_raw = v[0]; });
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
         } else {
             // m-tile 0 = sigma row, m-tiles 1..8 = bottleneck (identity activation) -> H
             run_layer<P, SLOT, HKG, 9, FwdG<P, HKG, 9>::G, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
-                [&](int mt, const f32x16& v) {
-                    if (mt == 0) { sigma_raw = v[0]; return; }
-                    Units32<P> u = pack_units(P(), v);
-#pragma unroll
-                    for (int s = 0; s < P::KG32; ++s) H[(mt - 1) * P::KG32 + s] = u.u[s];
-                    if constexpr (TRAIN) sw.tile(ACT_ROW_BOTT + 32 * (mt - 1), u);
+                [&](int mt, const f32x16& v, int s) {
+                    if (mt == 0) { if (s == 0) sigma_raw = v[0]; return; }
+                    const Sl<P> x = pack_slice(P(), v, s);
+                    put_slice(P(), H, mt - 1, s, x);
+                    if constexpr (TRAIN) sw.stage(ACT_ROW_BOTT + 32 * (mt - 1), s, x);
                 });
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
 
             // ---------------- albedo head: 256 -> 128 (ReLU) -> 3 (Sigmoid) ----------------
             U A1[QKG];
             run_layer<P, SLOT, HKG, 4, FwdG<P, HKG, 4>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return H[kg]; },
-                [&](int mt, const f32x16& v) { relu_epi(A1, ACT_ROW_A1, mt, v); });
+                [&](int mt, const f32x16& v, int s) { relu_epi(A1, ACT_ROW_A1, mt, v, s); });
             save_mask(8, 2);
             run_layer<P, SLOT, QKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return A1[kg]; },
-                [&](int, const f32x16& v) {
-                    if (h == 0 && live) {
+                [&](int, const f32x16& v, int s) {
+                    if (s == 0 && h == 0 && live) {
                         a.albedo[p] = sigmoid_f(v[0]);
                         a.albedo[(size_t)a.p_pad + p] = sigmoid_f(v[1]);
                         a.albedo[2 * (size_t)a.p_pad + p] = sigmoid_f(v[2]);
@@ -168,23 +169,23 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             U T1[QKG], T2[QKG];
             run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true, NST_T>(ws, mid, lane, h,
                 [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : EMB; },
-                [&](int mt, const f32x16& v) { relu_epi_t(T1, ACT_ROW_T1, mt, v); });
+                [&](int mt, const f32x16& v, int s) { relu_epi_t(T1, ACT_ROW_T1, mt, v, s); });
             if constexpr (TSAVE) save_mask(9, 2);
             run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },
-                [&](int mt, const f32x16& v) { relu_epi_t(T2, ACT_ROW_T1 + 128, mt, v); });
+                [&](int mt, const f32x16& v, int s) { relu_epi_t(T2, ACT_ROW_T1 + 128, mt, v, s); });
             if constexpr (TSAVE) save_mask(10, 2);
             run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T2[kg]; },
-                [&](int mt, const f32x16& v) { relu_epi_t(T1, ACT_ROW_T1 + 256, mt, v); });
+                [&](int mt, const f32x16& v, int s) { relu_epi_t(T1, ACT_ROW_T1 + 256, mt, v, s); });
             if constexpr (TSAVE) save_mask(11, 2);
             run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },
-                [&](int mt, const f32x16& v) { relu_epi_t(T2, ACT_ROW_T1 + 384, mt, v); });
+                [&](int mt, const f32x16& v, int s) { relu_epi_t(T2, ACT_ROW_T1 + 384, mt, v, s); });
             if constexpr (TSAVE) save_mask(12, 2);
             run_layer<P, SLOT, QKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return T2[kg]; },
-                [&](int, const f32x16& v) {
-                    if (h == 0 && live) { a.ts[p] = sigmoid_f(v[0]); a.tb[p] = softplus_f(v[1]); }
+                [&](int, const f32x16& v, int s) {
+                    if (s == 0 && h == 0 && live) { a.ts[p] = sigmoid_f(v[0]); a.tb[p] = softplus_f(v[1]); }
                 });
         }
-        if constexpr (TRAIN) sw.flush_pending();
+        if constexpr (TRAIN) sw.drain();
     }
 }
 
