@@ -72,8 +72,8 @@ namespace {
 
 int upload(DevStream& d, const PackedStream& s) {
     d.bytes = s.bytes; d.n_chunks = (int)s.chunks.size(); d.n16 = (int)s.e16.size(); d.n32 = (int)s.e32.size();
-    HIP_TRY(hipMalloc(&d.data, s.bytes));
-    HIP_TRY(hipMemset(d.data, 0, s.bytes));
+    HIP_TRY(hipMalloc(&d.data, s.bytes + 1024));      // + slack: the chain kernels copy whole 1-KiB pieces (WStream::round)
+    HIP_TRY(hipMemset(d.data, 0, s.bytes + 1024));
     HIP_TRY(hipMalloc(&d.chunks, s.chunks.size() * sizeof(ChunkDesc)));
     HIP_TRY(hipMemcpy(d.chunks, s.chunks.data(), s.chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
     if (d.n16) {

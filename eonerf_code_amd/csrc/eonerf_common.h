@@ -108,13 +108,14 @@ EO_DEV Units32<PF32> pack_units(PF32, const f32x16& v) {
 // ------------------------------------------------------------------------------------------------
 struct ChunkDesc { uint32_t off, bytes; };
 template <class P, int SLOT_BYTES> struct WStream {
+    static_assert(SLOT_BYTES % 1024 == 0, "copy rounds are whole 1-KiB pieces");
     const uint8_t* g;            // packed stream (global)
     const ChunkDesc* tab;        // chunk table (global, read through the scalar cache)
     uint8_t* lds;                // 2 * SLOT_BYTES
     int n_chunks;
     int q;                       // index (in tab) of the chunk currently resident / being consumed
     uint32_t par;                // slot parity of the resident chunk
-    int tid;
+    int wave_b, lane_b;          // byte offsets of this wave's 1-KiB piece of a copy round (SGPR) and of the lane inside it
 
     // descriptor of chunk qi.  Constant address space: the table is read-only for the whole launch, so this is an s_load
     // (a generic-pointer load becomes a VECTOR load + s_waitcnt vmcnt(0), which drains every outstanding slab store).
@@ -126,12 +127,15 @@ template <class P, int SLOT_BYTES> struct WStream {
     static constexpr uint32_t ROUND_B = P::NT * 16;
     static constexpr int MAX_ROUNDS = (SLOT_BYTES + ROUND_B - 1) / ROUND_B;
     uint32_t pf_off, pf_bytes, pf_base, pf_slot;     // prefetch in progress (wave-uniform)
+    // One round = one 1-KiB LDS-DMA piece per wave.  Everything but the lane offset is wave-uniform (SGPR address, M0 from
+    // scalar arithmetic, a scalar branch for the tail): a round costs the wave a handful of scalar instructions besides the
+    // DMA itself.  The tail piece is copied whole (chunks are padded to 1 KiB by rounding the copy up: the slot is a multiple
+    // of 1 KiB and the stream allocation carries 1 KiB of slack).
     EO_DEV void round() {
-        const uint32_t o = pf_base + tid * 16;
+        const uint32_t o = pf_base + wave_b;
         if (o < pf_bytes)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + pf_off + o),
-                                             (__attribute__((address_space(3))) void*)(lds + pf_slot * SLOT_BYTES + pf_base + (tid & ~63) * 16),
-                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + pf_off + o + lane_b),
+                                             (__attribute__((address_space(3))) void*)(lds + pf_slot * SLOT_BYTES + o), 16, 0, 0);
         pf_base += ROUND_B;
     }
     // first chunk of the launch

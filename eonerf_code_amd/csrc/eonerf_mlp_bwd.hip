@@ -34,7 +34,8 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     const int n_pts = *a.n_pts;
 
     WStream<P, SLOT> ws;
-    ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks; ws.tid = tid;
+    ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks;
+    ws.wave_b = __builtin_amdgcn_readfirstlane(wave) * 1024; ws.lane_b = lane * 16;
     if ((int)blockIdx.x * P::TILE >= n_pts) return;
     ws.start();
 
