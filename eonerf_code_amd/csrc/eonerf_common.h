@@ -23,10 +23,15 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define EO_DEV __device__ __forceinline__
 
 // Diagnostic builds only (scripts/ablate.sh): EO_ABL bit 0 drops the per-chunk s_barrier, bit 1 the A-operand LDS re-reads,
-// bit 2 the ReLU/mask work of the epilogues, bit 3 the weight prefetch.  Results are WRONG with any bit set; the shipped
+// bit 2 the ReLU/mask work of the epilogues, bit 3 the weight prefetch, bit 4 the HBM traffic of the slab stores.  Results are WRONG with any bit set; the shipped
 // library is built with EO_ABL == 0.
 #ifndef EO_ABL
 #define EO_ABL 0
+#endif
+// EO_STAMP (diagnostic builds only, scripts/stamp.sh): s_memtime stamps around the waits of the chain kernels, summed per wave
+// into eo_stamps[] (total, copy wait, barrier wait, flush wait, waves) and read back by eonerf_debug_read().
+#ifdef EO_STAMP
+#define EO_T() __builtin_amdgcn_s_memtime()
 #endif
 
 // row of the 32x32 accumulator tile held in register r by a lane of half h (cdna guide, C/D map)
@@ -163,8 +168,22 @@ template <class P, int SLOT_BYTES> struct WStream {
     // at most YOUNGER operations are outstanding guarantees the prefetch has landed without draining the stores
     // (a full vmcnt(0) here serialises every chunk behind an HBM write round trip).  Raw s_barrier: __syncthreads()
     // would add its own vmcnt(0).
+#ifdef EO_STAMP
+    unsigned long long t_wait = 0, t_bar = 0, t_flush = 0;
+#endif
     template <int YOUNGER> EO_DEV void advance() {
         __builtin_amdgcn_sched_barrier(0);
+#ifdef EO_STAMP
+        const unsigned long long t0 = EO_T();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER > 63 ? 63 : YOUNGER) : "memory");
+        const unsigned long long t1 = EO_T();
+        asm volatile("s_barrier" ::: "memory");
+        const unsigned long long t2 = EO_T();
+        t_wait += t1 - t0; t_bar += t2 - t1;
+        q = q + 1; if (q == n_chunks) q = 0;
+        par ^= 1;
+        return;
+#endif
         if (EO_ABL & 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER > 63 ? 63 : YOUNGER) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(YOUNGER > 63 ? 63 : YOUNGER) : "memory");
         q = q + 1; if (q == n_chunks) q = 0;
@@ -237,7 +256,25 @@ EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& 
                 if (kg == PLAST) ws.pump_rest();
                 else if (kg < PLAST) ws.pump();
             }
-            if (kg == (g == 0 ? MID0 : MIDK)) mid();
+            // slab flush of the oldest staged tile in two phases: the transposing LDS reads here, the stores FDIST MFMAs later
+            // behind a COUNTED lgkmcnt (only the A-unit reads issued in between may still be outstanding) -- a combined
+            // read + s_waitcnt lgkmcnt(0) + store stalled the wave for a full LDS round trip once per m-tile
+            {
+                constexpr int FDIST = KG >= 8 ? 2 : 0;
+                const int fk = g == 0 ? MID0 : MIDK;
+                if (FDIST == 0) { if (kg == fk) mid.flush(); }
+                else {
+                    if (kg == fk) mid.flush_issue();
+                    if (kg == fk + FDIST) {
+                        // A-unit reads issued since (iterations fk+1 .. fk+FDIST): one each while the window still refills
+                        const int f1 = g * KG + fk + 1, f2 = g * KG + fk + 2;
+                        const int n_younger = ((f1 + PF < NF) ? 1 : 0) + ((f2 + PF < NF) ? 1 : 0);
+                        if (n_younger == 2) mid.template flush_store<2>();
+                        else if (n_younger == 1) mid.template flush_store<1>();
+                        else mid.template flush_store<0>();
+                    }
+                }
+            }
             if (g > 0) {
 #pragma unroll
                 for (int sl = 0; sl < EPI_SLICES; ++sl)
@@ -365,12 +402,19 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 template <class P, class Map> struct SlabWriter;
 
+// the `mid` argument of run_layer for kernels that save nothing
+struct NoSlab {
+    EO_DEV void flush() {}
+    EO_DEV void flush_issue() {}
+    template <int N> EO_DEV void flush_store() {}
+};
+
 struct SlabWriterBase {
     uint8_t* slab; uint32_t nt, tile0;           // wave-uniform: slab base, sample tiles of the slab, this wave's first sample tile
     EO_DEV __amdgpu_buffer_rsrc_t block_rs(SlabBlk b) const {      // descriptor of a whole block (SGPRs)
         return __builtin_amdgcn_make_buffer_rsrc(slab + (size_t)b.s * nt * SEG_B, 0, b.r * nt * SEG_B, 0x00020000);
     }
-    EO_DEV uint32_t block_off(SlabBlk b, int row) const { return (tile0 * b.r + (row - b.s)) * SEG_B; }
+    EO_DEV uint32_t block_off(SlabBlk b, int row) const { return (((EO_ABL & 16) ? 0 : tile0) * b.r + (row - b.s)) * SEG_B; }   // EO_ABL 16: every wave writes sample tile 0 (stores stay in L2)
 };
 
 template <class Map> struct SlabWriter<PF32, Map> : SlabWriterBase {
@@ -378,6 +422,9 @@ template <class Map> struct SlabWriter<PF32, Map> : SlabWriterBase {
     static constexpr int FLUSH_STORES = 0;          // tile() stores at once, flush_pending() is a no-op
     int c, h;
     EO_DEV void flush_pending() {}
+    EO_DEV void flush() {}
+    EO_DEV void flush_issue() {}
+    template <int N> EO_DEV void flush_store() {}
     EO_DEV void drain() {}
     EO_DEV void init(void* slab_, int n_tiles, int wave_p0, int lane, uint8_t*) {
         c = lane & 31; h = lane >> 5;
@@ -428,33 +475,42 @@ template <class Map> struct SlabWriter<PBf16, Map> : SlabWriterBase {
         rptr = scratch_wave + (8 * g + qq) * TR_STRIDE + pp * 8;
         svoff = i * SEG_B + g * 16;
     }
-    EO_DEV void flush_pending() {
-        if (!n_pend) return;
-        // Inline asm on purpose: for the ds_read_tr intrinsic the compiler's wait-count pass assumes the read may alias the
-        // in-flight LDS-DMA weight prefetch and puts s_waitcnt vmcnt(0) in front of it -- a full drain of the prefetch AND of
-        // the previous tile's slab stores (an HBM write round trip) once per m-tile.  The scratch is wave-private and never
-        // written by LDS-DMA.
+    // Inline asm on purpose: for the ds_read_tr intrinsic the compiler's wait-count pass assumes the read may alias the
+    // in-flight LDS-DMA weight prefetch and puts s_waitcnt vmcnt(0) in front of it -- a full drain of the prefetch AND of
+    // the previous tile's slab stores (an HBM write round trip) once per m-tile.  The scratch is wave-private and never
+    // written by LDS-DMA.  The four result registers stay untouched between the two phases (tied through "+v").
+    u32x2 fa0, fb0, fa1, fb1;
+    int inflight = 0;
+    EO_DEV void flush_issue() {
+        if (!n_pend || inflight) return;
         const uint32_t ra = (uint32_t)(uintptr_t)(rptr + qa_buf * TR_WAVE_B);        // low 32 bits of a generic LDS address = LDS offset
-        u32x2 a0, b0, a1, b1;
         asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
                      "ds_read_b64_tr_b16 %1, %4 offset:288\n\t"
                      "ds_read_b64_tr_b16 %2, %4 offset:32\n\t"
-                     "ds_read_b64_tr_b16 %3, %4 offset:320\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1) : "v"(ra) : "memory");
+                     "ds_read_b64_tr_b16 %3, %4 offset:320"
+                     : "=&v"(fa0), "=&v"(fb0), "=&v"(fa1), "=&v"(fb1) : "v"(ra) : "memory");
         static_assert(4 * TR_STRIDE == 288, "asm offsets");
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], b0[0], b0[1]}, qa_rs, svoff, qa_off, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a1[0], a1[1], b1[0], b1[1]}, qa_rs, svoff, qa_off + 16 * SEG_B, 0);
+        inflight = 1;
+    }
+    // N = LDS operations issued after flush_issue() that may still be outstanding (LDS returns in order)
+    template <int N> EO_DEV void flush_store() {
+        if (!inflight) return;
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa0), "+v"(fb0), "+v"(fa1), "+v"(fb1) : "n"(N) : "memory");
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{fa0[0], fa0[1], fb0[0], fb0[1]}, qa_rs, svoff, qa_off, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{fa1[0], fa1[1], fb1[0], fb1[1]}, qa_rs, svoff, qa_off + 16 * SEG_B, 0);
         // A 128-bit store reads its data VGPRs a couple of cycles after issue.  The compiler only guards that window when the
         // store has no SGPR soffset; measured on gfx950 it exists with one too (a VALU write to the first data register right
         // behind the store reached memory instead of the tile: garbage in rows 28..31 of a 32x32 tile).
         asm volatile("s_nop 1" ::: "memory");
         qa_rs = qb_rs; qa_off = qb_off; qa_buf = qb_buf;
         --n_pend;
+        inflight = 0;
     }
+    EO_DEV void flush() { flush_issue(); flush_store<0>(); }
+    EO_DEV void flush_pending() { flush(); }
     // slice s (one packed word = accumulator registers 2s, 2s+1) of the 32-row tile starting at row0
     EO_DEV void stage(int row0, int s, const Sl<PBf16>& v) {
-        if (s == 0 && n_pend == 2) flush_pending();                 // both buffers queued: not in the regular schedule
+        if (s == 0 && n_pend == 2) { flush_store<0>(); flush(); }   // both buffers queued: not in the regular schedule
         if (s & 1) *reinterpret_cast<u32x2*>(wptr + buf * TR_WAVE_B + 16 * (s >> 1)) = u32x2{wprev, v.w};
         else wprev = v.w;
         if (s == EPI_SLICES - 1) {
@@ -465,7 +521,7 @@ template <class Map> struct SlabWriter<PBf16, Map> : SlabWriterBase {
             buf ^= 1;
         }
     }
-    EO_DEV void drain() { flush_pending(); flush_pending(); }
+    EO_DEV void drain() { flush_store<0>(); flush(); flush(); }
     EO_DEV void elem(int row, float v) const {
         const SlabBlk b = Map::block(row);
         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), block_rs(b), voff1, block_off(b, row), 0);

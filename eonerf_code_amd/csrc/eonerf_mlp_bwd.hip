@@ -8,6 +8,9 @@
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
 
+#ifdef EO_STAMP
+__device__ unsigned long long eo_stamps_bwd[8];
+#endif
 namespace {
 
 // k-group whose first (up to 4) features carry `v` on the h==0 lanes (rows 0..3 of a 32-row tile), zero elsewhere
@@ -38,6 +41,9 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     ws.wave_b = __builtin_amdgcn_readfirstlane(wave) * 1024; ws.lane_b = lane * 16;
     if ((int)blockIdx.x * P::TILE >= n_pts) return;
     ws.start();
+#ifdef EO_STAMP
+    const unsigned long long t_begin = EO_T();
+#endif
 
     for (int tile = blockIdx.x; tile * P::TILE < n_pts; tile += gridDim.x) {
         const int p = tile * P::TILE + wave * 32 + c;
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         SlabWriter<P, GrdMap> sw;                                                   // this wave's sample tile(s) of the gradient slab
         sw.init(a.grd, a.p_pad / Slab<P>::TSAMP, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
         uint32_t mb[4];
-        auto mid = [&]() { sw.flush_pending(); };
+        auto& mid = sw;          // run_layer's slab-flush hooks
 
         auto load_mask = [&](int slot, int nwords) {
             const uint32_t* mp = a.masks + ((size_t)slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4;
@@ -192,6 +198,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         }
         sw.drain();
     }
+#ifdef EO_STAMP
+    if (lane == 0) {
+        atomicAdd(&eo_stamps_bwd[0], EO_T() - t_begin); atomicAdd(&eo_stamps_bwd[1], ws.t_wait); atomicAdd(&eo_stamps_bwd[2], ws.t_bar); atomicAdd(&eo_stamps_bwd[3], ws.t_flush); atomicAdd(&eo_stamps_bwd[4], 1ull);
+    }
+#endif
 }
 
 template <class P, bool FULL, bool IG, bool TRANS>
@@ -221,3 +232,11 @@ hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool inp
     if (full == input_grad) return hipErrorInvalidValue;
     return bf16 ? dispatch<PBf16>(a, full, transient, grid, st) : dispatch<PF32>(a, full, transient, grid, st);
 }
+
+#ifdef EO_STAMP
+extern "C" void eonerf_debug_read_bwd(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(eo_stamps_bwd), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(eo_stamps_bwd), z, sizeof(z));
+}
+#endif

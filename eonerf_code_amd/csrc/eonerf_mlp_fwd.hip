@@ -8,6 +8,9 @@
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
 
+#ifdef EO_STAMP
+__device__ unsigned long long eo_stamps_fwd[8];
+#endif
 namespace {
 
 template <class P> struct EncUnits { typename P::U u[ENC_SLOTS / P::KF]; };
@@ -61,6 +64,9 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
     ws.wave_b = __builtin_amdgcn_readfirstlane(wave) * 1024; ws.lane_b = lane * 16;
     if ((int)blockIdx.x * P::TILE >= n_pts) return;      // uniform per workgroup
     ws.start();
+#ifdef EO_STAMP
+    const unsigned long long t_begin = EO_T();
+#endif
 
     for (int tile = blockIdx.x; tile * P::TILE < n_pts; tile += gridDim.x) {
         const int p = tile * P::TILE + wave * 32 + c;          // this lane's sample (both halves share it)
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                 for (int e = 0; e < P::NE; ++e) sw.elem(ACT_ROW_ENC + P::feat(kg, 0, e), (float)E.u[kg][e]);
         }
 
-        auto mid = [&]() { if constexpr (TRAIN) sw.flush_pending(); };
+        auto& mid = sw;          // run_layer's slab-flush hooks
         U H[HKG], N[HKG];
         uint32_t mbits[4];
         uint32_t tbits = 0;      // ReLU flags of the tile whose epilogue is in progress
@@ -188,6 +194,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         }
         if constexpr (TRAIN) sw.drain();
     }
+#ifdef EO_STAMP
+    if (lane == 0) {
+        atomicAdd(&eo_stamps_fwd[0], EO_T() - t_begin); atomicAdd(&eo_stamps_fwd[1], ws.t_wait); atomicAdd(&eo_stamps_fwd[2], ws.t_bar); atomicAdd(&eo_stamps_fwd[3], ws.t_flush); atomicAdd(&eo_stamps_fwd[4], 1ull);
+    }
+#endif
 }
 
 template <class P, bool FULL, int MODE>
@@ -215,3 +226,11 @@ template <class P> hipError_t dispatch(const MlpFwdArgs& a, bool full, int mode,
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st) {
     return bf16 ? dispatch<PBf16>(a, full, mode, grid, st) : dispatch<PF32>(a, full, mode, grid, st);
 }
+
+#ifdef EO_STAMP
+extern "C" void eonerf_debug_read_fwd(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(eo_stamps_fwd), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(eo_stamps_fwd), z, sizeof(z));
+}
+#endif
