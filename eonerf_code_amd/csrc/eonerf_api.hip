@@ -623,6 +623,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     for (int k = 0; k < tab.n; ++k) {
         WgradJob& j = sorted.j[k];
         j = tab.j[order[k]];
+        // default: 48 slices per job (measured: flat from ~2.4 to 6.5 items per CU, clearly slower below 2)
         int sl = ctx->wgrad_items ? (int)(((long long)ctx->wgrad_items * weight[order[k]] + total / 2) / total) : 48;
         j.slices = sl < 1 ? 1 : sl;
         j.item0 = sorted.items;
