@@ -46,6 +46,7 @@ struct PassBuffers {       // one MLP pass (camera or sun) over up to p_cap samp
 struct RenderWs {
     int *cnt_first, *cnt_retry, *flags;
     float* ray_rec; float* g_ray; float* amb_save;
+    float* m_bott;        // [2][128][256] fp32: dA1^T X8 and dT1^T X8 (factors of the bottleneck weight gradient)
     PassBuffers cam, sun;
     size_t bytes;
 };
@@ -166,6 +167,7 @@ RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) 
     w.ray_rec = c.take<float>((size_t)n_rays * RAY_REC);
     w.g_ray = train ? c.take<float>((size_t)n_rays * RAY_REC) : nullptr;
     w.amb_save = train ? c.take<float>((size_t)n_rays * 160) : nullptr;
+    w.m_bott = train ? c.take<float>(2 * 128 * 256) : nullptr;
     carve_pass(c, w.cam, n_rays, p_cap, !od, train, false, ab);
     if (shadows && !od) carve_pass(c, w.sun, n_rays, p_cap, false, train, true, ab); else memset(&w.sun, 0, sizeof(w.sun));
     w.bytes = c.off + 256;
@@ -599,7 +601,10 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
     };
     trunk_jobs(w.cam);
-    add(w.cam, GRD_ROW_BOTT, 256, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.bot_w), 256, dptr(pl.bot_b), nullptr, 2, 4, 4, 2);
+    // bottleneck layer: factor M_a = dA1^T X8 (and M_t = dT1^T X8), finished by eo_launch_bott_wgrad below
+    HIP_TRY(hipMemsetAsync(w.m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
+    add(w.cam, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, w.m_bott, 256, nullptr, nullptr, 2, 4, 2, 2);
+    if (transient) add(w.cam, GRD_ROW_T1, 128, ACT_ROW_X1 + 256 * 7, 256, w.m_bott + 128 * 256, 256, nullptr, nullptr, 2, 4, 2, 2);
     add(w.cam, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
     add(w.cam, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
     if (transient) {
@@ -630,6 +635,14 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         sorted.items += j.slices;
     }
     { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(sorted, ctx->n_cu, p_cap, w.flags + 2, ctx->bf16, st)); }
+
+    {   // bottleneck layer: dW = W_A1^T M_a (+ W_T1^T M_t) from the two factors the GEMM above accumulated
+        BottWgradArgs bw;
+        bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = w.m_bott; bw.db_a1 = dptr(pl.a1_b);
+        bw.w_t1 = transient ? flat + pl.t[pl.t_w[0]].offset : nullptr; bw.m_t = w.m_bott + 128 * 256; bw.db_t1 = transient ? dptr(pl.t_b[0]) : nullptr;
+        bw.d_w = dptr(pl.bot_w); bw.d_b = dptr(pl.bot_b);
+        HIP_TRY(eo_launch_bott_wgrad(bw, st));
+    }
 
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
     if (transient) {

@@ -60,6 +60,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         };
         // dX tile -> (optional ReLU mask) -> units of the next backward layer + feature-major save for the wgrad GEMM
         // (slice s of the epilogue of m-tile mt, see chunk_compute)
+        // d bottleneck: identity activation, handed on in registers only.  Its weight gradient is computed WITHOUT the saved
+        // tensor: dW_bott = W_A1^T (dA1^T X8) [+ W_T1^T (dT1^T X8)] -- two 128-row jobs of the weight-gradient GEMM on operands
+        // that are saved anyway, and a 256x128x256 product afterwards (eo_launch_bott_wgrad), instead of 256 more rows written
+        // here and read back there.
+        auto bott_epi = [&](U* dst, int mt, const f32x16& accv, int s) { put_slice(P(), dst, mt, s, pack_slice(P(), accv, s)); };
         auto grad_epi = [&](U* dst, int grd_row, bool masked, int mt, const f32x16& accv, int s) {
             const Sl<P> v = masked ? mask_slice(P(), accv, s, mt, mb[mt >> 1]) : pack_slice(P(), accv, s);
             put_slice(P(), dst, mt, s, v);
@@ -119,13 +124,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, mid, lane, h,
                     [&](int kg) { return kg < QKG ? DA1[kg < QKG ? kg : 0] : TB[kg >= QKG ? kg - QKG : 0]; },
                     [&](int mt, const f32x16& v, int s) {
-                        if (mt < 8) { grad_epi(N, GRD_ROW_BOTT, false, mt, v, s); return; }
+                        if (mt < 8) { bott_epi(N, mt, v, s); return; }
                         if (s == 0 && h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
                     });
             } else {
                 // ---- dY_A1 -> d bottleneck ----
-                run_layer<P, SLOT, QKG, 8, FwdG<P, QKG, 8>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return DA1[kg]; },
-                    [&](int mt, const f32x16& v, int s) { grad_epi(N, GRD_ROW_BOTT, false, mt, v, s); });
+                run_layer<P, SLOT, QKG, 8, FwdG<P, QKG, 8>::G, false>(ws, mid, lane, h, [&](int kg) { return DA1[kg]; },
+                    [&](int mt, const f32x16& v, int s) { bott_epi(N, mt, v, s); });
             }
             // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
             const U u_sg = small_unit<P>(dsig, h);

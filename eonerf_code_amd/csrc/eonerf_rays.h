@@ -76,6 +76,13 @@ struct AmbientBwdArgs {
     float *d_w1, *d_b1, *d_w2, *d_b2;
 };
 
+// dW_bott += W_A1^T M_a (+ W_T1^T M_t),  db_bott += W_A1^T db_A1 (+ W_T1^T db_T1)   (see k_mlp_bwd, bott_epi)
+struct BottWgradArgs {
+    const float *w_a1, *m_a, *db_a1;     // [128][256] weights, [128][256] dA1^T X8, [128]
+    const float *w_t1, *m_t, *db_t1;     // transient head's first layer ([128][260] weights) or nullptr
+    float *d_w, *d_b;                    // [256][256], [256] inside the flat gradient buffer
+};
+
 struct EmbGradArgs {
     const int *offsets, *counts;
     const int64_t* img_idx;
@@ -103,6 +110,7 @@ hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st
 hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st);
+hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st);
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st);
 hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st);
 hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,

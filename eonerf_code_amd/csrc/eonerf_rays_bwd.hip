@@ -179,6 +179,27 @@ __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
     }
 }
 
+// ---- bottleneck layer weight gradient from the two factors (fp32): block = input feature i of the heads' first layers =
+//      output feature (row) of the bottleneck layer, thread = column j ----
+__global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
+    __shared__ float s_w[256];
+    const int i = blockIdx.x, j = threadIdx.x;
+    float acc = 0.f, accb = 0.f;
+    if (j < 128) s_w[j] = a.w_a1[j * 256 + i];
+    else s_w[j] = a.w_t1 ? a.w_t1[(j - 128) * 260 + i] : 0.f;
+    __syncthreads();
+    for (int k = 0; k < 128; ++k) acc += s_w[k] * a.m_a[k * 256 + j];
+    if (a.w_t1)
+        for (int k = 0; k < 128; ++k) acc += s_w[128 + k] * a.m_t[k * 256 + j];
+    a.d_w[i * 256 + j] += acc;                      // the only writer of this block of the gradient buffer
+    if (j == 0) {
+        for (int k = 0; k < 128; ++k) accb += s_w[k] * a.db_a1[k];
+        if (a.w_t1)
+            for (int k = 0; k < 128; ++k) accb += s_w[128 + k] * a.db_t1[k];
+        a.d_b[i] += accb;
+    }
+}
+
 // ---- transient embedding gradient: per-sample d emb (from the backward chain) summed per ray, added per image ---
 __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
     extern __shared__ float s_de[];                     // [n_img][4] block-local accumulation (0 floats if unused)
@@ -271,6 +292,10 @@ hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st) {
 }
 hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_cam_composite_bwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_bott_wgrad, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st) {
