@@ -143,9 +143,12 @@ def main():
         macs = mac_of[dom]
         step_flops = 2.0 * sum(mac_of.values()) * n_cam
         # HBM bytes each kernel must move per sample (bf16 slabs): rows x 2 B
-        rows_rd_wgrad = (2816 + 2692) if args.workload == "rgb" else (3392 + 3268)
-        bytes_of = {"fwd_chain_camera": (2496 if args.workload == "rgb" else 3040) * 2 + 9 * 32,
-                    "bwd_chain_camera": (2500 if args.workload == "rgb" else 3040) * 2 + 9 * 32,
+        #   forward chain writes   enc 64 + X1..X8 2048 + bottleneck 256 + albedo hidden 128 (+ transient 512 + emb 4) rows, 9 (13) masks
+        #   backward chain writes  dY0..7 2048 + dA1 128 + d sigma 1 + d albedo 3 (+ dT1..4 512 + d ts/tb 2) rows, reads the masks
+        #   weight-gradient GEMM   reads every job's two operands once (valid rows; camera-pass jobs only for --workload full)
+        rows_rd_wgrad = (2564 + 2816) if args.workload == "rgb" else (3334 + 3972)
+        bytes_of = {"fwd_chain_camera": (2496 if args.workload == "rgb" else 3012) * 2 + (9 if args.workload == "rgb" else 13) * 32,
+                    "bwd_chain_camera": (2180 if args.workload == "rgb" else 2694) * 2 + (9 if args.workload == "rgb" else 13) * 32,
                     "wgrad_gemm": rows_rd_wgrad * 2}
         elt = 2 if args.precision == "bf16" else 4
         for name in kernels:
