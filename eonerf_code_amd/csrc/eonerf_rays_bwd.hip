@@ -140,14 +140,18 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
     }
 }
 
-// ---- ambient head backward (radiance_fields/eonerf.py:132-139): one thread per hidden unit, rays strided over WGs
-__global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
-    const int j = threadIdx.x;
+// ---- ambient head backward (radiance_fields/eonerf.py:132-139): thread = (hidden unit j, ray stream q); the block's rays
+//      are dealt to AMB_STREAMS streams, whose partial sums meet in LDS before ONE set of atomics per block (256 blocks
+//      each adding into the same 3.9k addresses took 125 us: same-address atomics serialise) ----
+constexpr int AMB_STREAMS = 4;
+__global__ __launch_bounds__(128 * AMB_STREAMS) void k_ambient_bwd(AmbientBwdArgs a) {
+    __shared__ float red[AMB_STREAMS - 1][128][32];
+    const int j = threadIdx.x & 127, q = threadIdx.x >> 7;
     float dw1[27], dw2[3] = {0.f, 0.f, 0.f}, db1 = 0.f, db2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 27; ++i) dw1[i] = 0.f;
     const float w2[3] = {a.w.w2[j], a.w.w2[128 + j], a.w.w2[256 + j]};
-    for (int ray = blockIdx.x; ray < a.n_rays; ray += gridDim.x) {
+    for (int ray = blockIdx.x * AMB_STREAMS + q; ray < a.n_rays; ray += gridDim.x * AMB_STREAMS) {
         const float* rec = a.ray_rec + (size_t)ray * RAY_REC;
         const float* g = a.g_ray + (size_t)ray * RAY_REC;
         if (g[RR_AMB] == 0.f && g[RR_AMB + 1] == 0.f && g[RR_AMB + 2] == 0.f) continue;      // outside the graph (s == 1)
@@ -167,16 +171,33 @@ __global__ __launch_bounds__(128) void k_ambient_bwd(AmbientBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 27; ++i) dw1[i] += ghid * sv[i];
     }
+    // streams 1.. hand their sums to stream 0 through LDS: slots 0..26 dw1, 27 db1, 28..30 dw2
+    if (q > 0) {
+        float* r = red[q - 1][j];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) r[i] = dw1[i];
+        r[27] = db1; r[28] = dw2[0]; r[29] = dw2[1]; r[30] = dw2[2];
+    }
+    // db2 is the same for every hidden unit of a stream: one thread per stream adds it
+    if (j == 0) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) if (db2[o] != 0.f) atomicAdd(a.d_b2 + o, db2[o]);
+    }
+    __syncthreads();
+    if (q > 0) return;
+#pragma unroll
+    for (int s = 0; s < AMB_STREAMS - 1; ++s) {
+        const float* r = red[s][j];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) dw1[i] += r[i];
+        db1 += r[27]; dw2[0] += r[28]; dw2[1] += r[29]; dw2[2] += r[30];
+    }
     // zero contributions are skipped: with the shadow pass off the ambient head is outside the graph (1 - s == 0)
 #pragma unroll
     for (int i = 0; i < 27; ++i) if (dw1[i] != 0.f) atomicAdd(a.d_w1 + j * 27 + i, dw1[i]);
     if (db1 != 0.f) atomicAdd(a.d_b1 + j, db1);
 #pragma unroll
     for (int o = 0; o < 3; ++o) if (dw2[o] != 0.f) atomicAdd(a.d_w2 + o * 128 + j, dw2[o]);
-    if (j == 0) {
-#pragma unroll
-        for (int o = 0; o < 3; ++o) if (db2[o] != 0.f) atomicAdd(a.d_b2 + o, db2[o]);
-    }
 }
 
 // ---- bottleneck layer weight gradient from the two factors (fp32): block = input feature i of the heads' first layers =
@@ -299,7 +320,7 @@ hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_ambient_bwd, dim3(a.n_rays < 256 ? a.n_rays : 256), dim3(128), 0, st, a);      // the ray loop is a chain of dependent loads: keep it short
+    hipLaunchKernelGGL(k_ambient_bwd, dim3(a.n_rays < 256 ? (a.n_rays + 3) / 4 : 64), dim3(128 * AMB_STREAMS), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
