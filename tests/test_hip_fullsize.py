@@ -1,0 +1,102 @@
+"""GPU properties of the HIP path at the bench size (BASELINE.json configs[1]/[2]: 4096 rays x 128 samples, ~4.9e5 samples
+per pass), where the CPU oracle is too slow to be the checker.  They are size independent and must hold exactly or to
+fp32 reassociation noise:
+
+  * rays are independent units: rendering a batch in one call, in four chunks, or permuted gives the same
+    per-ray outputs bit for bit (the kernels pack samples into 256-sample tiles differently in each case);
+  * sample bookkeeping: sum(pts_per_ray) == n_rendering_samples, 0 <= pts_per_ray <= 127, rgb in [0,1], 0 <= depth <= 2;
+  * the gradient is linear in dL/d(out): scaling the upstream gradient by 2 doubles every parameter gradient, and the
+    gradient of a sum over rays is the sum of the gradients of its two halves (split-K sums + fp32 atomics: 2e-4 relative);
+  * the fused trainer at full size: bf16 loss decreases, gradients finite, steps of the order of lr.
+"""
+import pytest
+import torch
+
+from oracle import eonerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+STEP = 2.0 / 128
+R, N_IMG = 4096, 19
+
+
+def _setup(precision, seed=7):
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    from eonerf_code_amd.synthetic import synthetic_batch
+    torch.manual_seed(seed)
+    sd = orc.random_state_dict(N_IMG, seed=seed, bias_scale=0.05)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    f = EONerfMLP(N_IMG, radiometric_normalization=True, precision=precision)
+    f.load_state_dict(sd, strict=True)
+    f = f.cuda()
+    rays, img, rgbs = (t.cuda() for t in synthetic_batch(R, N_IMG))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    noise = tuple(torch.rand(R, 128, device="cuda", generator=g) for _ in range(3))
+    return f, rays, img, rgbs, noise
+
+
+def _render(f, rays, img, noise, epoch, chunk, idx=None):
+    from eonerf_code_amd.sat_rendering import render_image
+    from eonerf_code_amd.datasets.satellite import define_satrays_from_tensors
+    if idx is not None:
+        rays, img, noise = rays[idx], img[idx], tuple(u[idx] for u in noise)
+    n = rays.shape[0]
+    nz = [tuple(u[i:i + chunk].contiguous() for u in noise) for i in range(0, n, chunk)]
+    return render_image(f, None, define_satrays_from_tensors(rays, img[:, None]), None, None, epoch_idx=epoch, chunk=chunk,
+                        render_step_size=STEP, noise=nz)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_rays_are_independent_units_chunking_and_permutation(precision):
+    f, rays, img, rgbs, noise = _setup(precision)
+    with torch.no_grad():
+        full, n_full = _render(f, rays, img, noise, 3, 4096)
+        quart, n_quart = _render(f, rays, img, noise, 3, 1024)
+        perm = torch.randperm(R, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+        shuf, n_shuf = _render(f, rays, img, noise, 3, 4096, idx=perm)
+    assert n_full == n_quart == n_shuf
+    for k in full:
+        assert torch.equal(full[k], quart[k]), k
+        assert torch.equal(full[k][perm], shuf[k]), k
+    assert int(full["pts_per_ray"].sum().item()) == n_full
+    assert 0 <= full["pts_per_ray"].min().item() and full["pts_per_ray"].max().item() <= 127
+    assert full["rgb"].min().item() >= 0.0 and full["rgb"].max().item() <= 1.0
+    assert full["depth"].min().item() >= 0.0 and full["depth"].max().item() <= 2.0
+    assert torch.isfinite(torch.cat([v.reshape(-1) for v in full.values()])).all()
+
+
+def _grads(f, rays, img, noise, epoch, weight, idx=None):
+    """gradient of sum_r weight * (sum of rgb + depth + beta of ray r) -- a loss that is a plain SUM over rays"""
+    f.zero_grad()
+    res, _ = _render(f, rays, img, noise, epoch, 4096, idx=idx)
+    (weight * (res["rgb"].sum() + res["depth"].sum() + res["beta"].sum())).backward()
+    return [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for p in f.parameters()]
+
+
+def test_gradient_is_linear_in_the_upstream_gradient_and_additive_over_rays_fp32():
+    f, rays, img, rgbs, noise = _setup("fp32", seed=11)
+    g1 = _grads(f, rays, img, noise, 3, 1.0)
+    g2 = _grads(f, rays, img, noise, 3, 2.0)
+    half = R // 2
+    ga = _grads(f, rays, img, noise, 3, 1.0, idx=torch.arange(0, half, device="cuda"))
+    gb = _grads(f, rays, img, noise, 3, 1.0, idx=torch.arange(half, R, device="cuda"))
+    names = [n for n, _ in f.named_parameters()]
+    for name, a, b, c, d in zip(names, g1, g2, ga, gb):
+        scale = a.norm().item()
+        assert torch.isfinite(a).all(), name
+        assert (b - 2 * a).norm().item() <= 2e-4 * scale + 1e-12, ("linearity", name)
+        assert (c + d - a).norm().item() <= 2e-4 * scale + 1e-12, ("additivity", name)
+
+
+def test_fused_trainer_full_size_bf16():
+    from eonerf_code_amd.trainer import FusedTrainer
+    f, rays, img, rgbs, noise = _setup("bf16", seed=5)
+    tr = FusedTrainer(f, lr=5e-4, max_rays=R)
+    for epoch in (0, 3):
+        before = f.flat_params().clone()
+        losses = [float(tr.step(rays, img, rgbs, epoch)) for _ in range(8)]
+        assert all(l == l for l in losses)                     # no NaN
+        assert losses[-1] < losses[0], (epoch, losses)
+        assert torch.isfinite(tr.d_flat).all()
+        moved = (f.flat_params() - before).abs().max().item()
+        assert 0 < moved <= 8 * 5e-4 * 3                       # Adam: |step| = lr |m^|/sqrt(v^) ~ lr (a few lr when the gradient grows)
+    assert int(tr.n_samples.item()) > 100 * R                  # the synthetic geometry keeps ~120 of 127 samples per ray
