@@ -108,3 +108,117 @@ def get_rays(cols, rows, rpc, min_alt, max_alt, utm=True, device="cuda"):
     if not utm:
         raise NotImplementedError("the ECEF branch (--ecef) is not part of the hot path")
     return generate_rays(rpc, min_alt, max_alt, cols=cols, rows=rows, device=device)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Dataset side of ray generation: the metadata JSONs, the ray cache and scene.loc_utm of the reference
+# (datasets/satellite.py:299-307, 374-404, 406-481), without the image pixels (rasterio is not part of this path).
+#   <root>/<img>.json      keys img, height, width, rpc (rpcm dict), min_alt, max_alt, sun_elevation, sun_azimuth
+#   <cache_dir>/<id>.data  torch.save of the UN-normalised fp32 rays [h*w, 8] of get_rays (or [h*w, 11] incl. sun dirs)
+#   <root>/scene.loc_utm   JSON {X,Y,Z}_{scale,offset}
+# ---------------------------------------------------------------------------------------------------------------------
+def sun_direction(sun_elevation_deg, sun_azimuth_deg):
+    """get_sun_dirs(90 - sun_elevation, sun_azimuth) of load_data (:456-457) -> get_dir_vec_from_el_az (:57-63): fp64 3-vector."""
+    import math
+    el, az = math.radians(float(sun_elevation_deg)), math.radians(float(sun_azimuth_deg))
+    return [-math.sin(az) * math.cos(el), -math.cos(az) * math.cos(el), -math.sin(el)]
+
+
+def normalize_rays(rays, scene_offset, scene_scale):
+    """datasets/satellite.py:124-139 on the tensor's device: rays [N,8|11] holding the fp32 values of the cache (+ fp64 sun
+    directions) -> float64 [N,8|11] normalised rays, arithmetic in fp64 as numpy does after the hstack with the fp64 sun
+    directions (:458); scene_offset / scene_scale are the dataset's fp32 values (:303-307)."""
+    import torch
+    r = rays.to(torch.float64)
+    off = torch.as_tensor(scene_offset, dtype=torch.float32).to(r.device, torch.float64)
+    sc = torch.as_tensor(scene_scale, dtype=torch.float32).to(r.device, torch.float64)
+    o = r[:, :3]
+    e = o + r[:, 3:6] * r[:, 7:8]
+    o_n, e_n = (o - off) / sc, (e - off) / sc
+    d = e_n - o_n
+    far = torch.linalg.norm(d, dim=1, keepdim=True)
+    cols = [o_n, d / far, torch.zeros_like(far), far]
+    if r.shape[1] == 11:
+        s = r[:, 8:11] / sc
+        cols.append(s / torch.linalg.norm(s, dim=1, keepdim=True))
+    return torch.cat(cols, dim=1)
+
+
+def rpc_scaling_params(v):
+    """sat_utils.rpc_scaling_params (sat_utils.py:32-39): (scale, offset) of a vector."""
+    lo, hi = float(v.min()), float(v.max())
+    scale = (hi - lo) / 2
+    return scale, lo + scale
+
+
+def scene_loc_from_rays(raw_rays):
+    """init_scaling_params (datasets/satellite.py:395-403): the scene.loc_utm dict from all un-normalised rays [N,>=8]."""
+    import torch
+    near = raw_rays[:, :3].double()
+    far = near + raw_rays[:, 7:8].double() * raw_rays[:, 3:6].double()
+    pts = torch.cat([near, far], 0)
+    d = {}
+    for k, name in enumerate("XYZ"):
+        d[name + "_scale"], d[name + "_offset"] = rpc_scaling_params(pts[:, k])
+    return d
+
+
+def read_scene_loc(path):
+    """-> (scene_offset[3], scene_scale[3]) as the dataset keeps them (:299-307)."""
+    import json
+    with open(path) as f:
+        d = json.load(f)
+    return ([float(d["X_offset"]), float(d["Y_offset"]), float(d["Z_offset"])],
+            [float(d["X_scale"]), float(d["Y_scale"]), float(d["Z_scale"])])
+
+
+def load_rays(json_files, scene_loc=None, img_downscale=1.0, cache_dir=None, device="cuda", verbose=False):
+    """The ray half of SatelliteDataset.load_data (datasets/satellite.py:406-481) with the RPC localisation on the GPU.
+    json_files: metadata JSON paths (one per image, their order defines the image index); scene_loc: path of scene.loc_utm,
+    an (offset, scale) pair, or None to derive it from these rays as init_scaling_params does.  Rays of an image found in
+    cache_dir are read from there, others are generated and written there in the reference's format.
+    Returns (all_rays fp32 [N,11] normalised, all_ids_img int64 [N], all_img_shapes [[h,w],...], scene_loc (offset, scale))."""
+    import json
+    import os
+    import torch
+    dev = torch.device(device)
+    raws, suns, ids, shapes = [], [], [], []
+    for t, jp in enumerate(json_files):
+        with open(jp) as f:
+            d = json.load(f)
+        img_id = os.path.splitext(os.path.basename(d["img"]))[0]                     # sat_utils.get_file_id
+        h, w = int(d["height"] // img_downscale), int(d["width"] // img_downscale)
+        cache_path = None if cache_dir is None else os.path.join(cache_dir, img_id + ".data")
+        if cache_path is not None and os.path.exists(cache_path):
+            raw = torch.load(cache_path, map_location="cpu")
+            raw = torch.as_tensor(raw).to(dev)
+            if raw.shape[0] != h * w or raw.shape[1] not in (8, 11):
+                raise ValueError(f"{cache_path}: expected [{h * w}, 8|11] rays, found {tuple(raw.shape)}")
+        else:
+            raw = generate_rays(d["rpc"], float(d["min_alt"]), float(d["max_alt"]), h=h, w=w, img_downscale=img_downscale, device=dev)
+            if cache_path is not None:
+                os.makedirs(os.path.dirname(cache_path) or ".", exist_ok=True)
+                torch.save(raw.cpu(), cache_path)
+        if raw.shape[1] == 8:      # sun directions are appended to freshly generated / 8-column cached rays (:455-458)
+            sun = torch.tensor(sun_direction(d["sun_elevation"], d["sun_azimuth"]), dtype=torch.float64, device=dev)
+            raw = torch.cat([raw.to(torch.float64), sun.expand(raw.shape[0], 3)], dim=1)
+        raws.append(raw.to(torch.float64))
+        ids.append(torch.full((raw.shape[0],), t, dtype=torch.int64, device=dev))
+        shapes.append([h, w])
+        if verbose:
+            print(f"Image {img_id} loaded ( {t + 1} / {len(json_files)} )")
+    all_raw = torch.cat(raws, 0)
+    if scene_loc is None:
+        dloc = scene_loc_from_rays(all_raw)
+        scene_loc = ([dloc["X_offset"], dloc["Y_offset"], dloc["Z_offset"]], [dloc["X_scale"], dloc["Y_scale"], dloc["Z_scale"]])
+    elif isinstance(scene_loc, (str, os.PathLike)):
+        scene_loc = read_scene_loc(scene_loc)
+    all_rays = normalize_rays(all_raw, scene_loc[0], scene_loc[1]).to(torch.float32)
+    return all_rays, torch.cat(ids, 0), shapes, scene_loc
+
+
+def write_scene_loc(path, scene_loc_dict):
+    """sat_utils.write_dict_to_json of init_scaling_params (:403)."""
+    import json
+    with open(path, "w") as f:
+        json.dump(scene_loc_dict, f, indent=2)
