@@ -222,3 +222,16 @@ def write_scene_loc(path, scene_loc_dict):
     import json
     with open(path, "w") as f:
         json.dump(scene_loc_dict, f, indent=2)
+
+
+def get_utmalt_from_nerf_prediction(rays, depth, scene_offset, scene_scale, double=True):
+    """SatelliteDataset.get_utmalt_from_nerf_prediction (datasets/satellite.py:502-533, UTM branch) on the tensors' device:
+    rays [N,>=6] normalised, depth [N,1] rendered depth -> (easts, norths, alts); fp64 by default, as the reference (the
+    altitude of the DSM criterion: within 1 cm of the reference path)."""
+    import torch
+    if double:
+        rays, depth = rays.double(), depth.double()
+    off = torch.as_tensor(scene_offset, dtype=torch.float32).to(rays.device, rays.dtype)      # fp32 tensors in the dataset (:303-307)
+    sc = torch.as_tensor(scene_scale, dtype=torch.float32).to(rays.device, rays.dtype)
+    xyz = (rays[:, 0:3] + rays[:, 3:6] * depth.view(-1, 1)) * sc + off
+    return xyz[:, 0], xyz[:, 1], xyz[:, 2]

@@ -177,6 +177,11 @@ def test_altitude_within_1cm_fp32():
     alt_ref = orc.altitude_from_depth(rays, ref[:, 3:4], 50.0, 20.0)
     alt = orc.altitude_from_depth(rays, res["depth"].cpu(), 50.0, 20.0)
     assert (alt - alt_ref).abs().max().item() < 0.01
+    # the product's mirror of get_utmalt_from_nerf_prediction (datasets/satellite.py:502-533) on the GPU tensors
+    from eonerf_code_amd.datasets.satellite import get_utmalt_from_nerf_prediction
+    e, n, a = get_utmalt_from_nerf_prediction(rays.cuda(), res["depth"], [4.4e5, 3.35e6, 20.0], [300.0, 300.0, 50.0])
+    assert a.dtype == torch.float64 and (a.cpu() - alt_ref).abs().max().item() < 0.01
+    assert (e.cpu() - ((rays[:, 0].double() + rays[:, 3].double() * res["depth"].cpu().double().view(-1)) * 300.0 + 4.4e5)).abs().max().item() < 1e-6
 
 
 def test_satnerf_sampling_bit_exact_vs_reference_golden_g4():
