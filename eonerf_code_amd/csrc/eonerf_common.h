@@ -220,6 +220,23 @@ EO_DEV f32x16 zero_acc() { f32x16 a; for (int i = 0; i < 16; ++i) a[i] = 0.f; re
 // a block of ~50 behind the last MFMA of every tile (with the s_nop the matrix pipeline needs before its result can be
 // read), during which this wave has no matrix work in flight.  The last tile of a chunk is finished before the chunk
 // barrier.
+// Chunk grouping of a layer (shared with the packer, eonerf_pack.cpp): its MT m-tiles are cut into the fewest chunks of at most
+// CHUNK_KG_TARGET k-group units (and 8 m-tiles), as even as possible -- e.g. a 256 x 256 layer (KG = 16, MT = 8) into 3 + 3 + 2
+// m-tiles.  Every chunk costs a workgroup barrier, so fewer, larger chunks; two chunk slots + the slab staging fill the LDS.
+constexpr int CHUNK_KG_TARGET = 48;
+__host__ __device__ constexpr int group_max(int kg, int mt) {
+    int g = CHUNK_KG_TARGET / kg;
+    g = g > 8 ? 8 : g;
+    g = g > mt ? mt : g;
+    return g < 1 ? 1 : g;
+}
+__host__ __device__ constexpr int n_groups(int kg, int mt) { return (mt + group_max(kg, mt) - 1) / group_max(kg, mt); }
+__host__ __device__ constexpr int group_size(int kg, int mt, int c) { return mt / n_groups(kg, mt) + (c < mt % n_groups(kg, mt) ? 1 : 0); }
+__host__ __device__ constexpr int group_start(int kg, int mt, int c) {
+    int s = 0;
+    for (int k = 0; k < c; ++k) s += group_size(kg, mt, k);
+    return s;
+}
 constexpr int EPI_SLICES = 8;
 template <int KG> EO_DEV constexpr int slice_pos(int s) { return KG >= 14 ? 5 + s : (s * KG) / EPI_SLICES; }
 
@@ -292,21 +309,20 @@ EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& 
     }
 }
 
-// A whole layer: MT m-tiles in MT/G chunks.  NST = slab stores every m-tile's epilogue issues (lower bound, 0 = unknown).
-// `mid` is called once per m-tile a few MFMAs in: the slab flush of the oldest staged tile (or a no-op).
-template <class P, int SLOT, int KG, int MT, int G, bool BIAS, int NST = 0, class Mid, class BArr, class Epi>
+// A whole layer: MT m-tiles in n_groups(KG, MT) chunks.  NST = slab stores every m-tile's epilogue issues (lower bound, 0 = unknown).
+// `mid` provides the slab-flush hooks called a few MFMAs into every m-tile (or no-ops).
+template <class P, int SLOT, int KG, int MT, bool BIAS, int NST = 0, int C = 0, class Mid, class BArr, class Epi>
 EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BArr& B, Epi&& epi) {
-    static_assert(MT % G == 0, "G must divide MT");
-    static_assert(G * (KG * 1024 + 128) <= SLOT, "chunk does not fit the LDS slot");
-#pragma unroll
-    for (int mg = 0; mg < MT / G; ++mg) {
+    if constexpr (C < n_groups(KG, MT)) {
+        constexpr int G = group_size(KG, MT, C), M0 = group_start(KG, MT, C);
+        static_assert(G * (KG * 1024 + 128) <= SLOT, "chunk does not fit the LDS slot");
         ws.prefetch_next();
-        chunk_compute<P, KG, G, BIAS>(ws, lane, h, B, mg * G, epi, mid);
+        chunk_compute<P, KG, G, BIAS>(ws, lane, h, B, M0, epi, mid);
         // stores younger than the copy (LOWER bound, see WStream::advance).  bf16: one flush (NST = 2 stores) per m-tile once the
         // staging queue runs: always from the layer's third tile on, and in every tile after the first of a later chunk.  fp32
         // stores inside the slices, interleaved with the copy: not counted.
-        if (mg == 0) ws.template advance<(P::IS_BF16 ? (G >= 2 ? G - 2 : 0) * NST : 0)>();
-        else ws.template advance<(P::IS_BF16 ? (G - 1) * NST : 0)>();
+        ws.template advance<(P::IS_BF16 ? (C == 0 ? (G >= 2 ? G - 2 : 0) : G - 1) * NST : 0)>();
+        run_layer<P, SLOT, KG, MT, BIAS, NST, C + 1>(ws, mid, lane, h, B, epi);
     }
 }
 

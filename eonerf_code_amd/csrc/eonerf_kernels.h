@@ -48,22 +48,8 @@ struct GrdMap {
 constexpr int MASK_SLOTS_FULL = 13;                 // trunk 0..7, A1, T1..T4
 constexpr int MASK_SLOTS_DENSITY = 8;
 
-// LDS slot (one packed weight chunk) and chunk grouping
-template <class P> struct FwdSlot { static constexpr int KG_TARGET = 40; static constexpr int BYTES = KG_TARGET * 1024 + 1024; };
-template <class P, int KG, int MT> struct FwdG {
-    static constexpr int pick() {
-        int best = 1;
-        for (int g = 1; g <= MT; ++g) if (MT % g == 0 && g * KG <= FwdSlot<P>::KG_TARGET && g <= 8) best = g;
-        return best;
-    }
-    static constexpr int G = pick();
-};
-__host__ __device__ constexpr int pick_group(bool bf16, int kg, int mt) {
-    int best = 1;
-    const int target = 40; (void)bf16;
-    for (int g = 1; g <= mt; ++g) if (mt % g == 0 && g * kg <= target && g <= 8) best = g;
-    return best;
-}
+// LDS slot (one packed weight chunk; grouping: eonerf_common.h)
+template <class P> struct FwdSlot { static constexpr int BYTES = CHUNK_KG_TARGET * 1024 + 1024; };
 
 struct MlpFwdArgs {
     const float *px, *py, *pz;     // [p_pad] compact sample positions (SoA)

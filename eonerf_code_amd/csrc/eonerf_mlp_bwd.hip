@@ -102,26 +102,26 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 // ---- transient head backwards: {ts,tb}_pre -> T4 -> T3 -> T2 -> T1 ----
                 const U u_tr = small_unit<P>(dtr, h);
                 load_mask(12, 2);
-                run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_tr; },
+                run_layer<P, SLOT, 1, 4, false, NST>(ws, mid, lane, h, [&](int) { return u_tr; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v, s); });
                 load_mask(11, 2);
-                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
+                run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v, s); });
                 load_mask(10, 2);
-                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
+                run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v, s); });
                 load_mask(9, 2);
-                run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
+                run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TB, GRD_ROW_T1, true, mt, v, s); });        // TB = dY_T1
             }
             // ---- albedo head backwards: albedo_pre -> A1 ----
             const U u_al = small_unit<P>(dalb, h);
             load_mask(8, 2);
-            run_layer<P, SLOT, 1, 4, FwdG<P, 1, 4>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_al; },
+            run_layer<P, SLOT, 1, 4, false, NST>(ws, mid, lane, h, [&](int) { return u_al; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(DA1, GRD_ROW_A1, true, mt, v, s); });
             if constexpr (TRANS) {
                 // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
-                run_layer<P, SLOT, 2 * QKG, 9, FwdG<P, 2 * QKG, 9>::G, false>(ws, mid, lane, h,
+                run_layer<P, SLOT, 2 * QKG, 9, false>(ws, mid, lane, h,
                     [&](int kg) { return kg < QKG ? DA1[kg < QKG ? kg : 0] : TB[kg >= QKG ? kg - QKG : 0]; },
                     [&](int mt, const f32x16& v, int s) {
                         if (mt < 8) { bott_epi(N, mt, v, s); return; }
@@ -129,19 +129,19 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                     });
             } else {
                 // ---- dY_A1 -> d bottleneck ----
-                run_layer<P, SLOT, QKG, 8, FwdG<P, QKG, 8>::G, false>(ws, mid, lane, h, [&](int kg) { return DA1[kg]; },
+                run_layer<P, SLOT, QKG, 8, false>(ws, mid, lane, h, [&](int kg) { return DA1[kg]; },
                     [&](int mt, const f32x16& v, int s) { bott_epi(N, mt, v, s); });
             }
             // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
-            run_layer<P, SLOT, HKG + 1, 8, FwdG<P, HKG + 1, 8>::G, false, NST>(ws, mid, lane, h,
+            run_layer<P, SLOT, HKG + 1, 8, false, NST>(ws, mid, lane, h,
                 [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v, s); });
         } else {
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
-            run_layer<P, SLOT, 1, 8, FwdG<P, 1, 8>::G, false, NST>(ws, mid, lane, h, [&](int) { return u_sg; },
+            run_layer<P, SLOT, 1, 8, false, NST>(ws, mid, lane, h, [&](int) { return u_sg; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v, s); });
         }
 
@@ -149,14 +149,14 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         f32x16 denc[2];
         auto trunk_step = [&](U* src, U* dst, int l) {      // consumes dY_l, produces dY_{l-1}
             load_mask(l - 1, 4);
-            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, false, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
+            run_layer<P, SLOT, HKG, 8, false, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(dst, GRD_ROW_Y0 + (l - 1) * 256, true, mt, v, s); });
         };
         trunk_step(D, N, 7);
         trunk_step(N, D, 6);
         // layer 5 consumed [h, enc]: rows 0..255 go on down the trunk, rows 256..319 are d enc (skip path)
         load_mask(4, 4);
-        run_layer<P, SLOT, HKG, IG ? 10 : 8, FwdG<P, HKG, IG ? 10 : 8>::G, false>(ws, mid, lane, h, [&](int kg) { return D[kg]; },
+        run_layer<P, SLOT, HKG, IG ? 10 : 8, false>(ws, mid, lane, h, [&](int kg) { return D[kg]; },
             [&](int mt, const f32x16& v, int s) {
                 if (mt < 8) { grad_epi(N, GRD_ROW_Y0 + 4 * 256, true, mt, v, s); return; }
                 if constexpr (IG) { if (s == 0) denc[mt == 8 ? 0 : 1] = v; }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         trunk_step(D, N, 1);                                        // N = dY_0
 
         if constexpr (IG) {
-            run_layer<P, SLOT, HKG, 2, FwdG<P, HKG, 2>::G, false>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
+            run_layer<P, SLOT, HKG, 2, false>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
                 [&](int mt, const f32x16& v, int s) {
                     if (s != 0) return;
 #pragma unroll

@@ -109,13 +109,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             }
         };
         auto plain_layer = [&](U* src, U* dst, int l) {
-            run_layer<P, SLOT, HKG, 8, FwdG<P, HKG, 8>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
+            run_layer<P, SLOT, HKG, 8, true, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
                 [&](int mt, const f32x16& v, int s) { relu_epi(dst, ACT_ROW_X1 + 256 * l, mt, v, s); });
             save_mask(l, 4);
         };
 
         // layer 0: enc(64) -> 256
-        run_layer<P, SLOT, EKG, 8, FwdG<P, EKG, 8>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return E.u[kg]; },
+        run_layer<P, SLOT, EKG, 8, true, NST>(ws, mid, lane, h, [&](int kg) { return E.u[kg]; },
             [&](int mt, const f32x16& v, int s) { relu_epi(H, ACT_ROW_X1, mt, v, s); });
         save_mask(0, 4);
         plain_layer(H, N, 1);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         plain_layer(H, N, 3);
         plain_layer(N, H, 4);
         // layer 5 consumes [h, enc] (skip-concat after layer 4, mlp.py:92-97)
-        run_layer<P, SLOT, HKG + EKG, 8, FwdG<P, HKG + EKG, 8>::G, true, NST>(ws, mid, lane, h,
+        run_layer<P, SLOT, HKG + EKG, 8, true, NST>(ws, mid, lane, h,
             [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : E.u[kg >= HKG ? kg - HKG : 0]; },
             [&](int mt, const f32x16& v, int s) { relu_epi(N, ACT_ROW_X1 + 256 * 5, mt, v, s); });
         save_mask(5, 4);
@@ -133,12 +133,12 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         // ---------------- sigma (+ bottleneck) ----------------
         float sigma_raw = 0.f;
         if constexpr (!FULL) {
-            run_layer<P, SLOT, HKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
+            run_layer<P, SLOT, HKG, 1, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
                 [&](int, const f32x16& v, int s) { if (s == 0) sigma_raw = v[0]; });
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
         } else {
             // m-tile 0 = sigma row, m-tiles 1..8 = bottleneck (identity activation) -> H
-            run_layer<P, SLOT, HKG, 9, FwdG<P, HKG, 9>::G, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
+            run_layer<P, SLOT, HKG, 9, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
                 [&](int mt, const f32x16& v, int s) {
                     if (mt == 0) { if (s == 0) sigma_raw = v[0]; return; }
                     const Sl<P> x = pack_slice(P(), v, s);
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 
             // ---------------- albedo head: 256 -> 128 (ReLU) -> 3 (Sigmoid) ----------------
             U A1[QKG];
-            run_layer<P, SLOT, HKG, 4, FwdG<P, HKG, 4>::G, true, NST>(ws, mid, lane, h, [&](int kg) { return H[kg]; },
+            run_layer<P, SLOT, HKG, 4, true, NST>(ws, mid, lane, h, [&](int kg) { return H[kg]; },
                 [&](int mt, const f32x16& v, int s) { relu_epi(A1, ACT_ROW_A1, mt, v, s); });
             save_mask(8, 2);
-            run_layer<P, SLOT, QKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return A1[kg]; },
+            run_layer<P, SLOT, QKG, 1, true>(ws, mid, lane, h, [&](int kg) { return A1[kg]; },
                 [&](int, const f32x16& v, int s) {
                     if (s == 0 && h == 0 && live) {
                         a.albedo[p] = sigmoid_f(v[0]);
@@ -174,20 +174,20 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                 for (int e = 0; e < 4; ++e) sw.elem(ACT_ROW_EMB + e, (float)EMB[e]);
             }
             U T1[QKG], T2[QKG];
-            run_layer<P, SLOT, HKG + 1, 4, FwdG<P, HKG + 1, 4>::G, true, NST_T>(ws, mid, lane, h,
+            run_layer<P, SLOT, HKG + 1, 4, true, NST_T>(ws, mid, lane, h,
                 [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : EMB; },
                 [&](int mt, const f32x16& v, int s) { relu_epi_t(T1, ACT_ROW_T1, mt, v, s); });
             if constexpr (TSAVE) save_mask(9, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },
+            run_layer<P, SLOT, QKG, 4, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },
                 [&](int mt, const f32x16& v, int s) { relu_epi_t(T2, ACT_ROW_T1 + 128, mt, v, s); });
             if constexpr (TSAVE) save_mask(10, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T2[kg]; },
+            run_layer<P, SLOT, QKG, 4, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T2[kg]; },
                 [&](int mt, const f32x16& v, int s) { relu_epi_t(T1, ACT_ROW_T1 + 256, mt, v, s); });
             if constexpr (TSAVE) save_mask(11, 2);
-            run_layer<P, SLOT, QKG, 4, FwdG<P, QKG, 4>::G, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },
+            run_layer<P, SLOT, QKG, 4, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },
                 [&](int mt, const f32x16& v, int s) { relu_epi_t(T2, ACT_ROW_T1 + 384, mt, v, s); });
             if constexpr (TSAVE) save_mask(12, 2);
-            run_layer<P, SLOT, QKG, 1, 1, true>(ws, mid, lane, h, [&](int kg) { return T2[kg]; },
+            run_layer<P, SLOT, QKG, 1, true>(ws, mid, lane, h, [&](int kg) { return T2[kg]; },
                 [&](int, const f32x16& v, int s) {
                     if (s == 0 && h == 0 && live) { a.ts[p] = sigmoid_f(v[0]); a.tb[p] = softplus_f(v[1]); }
                 });

@@ -56,14 +56,14 @@ int enc_col_of_slot(bool bf16, int slot) {
 }
 
 void append_layer(PackedStream& s, bool bf16, const PackLayer& L) {
-    const int G = pick_group(bf16, L.KG, L.MT);
     const int ne = bf16 ? 8 : 4, esz = bf16 ? 2 : 4;
-    for (int mg = 0; mg < L.MT / G; ++mg) {
+    for (int mg = 0; mg < n_groups(L.KG, L.MT); ++mg) {          // the chunk grouping run_layer walks (eonerf_common.h)
+        const int G = group_size(L.KG, L.MT, mg), m0 = group_start(L.KG, L.MT, mg);
         const uint32_t off = (uint32_t)s.bytes;
         const uint32_t bytes = (uint32_t)(G * (L.KG * 1024 + 128));
         s.chunks.push_back(ChunkDesc{off, bytes});
         for (int g = 0; g < G; ++g) {
-            const int mt = mg * G + g;
+            const int mt = m0 + g;
             for (int kg = 0; kg < L.KG; ++kg)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int r = lane & 31, h = lane >> 5;
