@@ -22,7 +22,7 @@ def take(nbytes):
     off = (off + 255) & ~255
     p = off; off += nbytes
     return p
-take(4 * n); take(4 * n); take(16); take(4 * n * 12); take(4 * n * 12); take(4 * n * 160)
+take(4 * n); take(4 * n); take(16); take(4 * n * 12); take(4 * n * 12); take(4 * n * 160); take(4 * 2 * 128 * 256)
 take(4 * n); take(4 * (n + 1)); o_npts = take(16)
 for _ in range(5): take(4 * p_cap)
 take(4 * p_cap); take(4 * p_cap); take(12 * p_cap); take(4 * p_cap); take(4 * p_cap)
@@ -35,16 +35,18 @@ act = ws[o_act:o_act + 3040 * p_cap * 2].view(torch.bfloat16).view(-1, 32)
 def block(slab, S, R):
     return slab[S * NT:(S + R) * NT].view(NT, R, 32).float()          # [tile][row][sample]
 live_tiles = (n_pts + 255) // 256 * 8
-for name, slab, S, R in (("dY7", grd, 1792, 256), ("dY6", grd, 1536, 256), ("dT4", grd, 2880, 128), ("dT3", grd, 2752, 128), ("dA1", grd, 2336, 128),
+for name, slab, S, R in (("dY7", grd, 1792, 256), ("dY6", grd, 1536, 256), ("dY1", grd, 256, 256), ("dY0", grd, 0, 256), ("dA1", grd, 2336, 128),
+                         ("X1", act, 64, 256), ("X2", act, 64 + 256, 256),
                          ("X7", act, 64 + 256 * 6, 256), ("T3", act, 2496 + 256, 128)):
     b = block(slab, S, R)[:live_tiles]
     bad = ~torch.isfinite(b) | (b.abs() > 1e4)
     print(f"{name}: tiles {live_tiles} bad elems {int(bad.sum())}  bad tiles {bad.any(dim=2).any(dim=1).nonzero().flatten().tolist()[:20]}"
           f"  bad rows {bad.any(dim=2).any(dim=0).nonzero().flatten().tolist()[:40]}  max|finite| {b[~bad].abs().max().item():.3e}")
-b = block(grd, 2880, 128)[:live_tiles]
+b = block(grd, 2336, 128)[:live_tiles]
 bad = ~torch.isfinite(b) | (b.abs() > 1e4)
-t0 = bad.any(dim=2).any(dim=1).nonzero().flatten().tolist()[:3]
+t0 = bad.any(dim=2).any(dim=1).nonzero().flatten().tolist()[:2]
 for t in t0:
-    print("tile", t, "first sample", t * 32, "live" if t * 32 < n_pts else "DEAD")
-    for r in (27, 28, 29, 30, 31, 59, 60, 61, 62, 63, 92, 124):
+    print("tile", t, "first sample", t * 32, "live" if t * 32 < n_pts else "DEAD", "bad rows", bad[t].any(dim=1).nonzero().flatten().tolist()[:48])
+    r0 = bad[t].any(dim=1).nonzero().flatten().tolist()[0]
+    for r in (r0, r0 + 1):
         print("  row", r, " ".join(f"{v:9.2e}" for v in b[t, r].tolist()[:32]))
