@@ -19,7 +19,9 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_param_info", "eonerf_param_floats", "eonerf_set_weights", "eonerf_field_workspace_bytes",
            "eonerf_render_workspace_bytes", "eonerf_field_forward", "eonerf_query_density", "eonerf_render_forward",
            "eonerf_render_backward", "eonerf_adam_step", "eonerf_profile_enable", "eonerf_profile_read",
-           "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering", "eonerf_generate_rays"]
+           "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering", "eonerf_generate_rays",
+           "eonerf_adam_step_late", "eonerf_param_is_late", "eonerf_field_train_workspace_bytes", "eonerf_field_forward_train",
+           "eonerf_field_backward", "eonerf_set_noise_seed"]
 
 
 class EonerfRpc(C.Structure):
@@ -77,10 +79,17 @@ def lib():
     L.eonerf_render_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_render_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp]
+    L.eonerf_adam_step_late.argtypes = [vp, vp, vp, vp, vp, i, i, fp, fp, fp, fp, fp, vp]
+    L.eonerf_param_is_late.argtypes = [vp, i]
+    L.eonerf_field_train_workspace_bytes.restype = sz
+    L.eonerf_field_train_workspace_bytes.argtypes = [vp, i, i]
+    L.eonerf_field_forward_train.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.eonerf_field_backward.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_train_loss.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
     L.eonerf_generate_rays.argtypes = [C.POINTER(EonerfRpc), vp, vp, C.c_long, i, C.c_double, C.c_double, i, i, C.c_double, C.c_double,
                                        C.POINTER(fp), C.POINTER(fp), vp, vp, vp]
-    L.eonerf_sample_rays.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.eonerf_sample_rays.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.eonerf_set_noise_seed.argtypes = [vp, C.c_uint64]
     L.eonerf_rendering.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_profile_enable.argtypes = [vp, i]
     L.eonerf_profile_read.argtypes = [vp, i, C.POINTER(fp), C.POINTER(i)]
@@ -93,6 +102,12 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError(f"libeonerf_hip: {lib().eonerf_strerror(rc).decode()} (code {rc})")
+
+
+def late_param_names(ctx):
+    """Names of the tensors whose Adam step starts counting when the shadow pass switches on (eonerf_adam_step_late)."""
+    L = lib()
+    return {name for k, (name, _, _, _) in enumerate(param_layout(ctx)) if L.eonerf_param_is_late(ctx, k) == 1}
 
 
 def param_layout(ctx):

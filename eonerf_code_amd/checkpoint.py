@@ -12,27 +12,32 @@ import torch
 
 
 def occ_grid_state_dict(resolution=128):
-    """State of nerfacc.OccGridEstimator(roi_aabb=[-1,-1,-1,1,1,1], resolution, levels=1) with everything marked occupied.
-    (key names as of nerfacc v0.5.2; the grid is output-irrelevant in the reference)"""
+    """state_dict() of nerfacc.OccGridEstimator(roi_aabb=[-1,-1,-1,1,1,1], resolution, levels=1) with everything marked
+    occupied: the four PERSISTENT buffers of nerfacc v0.5.2 (setup_env.sh:10) -- `grid_coords` / `grid_indices` are registered
+    with persistent=False there and must not appear, or eval_eonerf.py:71's strict load_state_dict rejects the file.
+    (The grid is output-irrelevant in the reference)"""
     r = int(resolution)
     return {"resolution": torch.tensor([r, r, r], dtype=torch.int32),
             "aabbs": torch.tensor([[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]]),
             "occs": torch.zeros(r ** 3),
-            "binaries": torch.ones(1, r, r, r, dtype=torch.bool),
-            "grid_coords": torch.stack(torch.meshgrid(*[torch.arange(r)] * 3, indexing="ij"), -1).reshape(-1, 3),
-            "grid_indices": torch.arange(r ** 3)}
+            "binaries": torch.ones(1, r, r, r, dtype=torch.bool)}
 
 
-def adam_state_dict(field, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8):
-    """torch.optim.Adam.state_dict() equivalent built from the flat moment buffers of FusedTrainer."""
+def adam_state_dict(field, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, step_late=None, late_names=()):
+    """torch.optim.Adam.state_dict() equivalent built from the flat moment buffers of FusedTrainer.  Parameters in
+    `late_names` (transient embedding / head, ambient head: grad None in the reference while epoch_idx < 2) carry their own
+    step count `step_late`, and NO state entry while it is 0 -- exactly what torch.optim.Adam holds for them."""
     by_name = {name: (off, r, c) for name, off, r, c in field._layout}
     state, ids = {}, []
     for i, (name, p) in enumerate(field.named_parameters()):
+        ids.append(i)
+        st = step_late if (step_late is not None and name in late_names) else step
+        if st == 0:
+            continue
         off, r, c = by_name[name]
-        state[i] = {"step": torch.tensor(float(step)),
+        state[i] = {"step": torch.tensor(float(st)),
                     "exp_avg": exp_avg[off:off + r * c].view(p.shape).detach().cpu().clone(),
                     "exp_avg_sq": exp_avg_sq[off:off + r * c].view(p.shape).detach().cpu().clone()}
-        ids.append(i)
     group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
              "capturable": False, "differentiable": False, "fused": None, "params": ids}
     return {"state": state, "param_groups": [group]}
@@ -43,7 +48,8 @@ def save_checkpoint(path, epoch, field, trainer=None, loss=None, grid_resolution
     ckpt = {"epoch": epoch, "occ_grid_state_dict": occ_grid_state_dict(grid_resolution),
             "model_state_dict": {k: v.detach().cpu() for k, v in field.state_dict().items()},
             "optimizer_state_dict": (adam_state_dict(field, trainer.exp_avg, trainer.exp_avg_sq, trainer.step_count, trainer.lr,
-                                                     trainer.betas, trainer.eps) if trainer is not None else None),
+                                                     trainer.betas, trainer.eps, getattr(trainer, "step_late", None),
+                                                     getattr(trainer, "late_names", ())) if trainer is not None else None),
             "loss": None if loss is None else torch.as_tensor(loss).detach().cpu()}
     torch.save(ckpt, path)
     return path
@@ -56,11 +62,15 @@ def load_checkpoint(path, field, trainer=None, map_location="cpu"):
     if trainer is not None and ckpt.get("optimizer_state_dict"):
         by_name = {name: (off, r, c) for name, off, r, c in field._layout}
         st = ckpt["optimizer_state_dict"]["state"]
+        late_names = getattr(trainer, "late_names", ())
+        steps, steps_late = [0], [0]
         for i, (name, p) in enumerate(field.named_parameters()):
             if i in st:
                 off, r, c = by_name[name]
                 trainer.exp_avg[off:off + r * c].copy_(st[i]["exp_avg"].reshape(-1))
                 trainer.exp_avg_sq[off:off + r * c].copy_(st[i]["exp_avg_sq"].reshape(-1))
-                trainer.step_count = int(float(st[i]["step"]))
+                (steps_late if name in late_names else steps).append(int(float(st[i]["step"])))
+        trainer.step_count = max(steps)
+        trainer.step_late = max(steps_late) if late_names else trainer.step_count
         trainer.lr = ckpt["optimizer_state_dict"]["param_groups"][0]["lr"]
     return ckpt["epoch"]

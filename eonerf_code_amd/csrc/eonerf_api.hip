@@ -59,7 +59,9 @@ struct eonerf_ctx {
     int n_cu;
     int wgrad_items;      // target number of weight-gradient work items per launch (EONERF_WGRAD_ITEMS, default 48 per job)
     ParamLayout pl;
-    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb;
+    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig;
+    uint64_t noise_seed = 0x5eed5eedULL; uint32_t noise_call = 0;   // in-kernel Philox jitter (eonerf_set_noise_seed)
+    bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
     bool weights_set = false;
     bool dens_dirty = false;         // density-only streams are re-packed lazily (only the shadow pass reads them)
@@ -203,6 +205,79 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, mode, grid, st);
 }
 
+
+// Weight gradients of up to two MLP passes in ONE split-K launch (eonerf_wgrad.hip) + the bottleneck factor product:
+//   full: a pass through the whole field (camera pass / EONerfMLP.forward), with or without the transient head in the graph;
+//   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
+int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
+                         const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st) {
+    const ParamLayout& pl = ctx->pl;
+    auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
+    WgradJobTable tab;
+    tab.n = 0;
+    const size_t n_tiles = (size_t)p_cap / (ctx->bf16 ? 32 : 16);      // sample tiles of the slabs (block-major layout, eonerf_common.h)
+    auto seg0 = [&](const void* slab, SlabBlk blk, int row) {           // (row, sample tile 0)
+        return reinterpret_cast<const uint8_t*>(slab) + ((size_t)blk.s * n_tiles + (row - blk.s)) * SEG_B;
+    };
+    auto add = [&](const PassBuffers& b, int grd_row, int m_rows, int act_row, int n_rows, float* dw, int dw_ld, float* db,
+                   const int* cmap, int gm, int gn, int wm, int wn) {
+        WgradJob& j = tab.j[tab.n++];
+        const SlabBlk ba = GrdMap::block(grd_row), bb = ActMap::block(act_row);
+        j.a = seg0(b.grd, ba, grd_row); j.b = seg0(b.act, bb, act_row); j.dw = dw; j.db = db; j.col_map = cmap; j.n_pts = b.n_pts;
+        j.a_stride = (uint32_t)(ba.r * SEG_B);       // consecutive sample tiles of a block are contiguous
+        j.b_stride = (uint32_t)(bb.r * SEG_B);
+        j.m_rows = m_rows; j.n_rows = n_rows; j.dw_ld = dw_ld; j.gm = gm; j.gn = gn; j.wm = wm; j.wn = wn;
+    };
+    auto trunk_jobs = [&](const PassBuffers& b) {
+        add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
+        for (int l = 1; l < 8; ++l) {
+            const int in_ld = l == 5 ? 319 : 256;
+            add(b, GRD_ROW_Y0 + 256 * l, 256, ACT_ROW_X1 + 256 * (l - 1), 256, dptr(pl.trunk_w[l]), in_ld, dptr(pl.trunk_b[l]), nullptr, 2, 4, 4, 2);
+            if (l == 5)   // skip columns 256..318 <- encoding slots
+                add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1);
+        }
+        add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
+    };
+    if (full) {
+        const PassBuffers& c = *full;
+        trunk_jobs(c);
+        // bottleneck layer: factor M_a = dA1^T X8 (and M_t = dT1^T X8), finished by eo_launch_bott_wgrad below
+        HIP_TRY(hipMemsetAsync(m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
+        add(c, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, nullptr, nullptr, 2, 4, 2, 2);
+        if (transient) add(c, GRD_ROW_T1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott + 128 * 256, 256, nullptr, nullptr, 2, 4, 2, 2);
+        add(c, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
+        add(c, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
+        if (transient) {
+            add(c, GRD_ROW_T1, 128, ACT_ROW_BOTT, 256, dptr(pl.t_w[0]), 260, dptr(pl.t_b[0]), nullptr, 2, 4, 2, 2);
+            add(c, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
+            for (int l = 1; l < 4; ++l)
+                add(c, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
+            add(c, GRD_ROW_T5, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);
+            add(c, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
+        }
+    }
+    if (dens) trunk_jobs(*dens);
+    // every work item = one slice of one job's sample range.  Equal slices: a K step costs about the same for every job shape
+    // (the loop is latency-bound); default 48 slices per job (measured: flat from ~2.4 to 6.5 items per CU, clearly slower below 2)
+    tab.items = 0;
+    for (int k = 0; k < tab.n; ++k) {
+        WgradJob& j = tab.j[k];
+        const int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : 48;
+        j.slices = sl < 1 ? 1 : sl;
+        j.item0 = tab.items;
+        tab.items += j.slices;
+    }
+    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st)); }
+    if (full) {   // bottleneck layer: dW = W_A1^T M_a (+ W_T1^T M_t) from the two factors the GEMM above accumulated
+        BottWgradArgs bw;
+        bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_a1 = dptr(pl.a1_b);
+        bw.w_t1 = transient ? flat + pl.t[pl.t_w[0]].offset : nullptr; bw.m_t = m_bott + 128 * 256; bw.db_t1 = transient ? dptr(pl.t_b[0]) : nullptr;
+        bw.d_w = dptr(pl.bot_w); bw.d_b = dptr(pl.bot_b);
+        HIP_TRY(eo_launch_bott_wgrad(bw, st));
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -239,6 +314,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     if (!rc) rc = upload(ctx->bwd_full, build_bwd_stream(ctx->pl, ctx->bf16, true, false));
     if (!rc) rc = upload(ctx->bwd_dens, build_bwd_stream(ctx->pl, ctx->bf16, false, true));
     if (!rc) rc = upload(ctx->bwd_rgb, build_bwd_stream(ctx->pl, ctx->bf16, true, false, false));
+    if (!rc) rc = upload(ctx->bwd_full_ig, build_bwd_stream(ctx->pl, ctx->bf16, true, true, true));
     if (!rc) {
         int cm[64];
         for (int s = 0; s < 64; ++s) cm[s] = enc_col_of_slot(ctx->bf16, s);
@@ -280,7 +356,7 @@ int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launc
 int eonerf_destroy(eonerf_ctx* ctx) {
     if (!ctx) return EONERF_E_ARG;
     for (int k = 0; k < 5; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
-    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb);
+    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     delete ctx;
     return EONERF_OK;
@@ -302,7 +378,7 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     if (!ctx || !flat) return EONERF_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int rc = pack({&ctx->fwd_full, &ctx->bwd_full, &ctx->bwd_rgb}, flat, st);
-    if (!rc) { ctx->weights_set = true; ctx->dens_dirty = true; }
+    if (!rc) { ctx->weights_set = true; ctx->dens_dirty = true; ctx->full_ig_dirty = true; }
     return rc;
 }
 
@@ -358,6 +434,91 @@ int eonerf_query_density(eonerf_ctx* ctx, const float* flat, const float* xyz, i
     return EONERF_OK;
 }
 
+// ---- differentiable EONerfMLP.forward / query_density (radiance_fields/eonerf.py:141-170 under autograd) ----------------
+namespace {
+struct FieldTrainWs { PassBuffers b; float* m_bott; int* queue; size_t bytes; };
+FieldTrainWs carve_field_train(const eonerf_ctx* ctx, void* base, int p_cap, bool full) {
+    Carver c(base);
+    FieldTrainWs w;
+    carve_pass(c, w.b, 1, p_cap, full, true, true, ctx->bf16 ? 2 : 4);
+    w.m_bott = c.take<float>(2 * 128 * 256);
+    w.queue = c.take<int>(4);
+    w.bytes = c.off + 256;
+    return w;
+}
+}  // namespace
+
+size_t eonerf_field_train_workspace_bytes(const eonerf_ctx* ctx, int n_points, int density_only) {
+    if (!ctx || n_points < 0) return 0;
+    return carve_field_train(ctx, nullptr, round_up(std::max(n_points, 1), 256), !density_only).bytes;
+}
+
+int eonerf_field_forward_train(eonerf_ctx* ctx, const float* flat, const float* xyz, const float* sun, const int64_t* img, int n,
+                               int density_only, float* sigma, float* albedo, float* ambient, float* ts, float* tb,
+                               void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx || !flat || !xyz || !sigma || n < 0 || !ws) return EONERF_E_ARG;
+    if (!density_only && (!sun || !img || !albedo || !ambient || !ts || !tb)) return EONERF_E_ARG;
+    if (!ctx->weights_set) return EONERF_E_STATE;
+    if (n == 0) return EONERF_OK;
+    const int p_cap = round_up(n, 256);
+    const bool full = !density_only;
+    FieldTrainWs w = carve_field_train(ctx, ws, p_cap, full);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    HIP_TRY(eo_launch_points_to_soa(xyz, full ? img : nullptr, n, p_cap, w.b.px, w.b.py, w.b.pz, w.b.simg, w.b.n_pts, st));
+    int rc = run_mlp_fwd(ctx, w.b, flat, p_cap, full, 1, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(sigma, w.b.sigma, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (!full) return EONERF_OK;
+    HIP_TRY(hipMemcpyAsync(ts, w.b.ts, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(tb, w.b.tb, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(eo_launch_soa3_to_aos(w.b.albedo, p_cap, n, albedo, st));
+    return (int)eo_launch_ambient_points(ambient_w(ctx, flat), sun, n, ambient, st);
+}
+
+int eonerf_field_backward(eonerf_ctx* ctx, const float* flat, const float* sun, int n, int density_only,
+                          const float* g_sigma, const float* g_albedo, const float* g_ambient, const float* g_ts, const float* g_tb,
+                          float* d_flat, float* d_xyz, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx || !flat || !d_flat || n < 0 || !ws) return EONERF_E_ARG;
+    if (!density_only && g_ambient && !sun) return EONERF_E_ARG;
+    if (!ctx->weights_set) return EONERF_E_STATE;
+    if (n == 0) return EONERF_OK;
+    const int p_cap = round_up(n, 256);
+    const bool full = !density_only;
+    FieldTrainWs w = carve_field_train(ctx, ws, p_cap, full);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    const ParamLayout& pl = ctx->pl;
+    PassBuffers& b = w.b;
+    HIP_TRY(eo_launch_field_grads_to_soa(g_sigma, g_albedo, g_ts, g_tb, n, p_cap, b.g_sigma, b.g_albedo, b.g_ts, b.g_tb, st));
+    if (full && ctx->full_ig_dirty) {
+        const int rc = pack({&ctx->bwd_full_ig}, flat, st);
+        if (rc) return rc;
+        ctx->full_ig_dirty = false;
+    }
+    if (!full) { const int rc = ensure_density_streams(ctx, flat, st); if (rc) return rc; }
+    const DevStream& bs = full ? ctx->bwd_full_ig : ctx->bwd_dens;
+    MlpBwdArgs m;
+    memset(&m, 0, sizeof(m));
+    m.n_pts = b.n_pts; m.p_pad = p_cap;
+    m.stream = bs.data; m.chunks = bs.chunks; m.n_chunks = bs.n_chunks;
+    m.sigma = b.sigma; m.albedo = b.albedo; m.ts = b.ts; m.tb = b.tb;
+    m.g_sigma = b.g_sigma; m.g_albedo = b.g_albedo; m.g_ts = b.g_ts; m.g_tb = b.g_tb;
+    m.masks = b.masks; m.grd = b.grd; m.g_emb = b.g_emb;
+    m.px = b.px; m.py = b.py; m.pz = b.pz; m.g_pos = b.g_pos;
+    const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
+    HIP_TRY(eo_launch_mlp_bwd(m, ctx->bf16, full, true, full, std::min(ctx->n_cu, p_cap / tile), st));
+    const int rc = run_weight_gradients(ctx, flat, d_flat, full ? &b : nullptr, true, full ? nullptr : &b, p_cap, w.m_bott, w.queue, st);
+    if (rc) return rc;
+    if (d_xyz) HIP_TRY(eo_launch_soa3_to_aos(b.g_pos, p_cap, n, d_xyz, st));
+    if (!full) return EONERF_OK;
+    HIP_TRY(eo_launch_emb_grad_points(b.g_emb, b.simg, n, d_flat + pl.t[pl.emb].offset, st));
+    if (g_ambient)
+        HIP_TRY(eo_launch_ambient_points_bwd(ambient_w(ctx, flat), sun, g_ambient, n, d_flat + pl.t[pl.am1_w].offset, d_flat + pl.t[pl.am1_b].offset,
+                                             d_flat + pl.t[pl.am2_w].offset, d_flat + pl.t[pl.am2_b].offset, st));
+    return EONERF_OK;
+}
+
 int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double* rows, long n, int width,
                          double min_alt, double max_alt, int utm_zone, int south,
                          double sun_elevation_deg, double sun_azimuth_deg, const float offset[3], const float scale[3],
@@ -391,18 +552,25 @@ int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double
     return (int)eo_launch_raygen(a, (hipStream_t)stream);
 }
 
-int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, const float* u, int n_rays,
+int eonerf_set_noise_seed(eonerf_ctx* ctx, uint64_t seed) {
+    if (!ctx) return EONERF_E_ARG;
+    ctx->noise_seed = seed; ctx->noise_call = 0;
+    return EONERF_OK;
+}
+
+int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, const float* u, int perturb, int n_rays,
                        int64_t* ray_indices, float* t_starts, float* t_ends, float* pts_per_ray, int* n_dev,
                        void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_rays == 0) return EONERF_OK;
-    if (!ctx || !rays || !zsteps || !u || !ray_indices || !t_starts || !t_ends || n_rays < 0 || !ws) return EONERF_E_ARG;
+    if (!ctx || !rays || !zsteps || !ray_indices || !t_starts || !t_ends || n_rays < 0 || !ws) return EONERF_E_ARG;
     RenderWs w = carve_render(ctx, ws, n_rays, EONERF_F_ONLY_DEPTH);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * sizeof(int), st));
     SampleArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.rays = rays; sa.zsteps = zsteps; sa.u = u; sa.n_rays = n_rays;
+    sa.rays = rays; sa.zsteps = zsteps; sa.u = u; sa.n_rays = n_rays; sa.perturb = perturb ? 1 : 0;
+    if (perturb && !u) { sa.seed = ctx->noise_seed; sa.call = ctx->noise_call++; }
     sa.cnt_first = w.cnt_first; sa.cnt_retry = w.cnt_retry; sa.counts = w.cam.counts; sa.offsets = w.cam.offsets;
     sa.flags = w.flags; sa.n_pts = w.cam.n_pts;
     sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
@@ -449,12 +617,13 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
                           int n_rays, int flags, float* out, int* n_samples_dev,
                           void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!ctx || !flat || !rays || !img_idx || !zsteps || !u_cam || !out || n_rays < 0 || !ws) return EONERF_E_ARG;
+    if (!ctx || !flat || !rays || !img_idx || !zsteps || !out || n_rays < 0 || !ws) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n_rays == 0) return EONERF_OK;
     const bool shadows = (flags & EONERF_F_SHADOWS) && !(flags & EONERF_F_ONLY_DEPTH);
     const bool train = flags & EONERF_F_TRAIN, od = flags & EONERF_F_ONLY_DEPTH;
-    if (shadows && !u_sun) return EONERF_E_ARG;
+    const bool philox = u_cam == nullptr;       // production: no noise buffers, the sampler draws its own jitter
+    if (philox ? (u_retry || u_sun) : (shadows && !u_sun)) return EONERF_E_ARG;
     if (train && od) return EONERF_E_UNSUPPORTED;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
@@ -465,6 +634,8 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     SampleArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.rays = rays; sa.img_idx = img_idx; sa.zsteps = zsteps; sa.u = u_cam; sa.u_retry = u_retry;
+    sa.perturb = 1; sa.retry = (philox || u_retry) ? 1 : 0;
+    if (philox) { sa.seed = ctx->noise_seed; sa.call = ctx->noise_call++; }
     sa.n_rays = n_rays; sa.sun_pass = 0; sa.patch_last = 1;
     sa.cnt_first = w.cnt_first; sa.cnt_retry = w.cnt_retry; sa.counts = w.cam.counts; sa.offsets = w.cam.offsets;
     sa.flags = w.flags; sa.n_pts = w.cam.n_pts;
@@ -484,7 +655,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     // ---- sun pass: shadow rays from the rendered surface toward the sun -----------------------------------
     if (shadows) {
         SampleArgs ss = sa;
-        ss.img_idx = nullptr; ss.u = u_sun; ss.u_retry = nullptr;
+        ss.img_idx = nullptr; ss.u = u_sun; ss.u_retry = nullptr; ss.retry = 0;
         ss.depth = w.ray_rec + RR_DEPTH; ss.depth_stride = RAY_REC; ss.sun_pass = 1; ss.patch_last = 0;
         ss.cnt_first = w.sun.counts; ss.cnt_retry = w.cnt_retry; ss.counts = w.sun.counts; ss.offsets = w.sun.offsets;
         ss.n_pts = w.sun.n_pts;
@@ -572,76 +743,9 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
     { ProfScope ps(ctx, 1, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st)); }
 
-    // ---- weight gradients: every layer of both passes in one split-K launch -------------------------------
-    WgradJobTable tab;
-    tab.n = 0;
-    std::vector<int> weight;
-    const size_t n_tiles = (size_t)p_cap / (ctx->bf16 ? 32 : 16);      // sample tiles of the slabs (block-major layout, eonerf_common.h)
-    auto seg0 = [&](const void* slab, SlabBlk blk, int row) {           // (row, sample tile 0)
-        return reinterpret_cast<const uint8_t*>(slab) + ((size_t)blk.s * n_tiles + (row - blk.s)) * SEG_B;
-    };
-    auto add = [&](const PassBuffers& b, int grd_row, int m_rows, int act_row, int n_rows, float* dw, int dw_ld, float* db,
-                   const int* cmap, int gm, int gn, int wm, int wn) {
-        WgradJob& j = tab.j[tab.n++];
-        const SlabBlk ba = GrdMap::block(grd_row), bb = ActMap::block(act_row);
-        j.a = seg0(b.grd, ba, grd_row); j.b = seg0(b.act, bb, act_row); j.dw = dw; j.db = db; j.col_map = cmap; j.n_pts = b.n_pts;
-        j.a_stride = (uint32_t)(ba.r * SEG_B);       // consecutive sample tiles of a block are contiguous
-        j.b_stride = (uint32_t)(bb.r * SEG_B);
-        j.m_rows = m_rows; j.n_rows = n_rows; j.dw_ld = dw_ld; j.gm = gm; j.gn = gn; j.wm = wm; j.wn = wn;
-        weight.push_back(1);      // measured: a K step costs about the same for every job shape (the loop is latency-bound), so equal slices          // ~ cost of one K step: operand rows fetched + a fixed part
-    };
-    auto trunk_jobs = [&](const PassBuffers& b) {
-        add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
-        for (int l = 1; l < 8; ++l) {
-            const int in_ld = l == 5 ? 319 : 256;
-            add(b, GRD_ROW_Y0 + 256 * l, 256, ACT_ROW_X1 + 256 * (l - 1), 256, dptr(pl.trunk_w[l]), in_ld, dptr(pl.trunk_b[l]), nullptr, 2, 4, 4, 2);
-            if (l == 5)   // skip columns 256..318 <- encoding slots
-                add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1);
-        }
-        add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
-    };
-    trunk_jobs(w.cam);
-    // bottleneck layer: factor M_a = dA1^T X8 (and M_t = dT1^T X8), finished by eo_launch_bott_wgrad below
-    HIP_TRY(hipMemsetAsync(w.m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
-    add(w.cam, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, w.m_bott, 256, nullptr, nullptr, 2, 4, 2, 2);
-    if (transient) add(w.cam, GRD_ROW_T1, 128, ACT_ROW_X1 + 256 * 7, 256, w.m_bott + 128 * 256, 256, nullptr, nullptr, 2, 4, 2, 2);
-    add(w.cam, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
-    add(w.cam, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
-    if (transient) {
-        add(w.cam, GRD_ROW_T1, 128, ACT_ROW_BOTT, 256, dptr(pl.t_w[0]), 260, dptr(pl.t_b[0]), nullptr, 2, 4, 2, 2);
-        add(w.cam, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
-        for (int l = 1; l < 4; ++l)
-            add(w.cam, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
-        add(w.cam, GRD_ROW_T5, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);
-        add(w.cam, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
-    }
-    if (shadows) trunk_jobs(w.sun);
-    // heaviest jobs first (longest-processing-time order for the work queue)
-    std::vector<int> order(tab.n);
-    for (int k = 0; k < tab.n; ++k) order[k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight[x] > weight[y]; });
-    // every work item = one slice of one job's sample range; slices in proportion to the job's cost per K step
-    WgradJobTable sorted;
-    sorted.n = tab.n; sorted.items = 0;
-    long long total = 0;
-    for (int k = 0; k < tab.n; ++k) total += weight[k];
-    for (int k = 0; k < tab.n; ++k) {
-        WgradJob& j = sorted.j[k];
-        j = tab.j[order[k]];
-        // default: 48 slices per job (measured: flat from ~2.4 to 6.5 items per CU, clearly slower below 2)
-        int sl = ctx->wgrad_items ? (int)(((long long)ctx->wgrad_items * weight[order[k]] + total / 2) / total) : 48;
-        j.slices = sl < 1 ? 1 : sl;
-        j.item0 = sorted.items;
-        sorted.items += j.slices;
-    }
-    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(sorted, ctx->n_cu, p_cap, w.flags + 2, ctx->bf16, st)); }
-
-    {   // bottleneck layer: dW = W_A1^T M_a (+ W_T1^T M_t) from the two factors the GEMM above accumulated
-        BottWgradArgs bw;
-        bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = w.m_bott; bw.db_a1 = dptr(pl.a1_b);
-        bw.w_t1 = transient ? flat + pl.t[pl.t_w[0]].offset : nullptr; bw.m_t = w.m_bott + 128 * 256; bw.db_t1 = transient ? dptr(pl.t_b[0]) : nullptr;
-        bw.d_w = dptr(pl.bot_w); bw.d_b = dptr(pl.bot_b);
-        HIP_TRY(eo_launch_bott_wgrad(bw, st));
+    {
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.flags + 2, st);
+        if (rcw) return rcw;
     }
 
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
@@ -663,12 +767,31 @@ int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, in
     return (int)eo_launch_loss(out, pixels, n_rays, kind, d_out, loss, (hipStream_t)stream);
 }
 
+static int adam_common(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
+                       int step, int step_late, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!ctx || !flat || !d_flat || !exp_avg || !exp_avg_sq || step < 1 || step_late < 0 || step_late > step) return EONERF_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const ParamLayout& pl = ctx->pl;
+    // "late" parameters (outside the reference's autograd graph while epoch_idx < 2): the transient embedding, and the
+    // transient head + ambient head, which are contiguous at the end of the flat buffer (ParamLayout::build)
+    const size_t late[4] = {pl.t[pl.emb].offset, pl.t[pl.rad].offset, pl.t[pl.t_w[0]].offset, pl.total};
+    HIP_TRY(eo_launch_adam(flat, d_flat, exp_avg, exp_avg_sq, pl.total, step, step_late, late, lr, beta1, beta2, eps, grad_scale, st));
+    return eonerf_set_weights(ctx, flat, stream);
+}
+
 int eonerf_adam_step(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
                      int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
-    if (!ctx || !flat || !d_flat || !exp_avg || !exp_avg_sq || step < 1) return EONERF_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(eo_launch_adam(flat, d_flat, exp_avg, exp_avg_sq, ctx->pl.total, step, lr, beta1, beta2, eps, grad_scale, st));
-    return eonerf_set_weights(ctx, flat, stream);
+    return adam_common(ctx, flat, d_flat, exp_avg, exp_avg_sq, step, step, lr, beta1, beta2, eps, grad_scale, stream);
+}
+
+int eonerf_adam_step_late(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
+                          int step, int step_late, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    return adam_common(ctx, flat, d_flat, exp_avg, exp_avg_sq, step, step_late, lr, beta1, beta2, eps, grad_scale, stream);
+}
+
+int eonerf_param_is_late(const eonerf_ctx* ctx, int index) {
+    if (!ctx || index < 0 || index >= (int)ctx->pl.t.size()) return EONERF_E_ARG;
+    return (index == ctx->pl.emb || index >= ctx->pl.t_w[0]) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -224,18 +224,20 @@ hipError_t launch(const MlpBwdArgs& a, int grid, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <class P> hipError_t dispatch(const MlpBwdArgs& a, bool full, bool transient, int grid, hipStream_t st) {
+template <class P> hipError_t dispatch(const MlpBwdArgs& a, bool full, bool input_grad, bool transient, int grid, hipStream_t st) {
     if (!full) return launch<P, false, true, false>(a, grid, st);
+    if (input_grad) return launch<P, true, true, true>(a, grid, st);
     return transient ? launch<P, true, false, true>(a, grid, st) : launch<P, true, false, false>(a, grid, st);
 }
 
 }  // namespace
 
-// the variants the render path needs: camera pass (all heads, with / without the transient head in the graph, no input
-// grad) and shadow pass (density only, with input grad)
+// the variants the callers need: camera pass (all heads, with / without the transient head in the graph, no input grad),
+// shadow pass / query_density (density only, with input grad) and the differentiable EONerfMLP.forward (all heads + input grad)
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st) {
-    if (full == input_grad) return hipErrorInvalidValue;
-    return bf16 ? dispatch<PBf16>(a, full, transient, grid, st) : dispatch<PF32>(a, full, transient, grid, st);
+    if (!full && !input_grad) return hipErrorInvalidValue;
+    if (full && input_grad && !transient) return hipErrorInvalidValue;
+    return bf16 ? dispatch<PBf16>(a, full, input_grad, transient, grid, st) : dispatch<PF32>(a, full, input_grad, transient, grid, st);
 }
 
 #ifdef EO_STAMP

@@ -12,8 +12,11 @@ struct SampleArgs {
     const float* rays;        // [R][11] fp32: o3 d3 near far sun3  (datasets/satellite.py:23-26)
     const int64_t* img_idx;   // [R] or nullptr
     const float* zsteps;      // [128] = torch.linspace(0,1,128)
-    const float* u;           // [R][128] jitter of this pass
-    const float* u_retry;     // [R][128] or nullptr: noise of the "some ray is empty -> resample" branch
+    const float* u;           // [R][128] jitter of this pass, or nullptr: drawn in the kernel (Philox4x32-10, seed/call below)
+    const float* u_retry;     // [R][128] noise of the "some ray is empty -> resample" branch (nullptr with retry: Philox)
+    int retry;                // 1: the resample branch exists (camera pass of render_image, sat_rendering.py:260-262)
+    int perturb;              // 0: perturb=False, z_vals stay on the uniform grid (sat_rendering.py:70-71 skipped)
+    uint64_t seed; uint32_t call;   // Philox key and the per-call word of its counter
     const float* depth;       // sun pass: rendered depth per ray
     int depth_stride;
     int n_rays;
@@ -111,10 +114,16 @@ hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st);
+hipError_t eo_launch_field_grads_to_soa(const float* g_sigma, const float* g_albedo, const float* g_ts, const float* g_tb, int n, int p_pad,
+                                       float* o_sigma, float* o_albedo, float* o_ts, float* o_tb, hipStream_t st);
+hipError_t eo_launch_emb_grad_points(const float* g_emb, const int* simg, int n, float* d_emb, hipStream_t st);
+hipError_t eo_launch_ambient_points_bwd(const AmbientW& w, const float* sun, const float* g_amb, int n,
+                                        float* d_w1, float* d_b1, float* d_w2, float* d_b2, hipStream_t st);
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st);
 hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st);
-hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
-                          float gscale, hipStream_t st);
+// late_ranges = {lo0, hi0, lo1, hi1}: flat-index ranges whose Adam step is step_late (0 = skipped), see k_adam
+hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, int step_late, const size_t late_ranges[4],
+                          float lr, float b1, float b2, float eps, float gscale, hipStream_t st);
 hipError_t eo_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 hipError_t eo_launch_shade_fwd(const ShadeArgs& a, hipStream_t st);
 hipError_t eo_launch_points_to_soa(const float* xyz, const int64_t* img, int n, int p_pad, float* px, float* py, float* pz,

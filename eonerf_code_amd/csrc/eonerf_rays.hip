@@ -27,11 +27,33 @@ EO_DEV float zperturbed(const float* zsteps, float near, int i, float u) {
     return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u));       // perturb_z_vals, :46-54
 }
 
-EO_DEV RaySamples sample_ray(const float* zsteps, const float* u_row, float near, float ox, float oy, float oz,
+// ---- jitter source: caller-provided arrays (parity tests, torch.rand) or the in-kernel Philox4x32-10 stream -------------
+//      Philox (Salmon et al. 2011, the generator behind torch.rand on GPUs): counter = (ray, lane, draw, call), key = seed;
+//      one counter gives the lane's two jitters (samples lane and lane + 64); 24 random bits -> [0, 1) fp32, as torch.rand.
+EO_DEV void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+EO_DEV void philox_u2(uint64_t seed, uint32_t ray, uint32_t lane, uint32_t draw, uint32_t call, float& ua, float& ub) {
+    uint32_t c[4] = {ray, lane, draw, call};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    ua = (float)(c[0] >> 8) * 0x1p-24f;
+    ub = (float)(c[1] >> 8) * 0x1p-24f;
+}
+// jitters of samples `lane` and `lane + 64` of draw `draw` (0 camera, 1 camera retry, 2 sun) of ray `ray`
+EO_DEV void jitter2(const SampleArgs& a, const float* u_arr, int draw, int ray, int lane, float& ua, float& ub) {
+    if (u_arr) { ua = u_arr[(size_t)ray * 128 + lane]; ub = u_arr[(size_t)ray * 128 + lane + 64]; }
+    else philox_u2(a.seed, (uint32_t)ray, (uint32_t)lane, (uint32_t)draw, a.call, ua, ub);
+}
+
+EO_DEV RaySamples sample_ray(const float* zsteps, bool perturb, float ua, float ub, float near, float ox, float oy, float oz,
                              float dx, float dy, float dz, int lane) {
     RaySamples s;
-    const float za = zperturbed(zsteps, near, lane, u_row[lane]);
-    const float zb = zperturbed(zsteps, near, lane + 64, u_row[lane + 64]);
+    const float za = perturb ? zperturbed(zsteps, near, lane, ua) : zval(zsteps, near, lane);          // perturb=False: :70-71 skipped
+    const float zb = perturb ? zperturbed(zsteps, near, lane + 64, ub) : zval(zsteps, near, lane + 64);
     float za1 = __shfl_down(za, 1, 64);
     const float zb0 = __shfl(zb, 0, 64);
     if (lane == 63) za1 = zb0;
@@ -77,18 +99,21 @@ __global__ __launch_bounds__(256) void k_count(SampleArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
     const RayGeom g = ray_geom(a, ray);
-    RaySamples s = sample_ray(a.zsteps, a.u + (size_t)ray * 128, g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+    float ua, ub;
+    jitter2(a, a.u, a.sun_pass ? 2 : 0, ray, lane, ua, ub);
+    RaySamples s = sample_ray(a.zsteps, a.perturb, ua, ub, g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
     const int cnt = __popcll(__ballot(s.valid[0])) + __popcll(__ballot(s.valid[1]));
     int cnt_retry = cnt;
-    if (a.u_retry) {
+    if (a.retry) {
         // the reference's retry passes near=None -> zeros (sat_rendering.py:262)
-        RaySamples s2 = sample_ray(a.zsteps, a.u_retry + (size_t)ray * 128, 0.f, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+        jitter2(a, a.u_retry, 1, ray, lane, ua, ub);
+        RaySamples s2 = sample_ray(a.zsteps, a.perturb, ua, ub, 0.f, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
         cnt_retry = __popcll(__ballot(s2.valid[0])) + __popcll(__ballot(s2.valid[1]));
     }
     if (lane == 0) {
         a.cnt_first[ray] = cnt;
         a.cnt_retry[ray] = cnt_retry;
-        if (cnt == 0 && a.u_retry) atomicOr(a.flags, 1);
+        if (cnt == 0 && a.retry) atomicOr(a.flags, 1);
     }
 }
 
@@ -97,7 +122,7 @@ __global__ __launch_bounds__(1024) void k_scan(SampleArgs a) {
     __shared__ int wsum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool retry = a.u_retry && (*a.flags & 1);
+    const bool retry = a.retry && (*a.flags & 1);
     const int* cnt = retry ? a.cnt_retry : a.cnt_first;
     if (tid == 0) carry = 0;
     __syncthreads();
@@ -128,9 +153,10 @@ __global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
     const RayGeom g = ray_geom(a, ray);
-    const bool retry = a.u_retry && (*a.flags & 1);
-    const float* u = (retry ? a.u_retry : a.u) + (size_t)ray * 128;
-    RaySamples s = sample_ray(a.zsteps, u, retry ? 0.f : g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+    const bool retry = a.retry && (*a.flags & 1);
+    float ua, ub;
+    jitter2(a, retry ? a.u_retry : a.u, retry ? 1 : (a.sun_pass ? 2 : 0), ray, lane, ua, ub);
+    RaySamples s = sample_ray(a.zsteps, a.perturb, ua, ub, retry ? 0.f : g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
     const unsigned long long m0 = __ballot(s.valid[0]), m1 = __ballot(s.valid[1]);
     const int n0 = __popcll(m0), n = n0 + __popcll(m1);
     const int off = a.offsets[ray];

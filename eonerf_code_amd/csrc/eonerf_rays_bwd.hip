@@ -200,6 +200,76 @@ __global__ __launch_bounds__(128 * AMB_STREAMS) void k_ambient_bwd(AmbientBwdArg
     for (int o = 0; o < 3; ++o) if (dw2[o] != 0.f) atomicAdd(a.d_w2 + o * 128 + j, dw2[o]);
 }
 
+// ---- differentiable EONerfMLP.forward on caller-provided points (radiance_fields/eonerf.py:154-170): glue around the chains ----
+// upstream gradients of the forward outputs (row-major, as autograd hands them over; any may be null = zero) -> the SoA
+// arrays the backward chain reads
+__global__ void k_field_grads_to_soa(const float* g_sigma, const float* g_albedo, const float* g_ts, const float* g_tb, int n, int p_pad,
+                                     float* o_sigma, float* o_albedo, float* o_ts, float* o_tb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    o_sigma[i] = g_sigma ? g_sigma[i] : 0.f;
+    if (o_albedo) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o_albedo[(size_t)c * p_pad + i] = g_albedo ? g_albedo[3 * (size_t)i + c] : 0.f;
+        o_ts[i] = g_ts ? g_ts[i] : 0.f;
+        o_tb[i] = g_tb ? g_tb[i] : 0.f;
+    }
+}
+// transient embedding gradient, one point per thread (nn.Embedding backward = index_add)
+__global__ void k_emb_grad_points(const float* g_emb, const int* simg, int n, float* d_emb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g_emb + 4 * (size_t)i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (v[e] != 0.f) atomicAdd(d_emb + 4 * (size_t)simg[i] + e, v[e]);
+}
+// ambient head backward per POINT (the render path evaluates the head once per ray, k_ambient_bwd): a wave per point recomputes
+// the head (27 -> 128 ReLU -> 3 Sigmoid), lanes own hidden units j = lane, lane + 64; sums stay in registers across the wave's
+// points and meet in one set of atomics per wave
+__global__ __launch_bounds__(256) void k_ambient_points_bwd(AmbientW w, const float* sun, const float* g_amb, int n,
+                                                             float* d_w1, float* d_b1, float* d_w2, float* d_b2) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    float dw1[2][27], db1[2] = {0.f, 0.f}, dw2[2][3], db2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int i = 0; i < 27; ++i) dw1[k][i] = 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) dw2[k][o] = 0.f;
+    }
+    for (int i = wave; i < n; i += n_waves) {
+        const AmbientRay ar = ambient_forward(w, sun[3 * (size_t)i], sun[3 * (size_t)i + 1], sun[3 * (size_t)i + 2], lane);
+        float gpre[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) { gpre[o] = g_amb[3 * (size_t)i + o] * ar.out[o] * (1.f - ar.out[o]); db2[o] += gpre[o]; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = lane + 64 * k;
+            float ghid = 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) { dw2[k][o] += gpre[o] * ar.hid[k]; ghid += w.w2[o * 128 + j] * gpre[o]; }
+            if (ar.hid[k] <= 0.f) ghid = 0.f;
+            db1[k] += ghid;
+#pragma unroll
+            for (int q = 0; q < 27; ++q) dw1[k][q] += ghid * ar.enc[q];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = lane + 64 * k;
+#pragma unroll
+        for (int q = 0; q < 27; ++q) if (dw1[k][q] != 0.f) atomicAdd(d_w1 + j * 27 + q, dw1[k][q]);
+        if (db1[k] != 0.f) atomicAdd(d_b1 + j, db1[k]);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) if (dw2[k][o] != 0.f) atomicAdd(d_w2 + o * 128 + j, dw2[k][o]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) if (db2[o] != 0.f) atomicAdd(d_b2 + o, db2[o]);
+    }
+}
+
 // ---- bottleneck layer weight gradient from the two factors (fp32): block = input feature i of the heads' first layers =
 //      output feature (row) of the bottleneck layer, thread = column j ----
 __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
@@ -285,10 +355,19 @@ __global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt,
 }
 
 // ---- torch.optim.Adam (no weight decay, no amsgrad) on the flat buffers --------------------------------------
+// Parameters inside the two "late" ranges (transient embedding; transient head + ambient head) have grad None in the
+// reference while epoch_idx < 2 (s = 1, MSE on rgb: sat_rendering.py:269-272, train_eonerf.py:139-141), so torch.optim.Adam
+// skips them and their per-parameter step starts counting at epoch 2: they get their own bias corrections (late.active == 0:
+// skipped altogether, as torch does for grad None).
+struct AdamLate { size_t lo0, hi0, lo1, hi1; float bc1, bc2_sqrt; int active; };
 __global__ void k_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                       float bc1, float bc2_sqrt, float gscale) {
+                       float bc1, float bc2_sqrt, float gscale, AdamLate late) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if ((i >= late.lo0 && i < late.hi0) || (i >= late.lo1 && i < late.hi1)) {
+        if (!late.active) return;
+        bc1 = late.bc1; bc2_sqrt = late.bc2_sqrt;
+    }
     const float gi = g[i] * gscale;
     const float mi = m[i] + (1.f - b1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1-beta1)
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -315,6 +394,21 @@ hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st
     hipLaunchKernelGGL(k_cam_composite_bwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
     return hipGetLastError();
 }
+hipError_t eo_launch_field_grads_to_soa(const float* g_sigma, const float* g_albedo, const float* g_ts, const float* g_tb, int n, int p_pad,
+                                       float* o_sigma, float* o_albedo, float* o_ts, float* o_tb, hipStream_t st) {
+    hipLaunchKernelGGL(k_field_grads_to_soa, dim3((n + 255) / 256), dim3(256), 0, st, g_sigma, g_albedo, g_ts, g_tb, n, p_pad, o_sigma, o_albedo, o_ts, o_tb);
+    return hipGetLastError();
+}
+hipError_t eo_launch_emb_grad_points(const float* g_emb, const int* simg, int n, float* d_emb, hipStream_t st) {
+    hipLaunchKernelGGL(k_emb_grad_points, dim3((n + 255) / 256), dim3(256), 0, st, g_emb, simg, n, d_emb);
+    return hipGetLastError();
+}
+hipError_t eo_launch_ambient_points_bwd(const AmbientW& w, const float* sun, const float* g_amb, int n,
+                                        float* d_w1, float* d_b1, float* d_w2, float* d_b2, hipStream_t st) {
+    const int blocks = n < 256 ? (n + 3) / 4 : 64;
+    hipLaunchKernelGGL(k_ambient_points_bwd, dim3(blocks), dim3(256), 0, st, w, sun, g_amb, n, d_w1, d_b1, d_w2, d_b2);
+    return hipGetLastError();
+}
 hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_bott_wgrad, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
@@ -333,9 +427,11 @@ hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, fl
     hipLaunchKernelGGL(k_loss, dim3((n + 255) / 256), dim3(256), 0, st, out, gt, n, kind, d_out, loss);
     return hipGetLastError();
 }
-hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
-                          float gscale, hipStream_t st) {
+hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, int step_late, const size_t late_ranges[4],
+                          float lr, float b1, float b2, float eps, float gscale, hipStream_t st) {
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale);
+    AdamLate late{late_ranges[0], late_ranges[1], late_ranges[2], late_ranges[3], 1.f, 1.f, step_late > 0 ? 1 : 0};
+    if (step_late > 0) { late.bc1 = 1.f - powf(b1, (float)step_late); late.bc2_sqrt = sqrtf(1.f - powf(b2, (float)step_late)); }
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, late);
     return hipGetLastError();
 }

@@ -177,12 +177,16 @@ def load_rays(json_files, scene_loc=None, img_downscale=1.0, cache_dir=None, dev
     json_files: metadata JSON paths (one per image, their order defines the image index); scene_loc: path of scene.loc_utm,
     an (offset, scale) pair, or None to derive it from these rays as init_scaling_params does.  Rays of an image found in
     cache_dir are read from there, others are generated and written there in the reference's format.
+    Cache semantics follow :441-476: an 8-column cache holds UN-normalised rays (sun direction appended and normalised here);
+    an 11-column cache holds FINAL rays (already normalised, sun direction included: recompute=False) and is passed through
+    unchanged.  The reference takes its `recompute` flag from the last image only, so a mix of 8- and 11-column caches
+    normalises either everything twice or nothing; such a mix is rejected here with a ValueError instead.
     Returns (all_rays fp32 [N,11] normalised, all_ids_img int64 [N], all_img_shapes [[h,w],...], scene_loc (offset, scale))."""
     import json
     import os
     import torch
     dev = torch.device(device)
-    raws, suns, ids, shapes = [], [], [], []
+    raws, ids, shapes, final = [], [], [], []
     for t, jp in enumerate(json_files):
         with open(jp) as f:
             d = json.load(f)
@@ -199,6 +203,7 @@ def load_rays(json_files, scene_loc=None, img_downscale=1.0, cache_dir=None, dev
             if cache_path is not None:
                 os.makedirs(os.path.dirname(cache_path) or ".", exist_ok=True)
                 torch.save(raw.cpu(), cache_path)
+        final.append(raw.shape[1] == 11)      # recompute = False (:443-444): final normalised rays, taken as they are
         if raw.shape[1] == 8:      # sun directions are appended to freshly generated / 8-column cached rays (:455-458)
             sun = torch.tensor(sun_direction(d["sun_elevation"], d["sun_azimuth"]), dtype=torch.float64, device=dev)
             raw = torch.cat([raw.to(torch.float64), sun.expand(raw.shape[0], 3)], dim=1)
@@ -208,6 +213,12 @@ def load_rays(json_files, scene_loc=None, img_downscale=1.0, cache_dir=None, dev
         if verbose:
             print(f"Image {img_id} loaded ( {t + 1} / {len(json_files)} )")
     all_raw = torch.cat(raws, 0)
+    if any(final):
+        if not all(final):
+            raise ValueError("ray caches mix 8-column (un-normalised) and 11-column (final) files; regenerate one kind")
+        if isinstance(scene_loc, (str, os.PathLike)):
+            scene_loc = read_scene_loc(scene_loc)
+        return all_raw.to(torch.float32), torch.cat(ids, 0), shapes, scene_loc
     if scene_loc is None:
         dloc = scene_loc_from_rays(all_raw)
         scene_loc = ([dloc["X_offset"], dloc["Y_offset"], dloc["Z_offset"]], [dloc["X_scale"], dloc["Y_scale"], dloc["Z_scale"]])

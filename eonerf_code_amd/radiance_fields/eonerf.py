@@ -23,6 +23,49 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _FieldFn(torch.autograd.Function):
+    """EONerfMLP.forward / query_density as ONE differentiable op (the reference class is an ordinary autograd module,
+    radiance_fields/eonerf.py:141-170): forward = eonerf_field_forward_train (chain kernel in training mode: activations and ReLU
+    masks stay in the op's workspace), backward = eonerf_field_backward (backward chain with input gradient, weight-gradient GEMM,
+    embedding and ambient-head gradients).  The parameters are inputs so autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, field, density_only, x, sun, img, *params):
+        L = _lib.lib()
+        flat = field._ensure_packed()
+        n, dev = x.shape[0], x.device
+        nb = L.eonerf_field_train_workspace_bytes(field._ctx, n, 1 if density_only else 0)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)        # lives until backward
+        sigma = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        if density_only:
+            albedo = ambient = ts = tb = None
+        else:
+            albedo, ambient = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(2))
+            ts, tb = (torch.empty(n, 1, dtype=torch.float32, device=dev) for _ in range(2))
+        _lib.check(L.eonerf_field_forward_train(field._ctx, _ptr(flat), _ptr(x), _ptr(sun), _ptr(img), n, 1 if density_only else 0,
+                                                _ptr(sigma), _ptr(albedo), _ptr(ambient), _ptr(ts), _ptr(tb), _ptr(ws), ws.numel(), _stream()))
+        ctx.field, ctx.density_only, ctx.ws, ctx.n = field, density_only, ws, n
+        ctx.sun = sun
+        ctx.need_dx = x.requires_grad
+        return sigma if density_only else (sigma, albedo, ambient, ts, tb)
+
+    @staticmethod
+    def backward(ctx, *g):
+        field, ws, n = ctx.field, ctx.ws, ctx.n
+        if ws is None:
+            raise RuntimeError("EONerfMLP: backward through the same forward twice (the op's workspace is released after the first)")
+        L = _lib.lib()
+        flat = field.flat_params()
+        d_flat = torch.zeros_like(flat)
+        gs = [None if t is None else t.contiguous().float() for t in g] + [None] * 4
+        d_x = torch.empty(n, 3, dtype=torch.float32, device=flat.device) if ctx.need_dx else None
+        _lib.check(L.eonerf_field_backward(field._ctx, _ptr(flat), _ptr(ctx.sun), n, 1 if ctx.density_only else 0,
+                                           _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), _ptr(gs[4]),
+                                           _ptr(d_flat), _ptr(d_x), _ptr(ws), ws.numel(), _stream()))
+        ctx.ws = None
+        return (None, None, d_x, None, None) + tuple(field.grad_views(d_flat))
+
+
 class EONerfMLP(nn.Module):
     def __init__(self, n_input_images: int, net_depth: int = 8, net_width: int = 256, skip_layer: int = 4,
                  radiometric_normalization: bool = False, precision: str = None):
@@ -114,6 +157,11 @@ class EONerfMLP(nn.Module):
             self._packed_version = ver
         return flat
 
+    def set_noise_seed(self, seed):
+        """Key of the sampler's in-kernel jitter stream (what torch.manual_seed is to perturb_z_vals' rand_like)."""
+        self._context()
+        _lib.check(_lib.lib().eonerf_set_noise_seed(self._ctx, int(seed)))
+
     def grad_views(self, d_flat):
         """Views of a flat gradient buffer in named_parameters() order (None for tensors absent from the layout)."""
         by_name = {name: (off, r, c) for name, off, r, c in self._layout}
@@ -130,46 +178,67 @@ class EONerfMLP(nn.Module):
             self._ws[key] = ws
         return ws
 
-    # ------------------------------------------------------------------ reference API (inference entry points)
-    @torch.no_grad()
+    # ------------------------------------------------------------------ reference API
+    def _wants_grad(self, *tensors):
+        if not torch.is_grad_enabled():
+            return False
+        return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in self.parameters())
+
     def query_density(self, x):
-        """radiance_fields/eonerf.py:141-145: x[..., 3] -> sigma[..., 1]."""
-        flat = self._ensure_packed()
+        """radiance_fields/eonerf.py:141-145: x[..., 3] -> sigma[..., 1].  Differentiable (w.r.t. the parameters and x) when
+        autograd is recording; a plain inference call otherwise."""
         shape = x.shape[:-1]
         xs = x.reshape(-1, 3).float().contiguous()
         n = xs.shape[0]
-        sigma = torch.empty(n, dtype=torch.float32, device=xs.device)
-        L = _lib.lib()
-        nb = L.eonerf_field_workspace_bytes(self._ctx, n)
-        ws = self._workspace("field", nb)
-        _lib.check(L.eonerf_query_density(self._ctx, _ptr(flat), _ptr(xs), n, _ptr(sigma), _ptr(ws), ws.numel(), _stream()))
+        if n > 0 and self._wants_grad(x):
+            self._ensure_packed()
+            return _FieldFn.apply(self, True, xs, None, None, *self.parameters()).view(*shape, 1)
+        with torch.no_grad():
+            flat = self._ensure_packed()
+            sigma = torch.empty(n, dtype=torch.float32, device=xs.device)
+            L = _lib.lib()
+            nb = L.eonerf_field_workspace_bytes(self._ctx, n)
+            ws = self._workspace("field", nb)
+            _lib.check(L.eonerf_query_density(self._ctx, _ptr(flat), _ptr(xs), n, _ptr(sigma), _ptr(ws), ws.numel(), _stream()))
         return sigma.view(*shape, 1)
 
     def query_opacity(self, x, step_size):
         """radiance_fields/eonerf.py:147-152."""
         return self.query_density(x) * step_size
 
-    @torch.no_grad()
     def forward(self, x, sun_dirs=None, img_indices=None):
         """radiance_fields/eonerf.py:154-170: -> (sigma[N,1], albedo[N,3], ambient[N,3], transient_scalar[N,1], transient_beta[N,1]).
-        Inference entry point; training differentiates through render_image (sat_rendering.py) instead."""
-        flat = self._ensure_packed()
+        Differentiable (parameters and x) when autograd is recording, as the reference module is; the training loop itself
+        differentiates through render_image (sat_rendering.py), which fuses sampling, both passes and compositing."""
         xs = x.reshape(-1, 3).float().contiguous()
         n = xs.shape[0]
         sun = sun_dirs.reshape(-1, 3).float().contiguous()
         img = img_indices.reshape(-1).to(torch.int64).contiguous()
-        dev = xs.device
-        sigma, ts, tb = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
-        albedo, ambient = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(2))
-        L = _lib.lib()
-        nb = L.eonerf_field_workspace_bytes(self._ctx, n)
-        ws = self._workspace("field", nb)
-        _lib.check(L.eonerf_field_forward(self._ctx, _ptr(flat), _ptr(xs), _ptr(sun), _ptr(img), n, _ptr(sigma), _ptr(albedo),
-                                          _ptr(ambient), _ptr(ts), _ptr(tb), _ptr(ws), ws.numel(), _stream()))
+        if n > 0 and self._wants_grad(x):
+            self._ensure_packed()
+            return _FieldFn.apply(self, False, xs, sun, img, *self.parameters())
+        with torch.no_grad():
+            flat = self._ensure_packed()
+            dev = xs.device
+            sigma, ts, tb = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
+            albedo, ambient = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(2))
+            L = _lib.lib()
+            nb = L.eonerf_field_workspace_bytes(self._ctx, n)
+            ws = self._workspace("field", nb)
+            _lib.check(L.eonerf_field_forward(self._ctx, _ptr(flat), _ptr(xs), _ptr(sun), _ptr(img), n, _ptr(sigma), _ptr(albedo),
+                                              _ptr(ambient), _ptr(ts), _ptr(tb), _ptr(ws), ws.numel(), _stream()))
         return sigma.view(n, 1), albedo, ambient, ts.view(n, 1), tb.view(n, 1)
 
-    @torch.no_grad()
     def _rendering(self, chunk_rays, t_starts, t_ends, ray_indices, depth_only):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # the reference's rendering()/render_depth() build an autograd graph; this entry point cannot (the fused, differentiable
+            # path is sat_rendering.render_image).  Fail loudly rather than hand back graph-less tensors to a loss.
+            raise RuntimeError("EONerfMLP.rendering/render_depth on caller-provided samples is an inference entry point: call it under "
+                               "torch.no_grad(), or differentiate through sat_rendering.render_image (same result, fused autograd)")
+        with torch.no_grad():
+            return self._rendering_impl(chunk_rays, t_starts, t_ends, ray_indices, depth_only)
+
+    def _rendering_impl(self, chunk_rays, t_starts, t_ends, ray_indices, depth_only):
         from ..datasets.satellite import satrays_to_table
         flat = self._ensure_packed()
         table, img = satrays_to_table(chunk_rays)
@@ -202,5 +271,6 @@ class EONerfMLP(nn.Module):
 
     def rendering(self, chunk_rays, t_starts, t_ends, ray_indices, epoch_idx=100):
         """radiance_fields/eonerf.py:196-248: -> (albedo_rgb_, depth_, transient_beta_, transient_scalar_, ambient_rgb_, entropy_).
-        Inference entry point; render_image fuses this with sampling, the shadow pass and autograd."""
+        Inference entry point (raises under a recording autograd with trainable parameters); render_image fuses this with
+        sampling, the shadow pass and autograd."""
         return self._rendering(chunk_rays, t_starts, t_ends, ray_indices, False)

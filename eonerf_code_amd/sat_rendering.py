@@ -4,8 +4,8 @@ Same signature, same result dict (12 keys, sat_rendering.py:322-334) and the sam
 library call replaces satnerf_sampling + EONerfMLP.rendering + compute_geometric_shadows + the irradiance /
 radiometric model (sat_rendering.py:252-312), and autograd is one library call back.
 
-The jitter noise the reference draws with torch.rand_like inside perturb_z_vals (:52) is drawn here with
-torch.rand on the device (same distribution, same draw order: camera, [retry], sun) or can be injected through
+The jitter noise the reference draws with torch.rand_like inside perturb_z_vals (:52) is drawn INSIDE the sampler
+kernels (Philox4x32-10, the generator family behind torch.rand; U[0,1) with 24 random bits) or can be injected through
 `noise=` for parity tests.
 """
 import ctypes as C
@@ -41,8 +41,6 @@ def count_number_of_pts_per_nerfacc_ray(rays, ray_indices):
 def satnerf_sampling(origins, viewdirs, sampling_args, near=None, far=None, perturb=True, noise=None, radiance_field=None):
     """sat_rendering.py:56-84: (ray_indices, t_starts, t_ends) of the cube-filtered stratified samples.
     `far` is ignored exactly as in the reference (far = near + 2); noise [R,128] replaces the rand_like draw."""
-    if not perturb:
-        raise NotImplementedError("the reference never calls the sampler with perturb=False")
     if int(2 / sampling_args["render_step_size"]) != 128:
         raise ValueError("the HIP sampler supports 128 samples per ray (run_JAX_RGB.sh:11)")
     n, dev = origins.shape[0], origins.device
@@ -50,7 +48,8 @@ def satnerf_sampling(origins, viewdirs, sampling_args, near=None, far=None, pert
     table[:, 0:3], table[:, 3:6] = origins, viewdirs
     if near is not None:
         table[:, 6:7] = near.reshape(n, 1)
-    u = torch.rand(n, 128, device=dev) if noise is None else noise.to(dev, torch.float32).contiguous()
+    # noise=None: the jitter is drawn inside the sampler kernel (Philox); perturb=False: no jitter at all (:70-71)
+    u = None if (noise is None or not perturb) else noise.to(dev, torch.float32).contiguous()
     cap = max(n * 127, 1)
     ri = torch.empty(cap, dtype=torch.int64, device=dev)
     ts_, te_ = torch.empty(cap, dtype=torch.float32, device=dev), torch.empty(cap, dtype=torch.float32, device=dev)
@@ -59,7 +58,7 @@ def satnerf_sampling(origins, viewdirs, sampling_args, near=None, far=None, pert
     field = radiance_field if radiance_field is not None else _any_field(dev)
     nb = L.eonerf_render_workspace_bytes(field._ctx, n, _lib.F_ONLY_DEPTH)
     ws = field._workspace("render", nb)
-    _lib.check(L.eonerf_sample_rays(field._ctx, _ptr(table), _ptr(_zsteps(dev)), _ptr(u), n, _ptr(ri), _ptr(ts_), _ptr(te_), None,
+    _lib.check(L.eonerf_sample_rays(field._ctx, _ptr(table), _ptr(_zsteps(dev)), _ptr(u), 1 if perturb else 0, n, _ptr(ri), _ptr(ts_), _ptr(te_), None,
                                     _ptr(cnt), _ptr(ws), ws.numel(), _stream()))
     k = int(cnt.item())
     return ri[:k], ts_[:k], te_[:k]
@@ -99,7 +98,9 @@ class _RenderChunk(torch.autograd.Function):
         if train:
             ctx.field, ctx.flags, ctx.ws = field, flags, ws
             ctx.save_for_backward(table, img)
-        ctx.mark_non_differentiable(n_samples)
+            ctx.mark_non_differentiable(n_samples)
+        else:       # inference / only_depth chunks keep nothing for a backward pass: their outputs carry no graph
+            ctx.mark_non_differentiable(out, n_samples)
         return out, n_samples
 
     @staticmethod
@@ -129,10 +130,8 @@ def render_rays_chunk(radiance_field, table, img, epoch_idx, eval=False, only_de
     params = list(radiance_field.parameters())
     if torch.is_grad_enabled() and any(p.requires_grad for p in params) and not only_depth:
         flags |= _lib.F_TRAIN
-    if noise is None:
-        u_cam = torch.rand(n, 128, device=dev)
-        u_retry = torch.rand(n, 128, device=dev)
-        u_sun = torch.rand(n, 128, device=dev) if flags & _lib.F_SHADOWS else None
+    if noise is None:       # production: no noise buffers, the sampler kernels draw the jitter (Philox; seed: EONerfMLP.set_noise_seed)
+        u_cam = u_retry = u_sun = None
     else:
         u_cam, u_retry, u_sun = (None if t is None else t.to(dev, torch.float32).contiguous() for t in noise)
     return _RenderChunk.apply(radiance_field, table, img, flags, u_cam, u_retry, u_sun, *params)

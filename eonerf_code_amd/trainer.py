@@ -44,11 +44,14 @@ class FusedTrainer:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
+        self.step_late = 0      # steps taken with the transient / ambient heads inside the graph (eonerf_adam_step_late)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         self.L = _lib.lib()
         self.ctx = field._ctx
+        self.late_names = _lib.late_param_names(self.ctx)
         self.max_rays = max_rays
         self._ws = {}
+        self._comm_stream = None
         self.out = torch.empty(max_rays, 21, dtype=torch.float32, device=dev)
         self.d_out = torch.zeros(max_rays, 21, dtype=torch.float32, device=dev)
         self.n_samples = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -82,12 +85,25 @@ class FusedTrainer:
     def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False):
         """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar."""
         n = rays.shape[0]
-        dev = rays.device
+        if n > self.max_rays:
+            raise ValueError(f"batch of {n} rays exceeds the trainer's max_rays={self.max_rays}")
+        if not (rays.is_cuda and rays.dtype == torch.float32 and rays.dim() == 2 and rays.shape[1] == 11 and rays.is_contiguous()):
+            raise ValueError("rays must be a contiguous CUDA fp32 [n, 11] table")
+        if not (img_idx.is_cuda and img_idx.dtype == torch.int64 and img_idx.is_contiguous() and img_idx.numel() == n):
+            raise ValueError("img_idx must be a contiguous CUDA int64 tensor with one entry per ray")
+        if not (pixels.is_cuda and pixels.dtype == torch.float32 and pixels.shape == (n, 3)):
+            raise ValueError("pixels must be a CUDA fp32 [n, 3] tensor")
+        # the packed weight streams follow every in-place change of the parameters (load_state_dict, load_checkpoint, manual
+        # init) and a re-bound flat buffer (.to()); adam_step re-packs them itself
+        flat = self.field._ensure_packed()
+        if flat.data_ptr() != self.flat.data_ptr():
+            if flat.numel() != self.flat.numel() or flat.device != self.flat.device:
+                raise RuntimeError("the field's parameters moved to another device after the trainer was built")
+            self.flat = flat
         # epoch < 2: s = 1 and the loss is MSE on rgb, so the transient head is outside the autograd graph (F_RGB_LOSS)
         flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else _lib.F_RGB_LOSS)
-        if noise is None:
-            u = torch.rand(3 if flags & _lib.F_SHADOWS else 2, n, 128, device=dev)
-            u_cam, u_retry, u_sun = u[0], u[1], (u[2] if flags & _lib.F_SHADOWS else None)
+        if noise is None:       # production: the sampler kernels draw the jitter themselves (Philox)
+            u_cam = u_retry = u_sun = None
         else:
             u_cam, u_retry, u_sun = noise
         ws = self._workspace(n, flags)
@@ -99,12 +115,33 @@ class FusedTrainer:
         self.d_flat.zero_()
         _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
                                                  _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
-        gscale = reduce_gradients(self.d_flat)
+        gscale = self._reduce(st)
         self.step_count += 1
-        _lib.check(self.L.eonerf_adam_step(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, gscale, st))
+        if flags & _lib.F_SHADOWS:
+            self.step_late += 1
+        _lib.check(self.L.eonerf_adam_step_late(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                                self.step_count, self.step_late, self.lr, self.betas[0], self.betas[1], self.eps, gscale, st))
         self.field._packed_version = tuple(p._version for p in self.field.parameters())   # adam_step re-packed the weights
         return loss
+
+    def _reduce(self, st):
+        """The gradient all-reduce on a SIDE stream: it starts when the last gradient kernel of the backward has
+        finished (event on the compute stream) and the Adam kernel waits for it; host-side launches of the next kernels are not
+        held up by the collective.  Single process: no-op."""
+        if self.world == 1:
+            return 1.0
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.flat.device)
+        cur = torch.cuda.current_stream()
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            gscale = reduce_gradients(self.d_flat)
+        cur.wait_stream(self._comm_stream)
+        return gscale
+
+    def set_noise_seed(self, seed):
+        """Key of the in-kernel jitter stream; data-parallel ranks must use different seeds (train_dp.py: seed + rank)."""
+        _lib.check(self.L.eonerf_set_noise_seed(self.ctx, int(seed)))
 
     # ---- measurement hooks ----
     def profile_enable(self, max_launches):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EONERF_VERSION 100
+#define EONERF_VERSION 200
 
 enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4 };
 
@@ -78,6 +78,20 @@ int eonerf_field_forward(eonerf_ctx* ctx, const float* flat_params, const float*
 int eonerf_query_density(eonerf_ctx* ctx, const float* flat_params, const float* xyz, int n, float* sigma,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same two calls as differentiable operators (the reference's EONerfMLP is an ordinary autograd module,
+ * radiance_fields/eonerf.py:141-170): eonerf_field_forward_train also keeps, in `workspace`, what eonerf_field_backward needs
+ * (activations, ReLU masks, positions); density_only != 0 is query_density (sun/img/albedo/ambient/ts/tb may be NULL).
+ * eonerf_field_backward: upstream gradients g_* of the outputs (same shapes as the outputs, NULL = zero) -> parameter
+ * gradients ACCUMULATED into d_flat_params and, if d_xyz != NULL, the input gradient d_xyz[n,3] (through the encoder
+ * derivative 2^k cos(2^k x)).  Must follow a forward_train on the same (n, density_only, workspace). */
+size_t eonerf_field_train_workspace_bytes(const eonerf_ctx* ctx, int n_points, int density_only);
+int eonerf_field_forward_train(eonerf_ctx* ctx, const float* flat_params, const float* xyz, const float* sun, const int64_t* img, int n,
+                               int density_only, float* sigma, float* albedo, float* ambient, float* ts, float* tb,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int eonerf_field_backward(eonerf_ctx* ctx, const float* flat_params, const float* sun, int n, int density_only,
+                          const float* g_sigma, const float* g_albedo, const float* g_ambient, const float* g_ts, const float* g_tb,
+                          float* d_flat_params, float* d_xyz, void* workspace, size_t workspace_bytes, void* stream);
+
 /* RPC camera model in rpcm's dict format (the "rpc" entry of the dataset JSON files, datasets/satellite.py:52-55). */
 typedef struct {
     double col_num[20], col_den[20], row_num[20], row_den[20];
@@ -97,10 +111,16 @@ int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double
                          double sun_elevation_deg, double sun_azimuth_deg, const float offset[3], const float scale[3],
                          float* raw8, float* rays, void* stream);
 
+/* Key of the in-kernel jitter stream (torch.manual_seed's role for perturb_z_vals' rand_like, sat_rendering.py:52;
+ * data-parallel ranks use different seeds).  Every call that draws noise advances the stream. */
+int eonerf_set_noise_seed(eonerf_ctx* ctx, uint64_t seed);
+
 /* sat_rendering.satnerf_sampling (sat_rendering.py:56-84) + count_number_of_pts_per_nerfacc_ray (:10-16):
  * rays[R,11] (origin, dir and near columns are used), u[R,128] jitter -> flattened, cube-filtered samples
- * ray_indices[n] (int64), t_starts[n], t_ends[n] (capacity R*127 each), pts_per_ray[R] (fp32) and *n_dev = n. */
-int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, const float* u, int n_rays,
+ * ray_indices[n] (int64), t_starts[n], t_ends[n] (capacity R*127 each), pts_per_ray[R] (fp32) and *n_dev = n.
+ * perturb = 0: the z values stay on the uniform grid (perturb=False, :70-71 skipped; u is ignored).  perturb != 0 with
+ * u == NULL: the jitter is drawn inside the kernel (Philox4x32-10, eonerf_set_noise_seed). */
+int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, const float* u, int perturb, int n_rays,
                        int64_t* ray_indices, float* t_starts, float* t_ends, float* pts_per_ray, int* n_dev,
                        void* workspace, size_t workspace_bytes, void* stream);
 
@@ -118,6 +138,9 @@ int eonerf_rendering(eonerf_ctx* ctx, const float* flat_params, const float* ray
  *   rays[R,11] fp32 (o3 d3 near far sun3), img_idx[R] int64, zsteps[128] = linspace(0,1,128),
  *   u_cam/u_sun[R,128] jitter in [0,1) (the reference draws rand_like inside perturb_z_vals, :52),
  *   u_retry (may be NULL): noise of the ":260-262 resample if some ray is empty" branch.
+ *   u_cam == NULL (then u_retry and u_sun must be NULL too): production mode, no noise buffers -- the sampler kernels draw the
+ *   jitter themselves (Philox4x32-10 keyed by eonerf_set_noise_seed, counter = (ray, sample lane, draw, call number); the
+ *   reference's torch.rand_like is the same generator family, :52), and the resample branch is always armed.
  *   out[R,21] = rgb3 depth1 albedo3 ambient3 geo1 ts1 beta1 entropy1 pts1 sc_pts1 opacity2 shadowless3 (:311-312)
  *   n_samples_dev: device int, number of camera samples (render_image's second return value). */
 int eonerf_render_forward(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
@@ -142,6 +165,15 @@ int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, in
  * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
 int eonerf_adam_step(eonerf_ctx* ctx, float* flat_params, const float* d_flat_params, float* exp_avg, float* exp_avg_sq,
                      int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* The same step with torch.optim.Adam's PER-PARAMETER step counts: the transient embedding, the transient head and the ambient
+ * head receive grad None in the reference while epoch_idx < 2 (s = 1 and MSE on rgb, sat_rendering.py:269-272,
+ * train_eonerf.py:139-141), so Adam skips them and their bias corrections start counting when the shadow pass switches on.
+ * step_late = number of steps taken with those parameters inside the graph (0: they are skipped, as torch does for grad None);
+ * eonerf_param_is_late(index) tells which tensors of eonerf_param_info these are (1 / 0). */
+int eonerf_adam_step_late(eonerf_ctx* ctx, float* flat_params, const float* d_flat_params, float* exp_avg, float* exp_avg_sq,
+                          int step, int step_late, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int eonerf_param_is_late(const eonerf_ctx* ctx, int index);
 
 /* Measurement hooks (no reference counterpart): with profiling enabled every launch of the three MFMA kernels is
  * bracketed by hipEvents on the caller's stream.  kernel: 0 = forward chain (camera), 1 = backward chain (camera),

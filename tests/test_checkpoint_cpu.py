@@ -50,3 +50,37 @@ def test_ray_table_rank_slices_cover_a_permutation():
     assert sorted(torch.cat(seen).tolist()) == list(range(n))       # disjoint, complete
     t = RayTable(rays, img, rgb, "cpu", seed=1)
     assert not torch.equal(t.batch(0, 0, 8)[1], t.batch(1, 0, 8)[1])  # reshuffled every epoch
+
+
+def test_occ_grid_state_dict_holds_only_nerfacc_persistent_buffers():
+    # nerfacc v0.5.2 OccGridEstimator registers grid_coords / grid_indices with persistent=False: a strict load_state_dict
+    # (eval_eonerf.py:71) accepts exactly these four entries
+    from eonerf_code_amd.checkpoint import occ_grid_state_dict
+    sd = occ_grid_state_dict(16)
+    assert list(sd.keys()) == ["resolution", "aabbs", "occs", "binaries"]
+    assert sd["resolution"].dtype == torch.int32 and sd["resolution"].tolist() == [16, 16, 16]
+    assert sd["aabbs"].shape == (1, 6) and sd["aabbs"].dtype == torch.float32
+    assert sd["occs"].shape == (16 ** 3,) and sd["occs"].dtype == torch.float32
+    assert sd["binaries"].shape == (1, 16, 16, 16) and sd["binaries"].dtype == torch.bool
+
+
+def test_adam_state_dict_per_parameter_steps_like_torch(tmp_path):
+    # parameters outside the graph for the first epochs have NO Adam state in torch (grad None) and their own step afterwards
+    from eonerf_code_amd.checkpoint import adam_state_dict
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    f = EONerfMLP(3, radiometric_normalization=True)
+    off, layout = 0, []
+    for name, p in f.named_parameters():
+        layout.append((name, off, 1, p.numel()))
+        off += p.numel()
+    f._layout = layout
+    late = {n for n, _ in f.named_parameters() if n.startswith(("transient_", "ambient_mlp"))}
+    m, v = torch.rand(off), torch.rand(off)
+    sd0 = adam_state_dict(f, m, v, 10, 5e-4, step_late=0, late_names=late)
+    names = [n for n, _ in f.named_parameters()]
+    assert all((i in sd0["state"]) == (names[i] not in late) for i in range(len(names)))
+    sd1 = adam_state_dict(f, m, v, 10, 5e-4, step_late=4, late_names=late)
+    assert all(float(sd1["state"][i]["step"]) == (4 if names[i] in late else 10) for i in range(len(names)))
+    opt = torch.optim.Adam(f.parameters(), lr=5e-4)
+    opt.load_state_dict(sd0)                                          # partial state, as a reference checkpoint of epoch < 2 has
+    opt.load_state_dict(sd1)

@@ -1,0 +1,122 @@
+"""GPU: EONerfMLP.forward / query_density are differentiable operators, as the reference's nn.Module is
+(radiance_fields/eonerf.py:141-170).  Checked against golden G7 -- the REFERENCE's own autograd on 64 points: gradients w.r.t.
+every parameter, w.r.t. the input positions of forward() (`dx`) and of query_density() (`dx_density`).
+
+Tolerances (fp32 mode): the input-gradient path multiplies by the encoder derivative 2^k cos(2^k x), k <= 9, so both sides carry
+fp32 rounding amplified by up to 512: dx within 2e-3 relative L2 of the golden; parameter gradients (strided sub-sample + sum +
+abs-sum, the golden's compact form) within 2e-3 relative L2.  bf16 mode: cosine > 0.99 per tensor against the same goldens.
+"""
+import pytest
+import torch
+
+from conftest import load_golden, T
+from oracle import eonerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+GRAD_STRIDE = 61
+
+
+def compact_grad(g):
+    flat = g.detach().reshape(-1).double().cpu()
+    head = torch.stack([flat.sum(), flat.abs().sum()])
+    body = flat if flat.numel() <= 1024 else flat[::GRAD_STRIDE]
+    return torch.cat([head, body])
+
+
+def _field(precision):
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    g3 = load_golden("g3_field_w256")
+    n_img = int(g3["n_img"])
+    f = EONerfMLP(n_img, radiometric_normalization=True, precision=precision)
+    f.load_state_dict(orc.closed_form_state_dict(n_img), strict=True)
+    return f.cuda(), g3
+
+
+def _g7_scalar(f, xs, sun, img):
+    sigma, albedo, ambient, ts, tb = f(xs, sun, img)
+    cw = torch.linspace(0.5, 1.5, 64, device=xs.device)[:, None]
+    return (cw * sigma).sum() + (albedo * cw).sum() * 0.7 + ambient.sum() * 0.3 + (ts * cw).sum() * 1.1 + tb.sum() * 0.9
+
+
+def test_forward_and_query_density_autograd_match_reference_golden_g7_fp32():
+    f, g3 = _field("fp32")
+    g7 = load_golden("g7_field_grads")
+    x, sun, img = T(g3["x"])[:64].cuda(), T(g3["sun"])[:64].cuda(), T(g3["img"])[:64].cuda()
+    xs = x.clone().requires_grad_(True)
+    f.zero_grad()
+    scalar = _g7_scalar(f, xs, sun, img)
+    assert abs(scalar.item() - float(g7["scalar"])) < 1e-3 * abs(float(g7["scalar"]))
+    scalar.backward()
+    dx_ref = T(g7["dx"])
+    assert (xs.grad.cpu() - dx_ref).norm().item() <= 2e-3 * dx_ref.norm().item(), "dx"
+    params = dict(f.named_parameters())
+    seen = 0
+    for k, v in g7.items():
+        if not k.startswith("grad."):
+            continue
+        p = params[k[5:]]
+        got = compact_grad(p.grad if p.grad is not None else torch.zeros_like(p))
+        ref = T(v)
+        assert (got - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-6, k
+        seen += 1
+    assert seen >= 40
+    # query_density: gradient w.r.t. the positions
+    xd = x.clone().requires_grad_(True)
+    cw = torch.linspace(0.5, 1.5, 64, device="cuda")[:, None]
+    (f.query_density(xd) * cw).sum().backward()
+    dd_ref = T(g7["dx_density"])
+    assert (xd.grad.cpu() - dd_ref).norm().item() <= 2e-3 * dd_ref.norm().item(), "dx_density"
+
+
+def test_forward_autograd_bf16_direction_and_no_grad_path_agree():
+    f, g3 = _field("bf16")
+    g7 = load_golden("g7_field_grads")
+    x, sun, img = T(g3["x"])[:64].cuda(), T(g3["sun"])[:64].cuda(), T(g3["img"])[:64].cuda()
+    xs = x.clone().requires_grad_(True)
+    f.zero_grad()
+    out_grad = f(xs, sun, img)
+    with torch.no_grad():
+        out_plain = f(x, sun, img)
+    for a, b in zip(out_grad, out_plain):                # training-mode chain == inference chain, bit for bit
+        assert torch.equal(a.detach(), b)
+    _g7_scalar(f, xs, sun, img).backward()
+    params = dict(f.named_parameters())
+    for k, v in g7.items():
+        if not k.startswith("grad.") or v.shape[0] < 100:
+            continue
+        got, ref = compact_grad(params[k[5:]].grad)[2:], T(v)[2:]
+        cos = torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30)
+        assert cos > 0.99, (k, cos.item())
+    dx_ref = T(g7["dx"]).flatten().double()
+    got = xs.grad.cpu().flatten().double()
+    assert torch.dot(got, dx_ref) / (got.norm() * dx_ref.norm()) > 0.98
+
+
+def test_field_autograd_matches_torch_autograd_on_the_oracle_random_weights_ragged():
+    n_img = 4
+    sd = orc.random_state_dict(n_img, seed=31, bias_scale=0.1)
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    f = EONerfMLP(n_img, radiometric_normalization=True, precision="fp32")
+    f.load_state_dict(sd, strict=True)
+    f = f.cuda()
+    g = torch.Generator().manual_seed(32)
+    for n in (1, 37, 300):
+        x = torch.rand(n, 3, generator=g) * 2 - 1
+        sun = torch.randn(n, 3, generator=g)
+        img = torch.randint(0, n_img, (n, 1), generator=g)
+        w = [torch.randn(n, c, generator=g) for c in (1, 3, 3, 1, 1)]
+        sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        xo = x.clone().requires_grad_(True)
+        ref = orc.Field(sdg).forward(xo, sun, img)
+        sum((o * wi).sum() for o, wi in zip(ref, w)).backward()
+        xs = x.cuda().requires_grad_(True)
+        f.zero_grad()
+        got = f(xs, sun.cuda(), img.cuda())
+        sum((o * wi.cuda()).sum() for o, wi in zip(got, w)).backward()
+        assert (xs.grad.cpu() - xo.grad).norm().item() <= 2e-3 * xo.grad.norm().item() + 1e-7, n
+        for name, p in f.named_parameters():
+            rg = sdg[name].grad
+            if rg is None:
+                assert p.grad is None or p.grad.abs().max().item() == 0.0, name
+                continue
+            assert (p.grad.cpu() - rg).norm().item() <= 2e-3 * rg.norm().item() + 1e-6, (n, name)

@@ -34,7 +34,7 @@ def g8_sd(g):
 
 def test_library_loaded_and_versions():
     from eonerf_code_amd import _lib
-    assert _lib.lib().eonerf_version() == 100
+    assert _lib.lib().eonerf_version() == 200
     assert torch.cuda.is_available()
 
 
@@ -213,11 +213,15 @@ def test_rendering_and_render_depth_on_flattened_samples_fp32():
         ref_depth = orc.render_depth(orc.Field(sd), orays, a, b, ri)
     hrays = define_satrays_from_tensors(rays.cuda(), ts.cuda())
     te = b.clone().cuda()
-    got = f.rendering(hrays, a.cuda(), te, ri.cuda())
+    with pytest.raises(RuntimeError, match="inference entry point"):      # trainable parameters + recording autograd: loud, not graph-less
+        f.rendering(hrays, a.cuda(), te, ri.cuda())
+    with torch.no_grad():
+        got = f.rendering(hrays, a.cuda(), te, ri.cuda())
     for name, r, h in zip(("albedo", "depth", "beta", "ts", "ambient", "entropy"), ref, got):
         assert (h.cpu() - r).abs().max().item() < 1e-4, name
     assert (te == 1e10).sum().item() == (torch.bincount(ri, minlength=R) > 0).sum().item()    # in-place patch like the reference
-    d2 = f.render_depth(hrays, a.cuda(), b.clone().cuda(), ri.cuda())
+    with torch.no_grad():
+        d2 = f.render_depth(hrays, a.cuda(), b.clone().cuda(), ri.cuda())
     assert (d2.cpu() - ref_depth).abs().max().item() < 1e-4 and d2[5].item() == 0.0
 
 

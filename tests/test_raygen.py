@@ -156,3 +156,31 @@ def test_load_rays_from_metadata_cache_roundtrip_and_oracle(tmp_path):
     bad = np.abs(got - ref) > 1e-6
     assert bad.mean() < 1e-3, bad.mean()
     assert np.abs(np.linalg.norm(got[:, 3:6], axis=1) - 1).max() < 1e-6 and np.abs(np.linalg.norm(got[:, 8:11], axis=1) - 1).max() < 1e-6
+
+
+def test_load_rays_cache_semantics_8_vs_11_columns_cpu(tmp_path):
+    """datasets/satellite.py:441-476: 8-column caches are un-normalised (sun appended, normalised on load), 11-column caches are
+    FINAL rays and pass through unchanged; a mix is rejected (the reference would normalise everything twice or nothing)."""
+    from eonerf_code_amd.datasets import satellite as ds
+    h, w, n_img = 6, 5, 2
+    files = _write_scene(tmp_path, n_img, h, w)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    raws = []
+    for t in range(n_img):
+        rpc = rg.synthetic_rpc(seed=10 + t)
+        zone = rg.utm_zone_number(rpc["lat_offset"], rpc["lon_offset"])
+        cols, rows = np.meshgrid(np.arange(w), np.arange(h))
+        raw = rg.get_rays(cols.flatten(), rows.flatten(), rpc, -20.0, 90.0, zone)
+        raws.append(raw)
+        torch.save(torch.from_numpy(raw), cache / f"JAX_999_{t:03d}_RGB.data")
+    rays, ids, shapes, loc = ds.load_rays(files, scene_loc=None, cache_dir=str(cache), device="cpu")
+    assert rays.shape == (n_img * h * w, 11) and np.abs(rays[:, :3].numpy()).max() <= 1.01
+    # now cache the FINAL rays (11 columns): the next load returns them bit for bit, without normalising again
+    for t in range(n_img):
+        torch.save(rays[t * h * w:(t + 1) * h * w].clone(), cache / f"JAX_999_{t:03d}_RGB.data")
+    rays2, ids2, _, _ = ds.load_rays(files, scene_loc=loc, cache_dir=str(cache), device="cpu")
+    assert torch.equal(rays2, rays) and torch.equal(ids2, ids)
+    torch.save(torch.from_numpy(raws[0]), cache / "JAX_999_000_RGB.data")     # image 0 back to 8 columns: a mix
+    with pytest.raises(ValueError, match="mix"):
+        ds.load_rays(files, scene_loc=loc, cache_dir=str(cache), device="cpu")
