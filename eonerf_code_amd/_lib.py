@@ -87,7 +87,7 @@ def lib():
     L.eonerf_field_backward.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_train_loss.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
     L.eonerf_generate_rays.argtypes = [C.POINTER(EonerfRpc), vp, vp, C.c_long, i, C.c_double, C.c_double, i, i, C.c_double, C.c_double,
-                                       C.POINTER(fp), C.POINTER(fp), vp, vp, vp]
+                                       C.POINTER(fp), C.POINTER(fp), vp, vp, vp, vp]
     L.eonerf_sample_rays.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_set_noise_seed.argtypes = [vp, C.c_uint64]
     L.eonerf_rendering.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]

@@ -522,8 +522,8 @@ int eonerf_field_backward(eonerf_ctx* ctx, const float* flat, const float* sun, 
 int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double* rows, long n, int width,
                          double min_alt, double max_alt, int utm_zone, int south,
                          double sun_elevation_deg, double sun_azimuth_deg, const float offset[3], const float scale[3],
-                         float* raw8, float* rays, void* stream) {
-    if (!rpc || n < 0 || (!raw8 && !rays) || (!cols != !rows) || (!cols && width < 1) || utm_zone < 1 || utm_zone > 60) return EONERF_E_ARG;
+                         float* raw8, float* rays, double* geo, void* stream) {
+    if (!rpc || n < 0 || (!raw8 && !rays && !geo) || (!cols != !rows) || (!cols && width < 1) || utm_zone < 1 || utm_zone > 60) return EONERF_E_ARG;
     if (rays && (!offset || !scale)) return EONERF_E_ARG;
     if (n == 0) return EONERF_OK;
     static_assert(sizeof(eonerf_rpc) == sizeof(RpcModel), "RPC struct mismatch");
@@ -548,7 +548,7 @@ int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double
     const double el = (90.0 - (90.0 - sun_elevation_deg)) * d2r, az = sun_azimuth_deg * d2r;
     a.sun[0] = -1.0 * (sin(az) * cos(el)); a.sun[1] = -1.0 * (cos(az) * cos(el)); a.sun[2] = -1.0 * sin(el);
     for (int k = 0; k < 3; ++k) { a.offset[k] = offset ? offset[k] : 0.f; a.scale[k] = scale ? scale[k] : 1.f; }
-    a.raw8 = raw8; a.rays = rays;
+    a.raw8 = raw8; a.rays = rays; a.geo = geo;
     return (int)eo_launch_raygen(a, (hipStream_t)stream);
 }
 

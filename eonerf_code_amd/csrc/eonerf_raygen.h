@@ -18,5 +18,6 @@ struct RayGenArgs {
     float offset[3], scale[3];      // scene.loc_utm X/Y/Z offset and scale (fp32, datasets/satellite.py:303-307)
     float* raw8;                    // optional [n,8] un-normalised rays (the reference's <cache_dir>/<img>.data payload)
     float* rays;                    // optional [n,11] normalised rays
+    double* geo;                    // optional [n,8] fp64: lon, lat (deg), east, north (m) at max_alt, then the same at min_alt
 };
 hipError_t eo_launch_raygen(const RayGenArgs& a, hipStream_t st);

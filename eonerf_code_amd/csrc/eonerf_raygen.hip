@@ -82,8 +82,10 @@ __global__ __launch_bounds__(128) void k_raygen(RayGenArgs a) {
     double lon, lat, e0, n0, e1, n1;
     localize(a.rpc, col, row, a.max_alt, lon, lat);          // highest points are the closest to the camera (:87-91)
     utm_forward(a.utm, lat, lon, e0, n0);
+    if (a.geo) { a.geo[i * 8] = lon; a.geo[i * 8 + 1] = lat; a.geo[i * 8 + 2] = e0; a.geo[i * 8 + 3] = n0; }
     localize(a.rpc, col, row, a.min_alt, lon, lat);
     utm_forward(a.utm, lat, lon, e1, n1);
+    if (a.geo) { a.geo[i * 8 + 4] = lon; a.geo[i * 8 + 5] = lat; a.geo[i * 8 + 6] = e1; a.geo[i * 8 + 7] = n1; }
     const double dx = e1 - e0, dy = n1 - n0, dz = a.min_alt - a.max_alt;
     const double len = sqrt(dx * dx + dy * dy + dz * dz);
     // the reference stores these eight numbers as float32 (datasets/satellite.py:119-120) before normalising

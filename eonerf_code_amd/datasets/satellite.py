@@ -70,10 +70,13 @@ def utm_zone_from_lonlat(lon, lat):
 
 
 def generate_rays(rpc, min_alt, max_alt, h=None, w=None, cols=None, rows=None, img_downscale=1.0, sun_elevation_deg=None,
-                  sun_azimuth_deg=None, scene_offset=None, scene_scale=None, zone=None, south=None, device="cuda", want_raw=False):
+                  sun_azimuth_deg=None, scene_offset=None, scene_scale=None, zone=None, south=None, device="cuda", want_raw=False,
+                  want_geo=False):
     """Rays of one image.  With scene_offset/scale (scene.loc_utm X/Y/Z) -> normalised fp32 [N,11] rays (what load_data keeps,
     datasets/satellite.py:456-478); want_raw additionally (or alone) returns the un-normalised [N,8] rays of get_rays
-    (:65-121), the payload of the reference's cache files.  Pixels: the full h x w grid, or explicit cols/rows."""
+    (:65-121), the payload of the reference's cache files.  Pixels: the full h x w grid, or explicit cols/rows.
+    want_geo: returns ONLY the fp64 intermediates [N,8] (lon, lat, east, north at max_alt, then at min_alt) -- the values of
+    rpc.localization / utm_from_latlon before the fp32 cast of :119-120 (tests)."""
     import ctypes as C
     import torch
     from .. import _lib
@@ -94,10 +97,13 @@ def generate_rays(rpc, min_alt, max_alt, h=None, w=None, cols=None, rows=None, i
     raw = torch.empty(n, 8, dtype=torch.float32, device=dev) if (want_raw or not normalise) else None
     off = (C.c_float * 3)(*[float(x) for x in scene_offset]) if normalise else None
     sc = (C.c_float * 3)(*[float(x) for x in scene_scale]) if normalise else None
+    geo = torch.empty(n, 8, dtype=torch.float64, device=dev) if want_geo else None
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().eonerf_generate_rays(C.byref(s), _ptr(c), _ptr(r), n, width, float(min_alt), float(max_alt), int(zone),
                                                    1 if south else 0, float(sun_elevation_deg or 0.0), float(sun_azimuth_deg or 0.0),
-                                                   off, sc, _ptr(raw), _ptr(rays), _stream()))
+                                                   off, sc, _ptr(raw), _ptr(rays), _ptr(geo), _stream()))
+    if want_geo:
+        return geo
     if normalise and want_raw:
         return rays, raw
     return rays if normalise else raw

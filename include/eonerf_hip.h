@@ -105,11 +105,13 @@ typedef struct {
  * rays[n,11] fp32 normalised rays incl. the sun direction (may be NULL).  utm_zone/south select "+proj=utm +zone=.. [+south]"
  * (sat_utils.py:99-116); sun_elevation_deg/sun_azimuth_deg are the JSON's values (the 90-elevation flip of :457 happens
  * inside); offset/scale are scene.loc_utm's X/Y/Z values.  RPC localisation (rpcm) and the UTM projection (PROJ) are
- * re-implemented from their published algorithms in fp64. */
+ * re-implemented from their published algorithms in fp64.  geo (may be NULL): the fp64 intermediates [n,8] = lon, lat (degrees),
+ * UTM east, north (metres) of the localised point at max_alt, then at min_alt -- what rpc.localization and
+ * utm_from_latlon return BEFORE the fp32 cast of datasets/satellite.py:119-120 (test / diagnostic output). */
 int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double* rows, long n, int width,
                          double min_alt, double max_alt, int utm_zone, int south,
                          double sun_elevation_deg, double sun_azimuth_deg, const float offset[3], const float scale[3],
-                         float* raw8, float* rays, void* stream);
+                         float* raw8, float* rays, double* geo, void* stream);
 
 /* Key of the in-kernel jitter stream (torch.manual_seed's role for perturb_z_vals' rand_like, sat_rendering.py:52;
  * data-parallel ranks use different seeds).  Every call that draws noise advances the stream. */

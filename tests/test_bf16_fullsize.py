@@ -1,0 +1,54 @@
+"""GPU: what the benchmarked precision (bf16 MFMA) does to the outputs at the BENCH size -- 4096 rays x 128 samples, ~4.9e5 samples
+per pass -- measured against the fp32-HIP path on identical rays, jitter and weights.  The fp32 path is itself pinned to the
+reference goldens / the oracle at 1e-4 (tests/test_hip_forward.py, test_hip_backward.py), so this chains bf16 to the reference at
+full size, where the CPU oracle is too slow to be the checker.
+
+Two weight states (tests/bf16_common.py):
+  (a) Xavier-uniform init (mlp.py:22-28): smooth, flat density;
+  (b) the same field after 400 optimisation steps (autograd path, in-kernel jitter) on a synthetic terrain with depth + colour
+      supervision: density concentrated around a surface -- the regime a DSM is exported from.
+Bounds (measured on MI355X, round 2: scripts/bf16_vs_fp32.py; values in DESIGN.md 4):
+  rgb            max |d| <= 5e-3 (a) / 2.5e-2 (b),  mean <= 1e-4 / 1e-3
+  depth          mean |d| <= 1.5e-4 (a) / 3e-4 (b)   (normalised units)
+  altitude       datasets/satellite.py:502-533 at Z_scale = 50 m:  MAE <= 0.5 cm (a), <= 1.0 cm (b) -- the north-star criterion
+                 "DSM altitude within 1 cm" -- and the 99th percentile <= 2 cm (a) / 5 cm (b)
+  gradients      one full train step (shadow pass + uncertainty loss), per tensor: cosine >= 0.999 (a) / 0.99 (b) against the fp32
+                 path's gradient, relative L2 error <= 3e-2 (a) / 1.5e-1 (b)
+The per-sample noise of bf16 activations averages out along a ray; what remains in (b) is mostly the systematic part (bf16-rounded
+WEIGHTS shift the learned surface by a fraction of a sample spacing).  A field trained in bf16 mode has learned with those rounded
+weights; for a bit-faithful export the same checkpoint renders in precision="fp32" (1e-4 parity mode).
+"""
+import json
+
+import pytest
+import torch
+
+from bf16_common import compare_precisions, make_fields, train_on_terrain
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(st, rgb_max, rgb_mean, depth_mean, alt_mae, alt_p99, cos_min, rel_max):
+    print("bf16 vs fp32 at 4096 x 128:", json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in st.items()}))
+    assert st["n_samples_equal"], "the sampler is precision independent: sample counts must be identical"
+    assert st["rgb_max"] <= rgb_max and st["rgb_mean"] <= rgb_mean, (st["rgb_max"], st["rgb_mean"])
+    assert st["depth_mean"] <= depth_mean, st["depth_mean"]
+    assert st["alt_mae_m"] <= alt_mae, f"altitude MAE {st['alt_mae_m'] * 100:.2f} cm"
+    assert st["alt_p99_m"] <= alt_p99, f"altitude p99 {st['alt_p99_m'] * 100:.2f} cm"
+    assert st["grad_cos_min"] >= cos_min, (st["grad_cos_min_name"], st["grad_cos_min"])
+    assert st["grad_rel_max"] <= rel_max, st["grad_rel_max"]
+
+
+def test_bf16_vs_fp32_xavier_init_full_size():
+    f16, f32 = make_fields(seed=42)
+    _check(compare_precisions(f16, f32, seed=1), rgb_max=5e-3, rgb_mean=1e-4, depth_mean=1.5e-4, alt_mae=0.005, alt_p99=0.02,
+           cos_min=0.999, rel_max=3e-2)
+
+
+def test_bf16_vs_fp32_trained_field_altitude_within_1cm_full_size():
+    f16, f32 = make_fields(seed=42)
+    train_on_terrain(f16, 400)
+    f32.load_state_dict(f16.state_dict())
+    st = compare_precisions(f16, f32, seed=1)
+    assert st["depth_err_vs_terrain_mean"] < 0.1                    # the field did learn the terrain (from 0.19 at init)
+    _check(st, rgb_max=2.5e-2, rgb_mean=1e-3, depth_mean=3e-4, alt_mae=0.010, alt_p99=0.05, cos_min=0.99, rel_max=1.5e-1)

@@ -184,3 +184,103 @@ def test_load_rays_cache_semantics_8_vs_11_columns_cpu(tmp_path):
     torch.save(torch.from_numpy(raws[0]), cache / "JAX_999_000_RGB.data")     # image 0 back to 8 columns: a mix
     with pytest.raises(ValueError, match="mix"):
         ds.load_rays(files, scene_loc=loc, cache_dir=str(cache), device="cpu")
+
+
+# ---- narrowing the unpinned surface of H1 / N2 (still parity-UNPINNED w.r.t. rpcm / pyproj: see the module docstring) -----------
+def worldview_like_rpc(seed=0):
+    """An RPC with the magnitudes of a WorldView-3 DFC2019 crop (datasets' JSON "rpc" entries): image normalisation of a few
+    thousand pixels, ground footprint of ~0.02 deg, height scale 500 m, second-order terms ~1e-3, cubic terms ~1e-5, denominators
+    1 + O(1e-3) -- larger non-linearities than synthetic_rpc(), so the localisation needs its iterations."""
+    g = np.random.default_rng(seed)
+    rpc = {"row_offset": 1100.0, "col_offset": 1050.0, "row_scale": 1101.0, "col_scale": 1051.0,
+           "lat_offset": 30.3325, "lon_offset": -81.6610, "alt_offset": -10.0,
+           "lat_scale": 0.0032, "lon_scale": 0.0037, "alt_scale": 501.0}
+
+    def num(lin_lon, lin_lat, lin_alt, const):
+        p = np.zeros(20)
+        p[4:10] = 1e-3 * g.standard_normal(6)
+        p[10:20] = 1e-5 * g.standard_normal(10)
+        p[0], p[1], p[2], p[3] = const, lin_lon, lin_lat, lin_alt
+        return p.tolist()
+
+    def den():
+        p = np.zeros(20)
+        p[1:4] = 1e-3 * g.standard_normal(3)
+        p[4:10] = 1e-5 * g.standard_normal(6)
+        p[10:20] = 1e-6 * g.standard_normal(10)
+        p[0] = 1.0
+        return p.tolist()
+
+    rpc["col_num"], rpc["row_num"] = num(1.002, 0.0123, -0.0951, 1.3e-3), num(-0.0184, -1.009, 0.0873, -2.1e-3)
+    rpc["col_den"], rpc["row_den"] = den(), den()
+    return rpc
+
+
+@pytest.mark.gpu
+def test_hip_ray_generation_worldview_scale_rpc_downscale_2():
+    from eonerf_code_amd.datasets.satellite import generate_rays, utm_zone_from_lonlat
+    rpc = worldview_like_rpc(seed=7)
+    downscale = 2.0
+    h, w = int(2200 // downscale) // 8, int(2100 // downscale) // 8          # a 137 x 131 corner of the half-resolution image
+    rpc_s = rg.rescale_rpc(rpc, 1.0 / downscale)
+    zone, south = utm_zone_from_lonlat(rpc["lon_offset"], rpc["lat_offset"])
+    off, sc = _scene(rpc_s, h, w, zone)
+    ref, ref_raw = rg.image_rays(rpc_s, h, w, -30.0, 120.0, 47.0, 163.0, off, sc, zone)
+    rays, raw = generate_rays(rpc, -30.0, 120.0, h=h, w=w, img_downscale=downscale, sun_elevation_deg=47.0, sun_azimuth_deg=163.0,
+                              scene_offset=off, scene_scale=sc, want_raw=True)
+    rays, raw = rays.cpu().numpy(), raw.cpu().numpy()
+    quantum = np.spacing(np.abs(ref_raw).astype(np.float32))
+    d_raw = np.abs(raw.astype(np.float64) - ref_raw.astype(np.float64))
+    assert (d_raw <= 1.01 * quantum).all() and (d_raw > 0).mean() < 1e-3
+    d = np.abs(rays.astype(np.float64) - ref.astype(np.float64))
+    assert (d > 2e-6).mean() < 1e-3 and d[:, 8:11].max() < 1e-6 and d[:, 3:6].max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,seed", [("synthetic", 3), ("worldview", 8)])
+def test_projection_of_hip_localization_returns_the_pixel(kind, seed):
+    """In-tree anchor: the RPC polynomial of the reference (apply_poly's term order, sat_utils.py:437-450, restated in the oracle)
+    applied to the lon/lat the HIP kernel localised must give back the pixel: |projection(localization(px)) - px| < 1e-6 px."""
+    from eonerf_code_amd.datasets.satellite import generate_rays
+    rpc = rg.synthetic_rpc(seed=seed) if kind == "synthetic" else worldview_like_rpc(seed)
+    g = np.random.default_rng(1)
+    cols, rows = g.uniform(0, 2000, 700), g.uniform(0, 2000, 700)
+    lo, hi = -25.0, 110.0
+    geo = generate_rays(rpc, lo, hi, cols=cols, rows=rows, want_geo=True).cpu().numpy()
+    for k, alt in ((0, hi), (4, lo)):
+        c2, r2 = rg.projection(rpc, geo[:, k], geo[:, k + 1], alt)
+        assert np.abs(c2 - cols).max() < 1e-6 and np.abs(r2 - rows).max() < 1e-6
+    # and the two numerical cores agree with the oracle's in fp64, before any fp32 rounding
+    lon, lat = rg.localization(rpc, cols, rows, hi * np.ones(700))
+    assert np.abs(geo[:, 0] - lon).max() < 1e-11 and np.abs(geo[:, 1] - lat).max() < 1e-11
+    zone = rg.utm_zone_number(rpc["lat_offset"], rpc["lon_offset"])
+    e, n = rg.utm_forward(geo[:, 1], geo[:, 0], zone)
+    assert np.abs(geo[:, 2] - e).max() < 1e-6 and np.abs(geo[:, 3] - n).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_krueger_series_closed_form_anchors_on_the_gpu_path():
+    """The UTM projection INSIDE the HIP kernel against closed-form anchors (not only the numpy oracle): an identity RPC
+    (col -> longitude, row -> latitude) steers the kernel to exact geodetic points of zone 17 (central meridian 81 W)."""
+    from eonerf_code_amd.datasets.satellite import generate_rays
+    ident = {"row_offset": 0.0, "col_offset": 0.0, "row_scale": 1.0, "col_scale": 1.0, "lat_offset": 0.0, "lon_offset": -81.0,
+             "alt_offset": 0.0, "lat_scale": 1.0, "lon_scale": 1.0, "alt_scale": 1.0}
+    z = [0.0] * 20
+    ident["col_num"] = [0.0, 1.0] + [0.0] * 18                     # poly[1] multiplies the normalised longitude (apply_poly)
+    ident["row_num"] = [0.0, 0.0, 1.0] + [0.0] * 17                # poly[2] multiplies the normalised latitude
+    ident["col_den"] = [1.0] + [0.0] * 19
+    ident["row_den"] = [1.0] + [0.0] * 19
+    # pixels = (lon - (-81), lat): equator & 30 N on the central meridian, 30 N one degree either side, 45 N on the meridian
+    cols = np.array([0.0, 0.0, 1.0, -1.0, 0.0])
+    rows = np.array([0.0, 30.0, 30.0, 30.0, 45.0])
+    geo = generate_rays(ident, -1.0, 1.0, cols=cols, rows=rows, zone=17, south=False, want_geo=True).cpu().numpy()
+    assert np.abs(geo[:, 0] - (-81.0 + cols)).max() < 1e-12 and np.abs(geo[:, 1] - rows).max() < 1e-12
+    e, n = geo[:, 2], geo[:, 3]
+    assert abs(e[0] - 500000.0) < 1e-8 and abs(n[0]) < 1e-8                      # equator x central meridian
+    assert abs(e[1] - 500000.0) < 1e-8 and abs(e[4] - 500000.0) < 1e-8           # on the central meridian east = false easting
+    # meridian arc lengths on WGS84 (geodesy tables): equator -> 30 N = 3 320 113.398 m, -> 45 N = 4 984 944.378 m; x k0
+    assert abs(n[1] - 0.9996 * 3320113.398) < 2e-3 and abs(n[4] - 0.9996 * 4984944.378) < 2e-3
+    # symmetry about the central meridian
+    assert abs((e[2] - 500000.0) + (e[3] - 500000.0)) < 1e-7 and abs(n[2] - n[3]) < 1e-7
+    # one degree of longitude at 30 N ~ 96.49 km on the ellipsoid, shortened by the scale factor near the meridian
+    assert 96400.0 < e[2] - 500000.0 < 96520.0

@@ -1,0 +1,117 @@
+"""GPU: FusedTrainer host logic -- argument checks, stale packed weights after in-place parameter changes, checkpoint resume
+(train_eonerf.py:180-191 / eval_eonerf.py:44-75), torch.optim.Adam's per-parameter step counts."""
+import pytest
+import torch
+
+from oracle import eonerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+N_IMG, R = 4, 128
+
+
+def _make(seed=91, precision="fp32"):
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    from eonerf_code_amd.trainer import FusedTrainer
+    sd = orc.random_state_dict(N_IMG, seed=seed, bias_scale=0.05)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    f = EONerfMLP(N_IMG, radiometric_normalization=True, precision=precision)
+    f.load_state_dict(sd, strict=True)
+    f = f.cuda()
+    return f, FusedTrainer(f, lr=5e-4, max_rays=R), sd
+
+
+def _batch(seed=92):
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R, N_IMG, seed=seed)
+    return rays.cuda(), ts.reshape(-1).cuda(), rgbs.cuda(), (u_cam.cuda(), None, u_sun.cuda())
+
+
+def test_step_rejects_oversized_and_malformed_batches():
+    f, tr, _ = _make()
+    rays, img, pix, noise = _batch()
+    big = torch.cat([rays, rays])
+    with pytest.raises(ValueError, match="max_rays"):
+        tr.step(big, torch.cat([img, img]), torch.cat([pix, pix]), 0)
+    with pytest.raises(ValueError, match="contiguous"):
+        tr.step(big[::2], img, pix, 0)                               # strided view of a table
+    with pytest.raises(ValueError, match="int64"):
+        tr.step(rays, img.int(), pix, 0)
+
+
+def test_in_place_weight_changes_reach_the_packed_streams():
+    # load_state_dict after the trainer was built (what load_checkpoint does): the next step must run on the NEW weights in the
+    # MLP chains too, not only in the tables read from the flat buffer
+    f, tr, sd = _make(seed=91)
+    rays, img, pix, noise = _batch()
+    sd2 = orc.random_state_dict(N_IMG, seed=17, bias_scale=0.05)
+    sd2["sigma_layer.output_layer.bias"] += 1.0
+    f.load_state_dict(sd2, strict=True)
+    loss_a = float(tr.step(rays, img, pix, 3, noise=noise))
+    g_a = tr.d_flat.clone()
+    f2, tr2, _ = _make(seed=17)
+    loss_b = float(tr2.step(rays, img, pix, 3, noise=noise))
+    assert abs(loss_a - loss_b) < 1e-6
+    assert (g_a - tr2.d_flat).norm().item() <= 1e-4 * tr2.d_flat.norm().item()
+
+
+def test_checkpoint_resume_continues_the_uninterrupted_run(tmp_path):
+    from eonerf_code_amd.checkpoint import save_checkpoint, load_checkpoint
+    rays, img, pix, noise = _batch()
+    rays2, img2, pix2, noise2 = _batch(seed=93)
+    # uninterrupted: 3 steps (2 before the shadow pass, 1 after) + 1 more
+    f, tr, _ = _make()
+    for epoch in (0, 1, 2):
+        tr.step(rays, img, pix, epoch, noise=noise)
+    path = save_checkpoint(str(tmp_path / "ckpts" / "epoch=2.ckpt"), 2, f, tr)
+    loss_ref = float(tr.step(rays2, img2, pix2, 3, noise=noise2))
+    g_ref, p_ref = tr.d_flat.clone(), tr.flat.detach().clone()
+    # resumed: fresh field (other weights) + trainer, load, same 4th step
+    f2, tr2, _ = _make(seed=5)
+    assert load_checkpoint(path, f2, tr2) == 2
+    assert tr2.step_count == 3 and tr2.step_late == 1
+    loss = float(tr2.step(rays2, img2, pix2, 3, noise=noise2))
+    assert abs(loss - loss_ref) < 1e-6
+    assert (tr2.d_flat - g_ref).norm().item() <= 1e-4 * g_ref.norm().item()
+    assert (tr2.flat.detach() - p_ref).abs().max().item() <= 2e-5      # Adam's sign-like first steps amplify 1e-7 gradient noise
+    ck = torch.load(path, weights_only=False)
+    st = ck["optimizer_state_dict"]["state"]
+    names = [n for n, _ in f.named_parameters()]
+    assert all(float(st[i]["step"]) == (1.0 if names[i] in tr.late_names else 3.0) for i in st)
+
+
+def test_adam_late_parameters_follow_torch_adam_with_none_grads():
+    # reference semantics: transient / ambient parameters get grad None for the first steps (torch.optim.Adam skips them), then
+    # start their own bias-correction count
+    import ctypes as C
+    from eonerf_code_amd import _lib
+    from eonerf_code_amd.radiance_fields.eonerf import _ptr, _stream
+    f, tr, _ = _make()
+    flat = tr.flat
+    layout = f._layout
+    late = torch.zeros(flat.numel(), dtype=torch.bool)
+    real = torch.zeros(flat.numel(), dtype=torch.bool)              # tensors sit at 16-byte aligned offsets: skip the padding floats
+    for name, off, r, c in layout:
+        real[off:off + r * c] = True
+        if name in tr.late_names:
+            late[off:off + r * c] = True
+    assert late.sum().item() > 80000 and "transient_encoder.weight" in tr.late_names and "ambient_mlp.output_layer.bias" in tr.late_names
+    main = real & ~late
+    p_main = flat.detach().cpu()[main].clone().requires_grad_(True)
+    p_late = flat.detach().cpu()[late].clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_main, p_late], lr=5e-4)
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    g = torch.Generator().manual_seed(3)
+    step_late = 0
+    for step in range(1, 6):
+        grad = torch.randn(flat.numel(), generator=g) * 0.01
+        in_graph = step >= 3
+        if not in_graph:
+            grad[late] = 0.0
+        p_main.grad = grad[main].clone()
+        p_late.grad = grad[late].clone() if in_graph else None
+        opt.step()
+        step_late += 1 if in_graph else 0
+        _lib.check(_lib.lib().eonerf_adam_step_late(f._ctx, _ptr(flat), _ptr(grad.cuda()), _ptr(m), _ptr(v), step, step_late,
+                                                    5e-4, 0.9, 0.999, 1e-8, 1.0, _stream()))
+    got = flat.detach().cpu()
+    assert (got[main] - p_main.detach()).abs().max().item() < 1e-6
+    assert (got[late] - p_late.detach()).abs().max().item() < 1e-6
