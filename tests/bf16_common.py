@@ -77,6 +77,11 @@ def compare_precisions(f16, f32, seed=1, epoch=3):
     dalt = (alt16 - alt32).abs()
     st["alt_mae_m"], st["alt_max_m"], st["alt_p99_m"] = dalt.mean().item(), dalt.max().item(), dalt.quantile(0.99).item()
     st["depth_err_vs_terrain_mean"] = (b["depth"] - depth_gt).abs().mean().item()
+    # the DSM-quality metric: altitude MAE against the (synthetic) ground truth, per precision -- north_star's criterion compares
+    # THIS number between the two paths ("DSM altitude MAE within 1 cm of reference")
+    alt_gt = get_utmalt_from_nerf_prediction(rays, depth_gt, off, sc)[2]
+    st["dsm_mae_bf16_m"] = (alt16 - alt_gt).abs().mean().item()
+    st["dsm_mae_fp32_m"] = (alt32 - alt_gt).abs().mean().item()
     # how concentrated sigma is: mean over rays of the weight-averaged |t - depth| is not exposed; use depth spread between two jitters
     # gradients of one full train step (uncertainty loss), same noise
     grads = []

@@ -10,7 +10,7 @@ Tolerances
       With the shadow pass on, d sigma/d position runs through the encoder derivative 2^k cos(2^k x) (k <= 9) and the
       reference's OWN fp32 autograd is only good to a few % against an fp64 evaluation of the same graph (measured:
       2-4 % on the G8 network).  There the criterion is "as exact as the reference's arithmetic":
-          |hip - fp64| <= 3 |fp32 reference - fp64| + 2e-3 |fp64|      (L2 norms per tensor).
+          |hip - fp64| <= 1.5 |fp32 reference - fp64| + 2e-3 |fp64|      (L2 norms per tensor; measured worst ratio in DESIGN.md 5).
   bf16 mode: gradients are bf16-rounded at every layer boundary; checked per tensor by relative L2 error < 6e-2 and
       cosine similarity > 0.998 against the fp32 oracle.
 """
@@ -67,6 +67,13 @@ def oracle_step64(sd, rays, ts, rgbs, u_cam, u_sun, epoch):
     return {k: v.grad for k, v in sdg.items() if v.is_floating_point()}
 
 
+# "as exact as the reference's own fp32 autograd": |hip - fp64| <= EXACT_FACTOR |ref32 - fp64| + 2e-3 |fp64| per tensor.
+# Measured on MI355X (round 2, printed by test_zz_report_exactness_ratios): the worst ratio err / (ref_err + 2e-3 |fp64|) over all
+# tensors and cases is recorded in DESIGN.md 5; the factor was 3 in round 1.
+EXACT_FACTOR = 1.5
+RATIOS = []
+
+
 def check_as_exact_as_reference(f, ref32, ref64, tag):
     for name, p in f.named_parameters():
         r64 = ref64[name] if ref64[name] is not None else torch.zeros_like(p, dtype=torch.float64, device="cpu")
@@ -74,7 +81,8 @@ def check_as_exact_as_reference(f, ref32, ref64, tag):
         got = (p.grad.cpu() if p.grad is not None else torch.zeros_like(r64)).double()
         ref_err = (r32 - r64).norm().item()
         err = (got - r64).norm().item()
-        assert err <= 3 * ref_err + 2e-3 * r64.norm().item() + 1e-9, (tag, name, err, ref_err, r64.norm().item())
+        RATIOS.append((err / (ref_err + 2e-3 * r64.norm().item() + 1e-9), tag, name))
+        assert err <= EXACT_FACTOR * ref_err + 2e-3 * r64.norm().item() + 1e-9, (tag, name, err, ref_err, r64.norm().item())
 
 
 @pytest.mark.parametrize("tag,epoch", [("e0", 0), ("e3", 3)])
@@ -97,7 +105,9 @@ def test_backward_fp32_matches_reference_autograd_g8(tag, epoch):
         ref = T(v)[2:]
         r64 = compact_grad(ref64[name] if ref64[name] is not None else torch.zeros_like(p, device="cpu"))[2:]
         ref_err = (ref - r64).norm().item()
-        assert (got - r64).norm().item() <= 3 * ref_err + 2e-3 * r64.norm().item() + 1e-9, (k, ref_err)
+        err = (got - r64).norm().item()
+        RATIOS.append((err / (ref_err + 2e-3 * r64.norm().item() + 1e-9), tag, name))
+        assert err <= EXACT_FACTOR * ref_err + 2e-3 * r64.norm().item() + 1e-9, (k, err, ref_err)
         if epoch < 2:    # no encoder-derivative path: direct agreement with the reference's fp32 numbers
             assert (got - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-7, k
 
@@ -201,3 +211,12 @@ def test_fused_trainer_matches_autograd_path_and_oracle():
             assert (g1 - g2).norm().item() <= 1e-4 * g1.norm().item() + 1e-9, (epoch, name)
         moved = (f2.flat_params() - before).abs().max().item()
         assert 0 < moved <= 5e-4 * 1.001                              # one Adam step moves a weight by at most lr
+
+
+def test_zz_report_exactness_ratios():
+    """Runs last in this file: prints the worst measured ratio err / (ref_err + 2e-3 |fp64|) of the fp32 gradient checks above."""
+    if not RATIOS:
+        pytest.skip("the fp32 gradient tests did not run in this session")
+    worst = sorted(RATIOS, reverse=True)[:5]
+    print("worst exactness ratios (err / (ref_err + 2e-3 |fp64|)):", [(round(r, 3), t, n) for r, t, n in worst])
+    assert worst[0][0] <= EXACT_FACTOR
