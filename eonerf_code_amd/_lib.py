@@ -21,7 +21,7 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_render_backward", "eonerf_adam_step", "eonerf_profile_enable", "eonerf_profile_read",
            "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering", "eonerf_generate_rays",
            "eonerf_adam_step_late", "eonerf_param_is_late", "eonerf_field_train_workspace_bytes", "eonerf_field_forward_train",
-           "eonerf_field_backward", "eonerf_set_noise_seed"]
+           "eonerf_field_backward", "eonerf_set_noise_seed", "eonerf_render_status"]
 
 
 class EonerfRpc(C.Structure):
@@ -85,6 +85,7 @@ def lib():
     L.eonerf_field_train_workspace_bytes.argtypes = [vp, i, i]
     L.eonerf_field_forward_train.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_field_backward.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.eonerf_render_status.argtypes = [vp, i, i, vp, sz, vp]
     L.eonerf_train_loss.argtypes = [vp, vp, vp, i, i, vp, vp, vp]
     L.eonerf_generate_rays.argtypes = [C.POINTER(EonerfRpc), vp, vp, C.c_long, i, C.c_double, C.c_double, i, i, C.c_double, C.c_double,
                                        C.POINTER(fp), C.POINTER(fp), vp, vp, vp, vp]

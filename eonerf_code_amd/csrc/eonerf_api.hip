@@ -43,7 +43,15 @@ struct PassBuffers {       // one MLP pass (camera or sun) over up to p_cap samp
     float *g_sigma, *g_albedo, *g_ts, *g_tb, *g_emb, *g_pos;
 };
 
+struct PipeWs {            // layer-pipelined trunk backward (eonerf_bwd_pipe.hip)
+    uint8_t* dy_in;        // dY_7 in unit order: p_cap x 512 B
+    uint8_t* rings;        // [n_pipes][6 edges][PIPE_RING][16 KiB]
+    uint32_t* sync;        // ONE block zeroed per launch: [0] role counter, [1] error bits, [64..) one scratch line per workgroup, then the edge flags
+    size_t sync_bytes;
+};
+
 struct RenderWs {
+    PipeWs pipe;
     int *cnt_first, *cnt_retry, *flags;
     float* ray_rec; float* g_ray; float* amb_save;
     float* m_bott;        // [2][128][256] fp32: dA1^T X8 and dT1^T X8 (factors of the bottleneck weight gradient)
@@ -59,7 +67,11 @@ struct eonerf_ctx {
     int n_cu;
     int wgrad_items;      // target number of weight-gradient work items per launch (EONERF_WGRAD_ITEMS, default 48 per job)
     ParamLayout pl;
-    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig;
+    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig, pipe_wt, bwd_full_heads, bwd_rgb_heads;
+    bool pipe = false;               // layer-pipelined trunk backward (bf16 camera pass; EONERF_PIPE=0 switches back to chain + GEMM)
+    int n_pipes = 0;
+    int pipe_fault_stage = -1;       // test hook (EONERF_PIPE_FAULT)
+    unsigned long long* pipe_stamps = nullptr;   // diagnostics (EONERF_PIPE_STAMPS=1): cycle sums per stage, read by eonerf_debug_pipe_stamps
     uint64_t noise_seed = 0x5eed5eedULL; uint32_t noise_call = 0;   // in-kernel Philox jitter (eonerf_set_noise_seed)
     bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
@@ -83,8 +95,10 @@ int upload(DevStream& d, const PackedStream& s) {
         HIP_TRY(hipMalloc(&d.e16, s.e16.size() * sizeof(PackEntry)));
         HIP_TRY(hipMemcpy(d.e16, s.e16.data(), s.e16.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc(&d.e32, s.e32.size() * sizeof(PackEntry)));
-    HIP_TRY(hipMemcpy(d.e32, s.e32.data(), s.e32.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+    if (d.n32) {
+        HIP_TRY(hipMalloc(&d.e32, s.e32.size() * sizeof(PackEntry)));
+        HIP_TRY(hipMemcpy(d.e32, s.e32.data(), s.e32.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 void release(DevStream& d) {
@@ -97,7 +111,7 @@ void release(DevStream& d) {
 
 // (re)packs the fp32 master weights into up to PACK_MAX_JOBS packed streams in ONE launch (blockIdx.y = job): after every
 // optimizer step three streams x {bf16, fp32} entries are rewritten, and six ~5 us launches cost more than the copies
-constexpr int PACK_MAX_JOBS = 8;
+constexpr int PACK_MAX_JOBS = 10;
 struct PackJob { const PackEntry* e; int n; uint8_t* data; int is16; };
 struct PackJobs { PackJob j[PACK_MAX_JOBS]; };
 __global__ void k_pack(const float* flat, PackJobs jobs) {
@@ -114,7 +128,7 @@ int pack(std::initializer_list<const DevStream*> streams, const float* flat, hip
     int n = 0, most = 1;
     for (const DevStream* d : streams) {
         if (d->n16) jobs.j[n++] = PackJob{d->e16, d->n16, d->data, 1};
-        jobs.j[n++] = PackJob{d->e32, d->n32, d->data, 0};
+        if (d->n32) jobs.j[n++] = PackJob{d->e32, d->n32, d->data, 0};
         most = std::max(most, std::max(d->n16, d->n32));
     }
     hipLaunchKernelGGL(k_pack, dim3(std::min((most + 255) / 256, 1024), n), dim3(256), 0, st, flat, jobs);
@@ -170,6 +184,13 @@ RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) 
     w.g_ray = train ? c.take<float>((size_t)n_rays * RAY_REC) : nullptr;
     w.amb_save = train ? c.take<float>((size_t)n_rays * 160) : nullptr;
     w.m_bott = train ? c.take<float>(2 * 128 * 256) : nullptr;
+    memset(&w.pipe, 0, sizeof(w.pipe));
+    if (train && ctx->pipe) {
+        w.pipe.dy_in = c.take<uint8_t>((size_t)p_cap * 512);
+        w.pipe.rings = c.take<uint8_t>((size_t)ctx->n_pipes * (PIPE_STAGES - 1) * PIPE_RING * PIPE_UNIT_B);
+        w.pipe.sync_bytes = (64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32 + (size_t)ctx->n_pipes * (PIPE_STAGES - 1) * 64) * sizeof(uint32_t);
+        w.pipe.sync = c.take<uint32_t>(w.pipe.sync_bytes / sizeof(uint32_t));
+    }
     carve_pass(c, w.cam, n_rays, p_cap, !od, train, false, ab);
     if (shadows && !od) carve_pass(c, w.sun, n_rays, p_cap, false, train, true, ab); else memset(&w.sun, 0, sizeof(w.sun));
     w.bytes = c.off + 256;
@@ -210,7 +231,7 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
 //   full: a pass through the whole field (camera pass / EONerfMLP.forward), with or without the transient head in the graph;
 //   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
-                         const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st) {
+                         const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false) {
     const ParamLayout& pl = ctx->pl;
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
@@ -228,11 +249,14 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         j.b_stride = (uint32_t)(bb.r * SEG_B);
         j.m_rows = m_rows; j.n_rows = n_rows; j.dw_ld = dw_ld; j.gm = gm; j.gn = gn; j.wm = wm; j.wn = wn;
     };
-    auto trunk_jobs = [&](const PassBuffers& b) {
+    // pipelined: the 256 x 256 products of layers 1..7 (and their biases) were accumulated by the layer-pipelined trunk backward;
+    // what is left are the two 256 x 64 products against the encoding (layer 0, skip columns of layer 5) and the sigma row
+    auto trunk_jobs = [&](const PassBuffers& b, bool pipelined) {
         add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
         for (int l = 1; l < 8; ++l) {
             const int in_ld = l == 5 ? 319 : 256;
-            add(b, GRD_ROW_Y0 + 256 * l, 256, ACT_ROW_X1 + 256 * (l - 1), 256, dptr(pl.trunk_w[l]), in_ld, dptr(pl.trunk_b[l]), nullptr, 2, 4, 4, 2);
+            if (!pipelined)
+                add(b, GRD_ROW_Y0 + 256 * l, 256, ACT_ROW_X1 + 256 * (l - 1), 256, dptr(pl.trunk_w[l]), in_ld, dptr(pl.trunk_b[l]), nullptr, 2, 4, 4, 2);
             if (l == 5)   // skip columns 256..318 <- encoding slots
                 add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1);
         }
@@ -240,7 +264,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     };
     if (full) {
         const PassBuffers& c = *full;
-        trunk_jobs(c);
+        trunk_jobs(c, full_trunk_done);
         // bottleneck layer: factor M_a = dA1^T X8 (and M_t = dT1^T X8), finished by eo_launch_bott_wgrad below
         HIP_TRY(hipMemsetAsync(m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
         add(c, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, nullptr, nullptr, 2, 4, 2, 2);
@@ -256,7 +280,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
             add(c, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
         }
     }
-    if (dens) trunk_jobs(*dens);
+    if (dens) trunk_jobs(*dens, false);
     // every work item = one slice of one job's sample range.  Equal slices: a K step costs about the same for every job shape
     // (the loop is latency-bound); default 48 slices per job (measured: flat from ~2.4 to 6.5 items per CU, clearly slower below 2)
     tab.items = 0;
@@ -291,6 +315,7 @@ const char* eonerf_strerror(int code) {
         case EONERF_E_WORKSPACE: return "eonerf: workspace too small";
         case EONERF_E_STATE: return "eonerf: call sequence error (set_weights / train forward missing)";
         case EONERF_E_UNSUPPORTED: return "eonerf: unsupported configuration";
+        case EONERF_E_DEVICE: return "eonerf: a device-side hand-off timed out (pipelined backward watchdog); the gradients of that step are invalid";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "eonerf: unknown error";
     }
 }
@@ -315,6 +340,17 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     if (!rc) rc = upload(ctx->bwd_dens, build_bwd_stream(ctx->pl, ctx->bf16, false, true));
     if (!rc) rc = upload(ctx->bwd_rgb, build_bwd_stream(ctx->pl, ctx->bf16, true, false, false));
     if (!rc) rc = upload(ctx->bwd_full_ig, build_bwd_stream(ctx->pl, ctx->bf16, true, true, true));
+    {
+        const char* e = getenv("EONERF_PIPE");
+        ctx->n_pipes = ctx->n_cu / PIPE_STAGES;
+        ctx->pipe = ctx->bf16 && ctx->n_pipes >= 1 && !(e && atoi(e) == 0);
+        if (!rc && ctx->pipe) rc = upload(ctx->pipe_wt, build_pipe_stream(ctx->pl));
+        if (!rc && ctx->pipe) rc = upload(ctx->bwd_full_heads, build_bwd_stream(ctx->pl, true, true, false, true, true));
+        if (!rc && ctx->pipe) rc = upload(ctx->bwd_rgb_heads, build_bwd_stream(ctx->pl, true, true, false, false, true));
+        { const char* f = getenv("EONERF_PIPE_FAULT"); ctx->pipe_fault_stage = f ? atoi(f) : -1; }
+        { const char* f = getenv("EONERF_PIPE_STAMPS");
+          if (!rc && ctx->pipe && f && atoi(f)) rc = (int)hipMalloc(&ctx->pipe_stamps, (size_t)ctx->n_pipes * PIPE_STAGES * 128 * sizeof(unsigned long long)); }
+    }
     if (!rc) {
         int cm[64];
         for (int s = 0; s < 64; ++s) cm[s] = enc_col_of_slot(ctx->bf16, s);
@@ -356,8 +392,9 @@ int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launc
 int eonerf_destroy(eonerf_ctx* ctx) {
     if (!ctx) return EONERF_E_ARG;
     for (int k = 0; k < 5; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
-    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig);
+    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
+    if (ctx->pipe_stamps) (void)hipFree(ctx->pipe_stamps);
     delete ctx;
     return EONERF_OK;
 }
@@ -377,7 +414,9 @@ int eonerf_param_info(const eonerf_ctx* ctx, int index, const char** name, size_
 int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     if (!ctx || !flat) return EONERF_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = pack({&ctx->fwd_full, &ctx->bwd_full, &ctx->bwd_rgb}, flat, st);
+    // pipelined backward: the camera pass reads the heads-only streams + the stage-stationary trunk weights
+    const int rc = ctx->pipe ? pack({&ctx->fwd_full, &ctx->bwd_full_heads, &ctx->bwd_rgb_heads, &ctx->pipe_wt}, flat, st)
+                             : pack({&ctx->fwd_full, &ctx->bwd_full, &ctx->bwd_rgb}, flat, st);
     if (!rc) { ctx->weights_set = true; ctx->dens_dirty = true; ctx->full_ig_dirty = true; }
     return rc;
 }
@@ -736,15 +775,35 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     memset(&mc, 0, sizeof(mc));
     mc.n_pts = w.cam.n_pts; mc.p_pad = p_cap;
     const bool transient = shadows || !(flags & EONERF_F_RGB_LOSS);
-    const DevStream& bs = transient ? ctx->bwd_full : ctx->bwd_rgb;
+    const bool pipe = ctx->pipe && w.pipe.dy_in;
+    const DevStream& bs = pipe ? (transient ? ctx->bwd_full_heads : ctx->bwd_rgb_heads) : (transient ? ctx->bwd_full : ctx->bwd_rgb);
     mc.stream = bs.data; mc.chunks = bs.chunks; mc.n_chunks = bs.n_chunks;
     mc.sigma = w.cam.sigma; mc.albedo = w.cam.albedo; mc.ts = w.cam.ts; mc.tb = w.cam.tb;
     mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
     mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
-    { ProfScope ps(ctx, 1, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st)); }
+    mc.dy7_units = pipe ? w.pipe.dy_in : nullptr;
+    {
+        ProfScope ps(ctx, 1, st);
+        HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st, pipe));
+        if (pipe) {      // trunk layers 7..1: dX chain + weight gradients, layer-pipelined (eonerf_bwd_pipe.hip)
+            HIP_TRY(hipMemsetAsync(w.pipe.sync, 0, w.pipe.sync_bytes, st));
+            BwdPipeArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.n_pts = w.cam.n_pts; pa.p_pad = p_cap; pa.n_pipes = ctx->n_pipes;
+            pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in; pa.act = w.cam.act; pa.masks = w.cam.masks; pa.grd = w.cam.grd;
+            pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(w.pipe.sync); pa.error = reinterpret_cast<int*>(w.pipe.sync) + 1;
+            pa.scratch_word = w.pipe.sync + 64; pa.flags = w.pipe.sync + 64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32;
+            pa.d_flat = d_flat; pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
+            for (int s = 0; s < PIPE_STAGES; ++s) {
+                const int l = 7 - s;
+                pa.dw_off[s] = pl.t[pl.trunk_w[l]].offset; pa.db_off[s] = pl.t[pl.trunk_b[l]].offset; pa.dw_ld[s] = l == 5 ? 319 : 256;
+            }
+            HIP_TRY(eo_launch_bwd_pipe(pa, st));
+        }
+    }
 
     {
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.flags + 2, st);
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.flags + 2, st, pipe);
         if (rcw) return rcw;
     }
 
@@ -760,6 +819,28 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
     HIP_TRY(eo_launch_ambient_bwd(ag, st));
     return EONERF_OK;
+}
+
+// diagnostics: copies the cycle sums of the last pipelined backward ([n_pipes * 7 roles][2 waves][8] u64) to the host; returns the
+// number of u64 written (0 when EONERF_PIPE_STAMPS is off)
+int eonerf_debug_pipe_stamps(eonerf_ctx* ctx, unsigned long long* host_out, int capacity) {
+    if (!ctx || !ctx->pipe_stamps || !host_out) return 0;
+    const int n = ctx->n_pipes * PIPE_STAGES * 128;
+    if (capacity < n) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpy(host_out, ctx->pipe_stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
+int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* ws, size_t ws_bytes, void* stream) {
+    if (!ctx || !ws || n_rays < 0) return EONERF_E_ARG;
+    RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    if (!w.pipe.sync) return EONERF_OK;
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, w.pipe.sync + 1, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return err ? EONERF_E_DEVICE : EONERF_OK;
 }
 
 int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, int n_rays, int kind, float* d_out, float* loss, void* stream) {

@@ -1,0 +1,386 @@
+// Layer-pipelined trunk backward (bf16): the dX chain AND the weight-gradient GEMM of trunk layers 7..1 in ONE launch, with the
+// inter-layer gradients dY_l kept on chip (H10 of SURVEY.md 8a; the layers are radiance_fields/mlp.py:87-101).
+//
+// The chain kernel (eonerf_mlp_bwd.hip) walks ALL layers for its 256 samples, so it re-streams every weight per tile and has to
+// park every dY_l in HBM for a separate GEMM (eonerf_wgrad.hip): 2.3 GB written + 5.4 GB read per 4096-ray step.  Here the
+// roles are turned around: one workgroup per LAYER ("stage"), 7 stages = one pipeline, floor(CUs / 7) pipelines.
+//   * W_l^T (128 KB bf16) is STATIONARY in the registers of the stage (wave w owns output m-tile w: 16 A units = 64 VGPRs);
+//   * dW_l (256 x 256 fp32) is STATIONARY in registers for the whole launch (wave w owns rows 32w..32w+31: 128 VGPRs);
+//   * per step of 32 samples the stage takes dY_l from its input ring (B-operand "unit" order [k-group 16][lane 64][16 B],
+//     exactly what the producer's accumulators pack to), the layer input X_l from the activation slab (feature-major rows ARE the
+//     B fragments of the dW product) and the 1-KiB ReLU-mask record, all by LDS-DMA into a 4-slot LDS ring, 3 steps in flight;
+//       dX = W_l^T dY_l                      16 MFMAs per wave  (A registers, B ds_read_b128 of the dY image)
+//       dY_{l-1} = dX .* relu'(mask)         packed to two 1-KiB units, stored write-through (sc1) into the output ring
+//       dW_l += dY_l X_l^T                   16 MFMAs per wave  (A = ds_read_b64_tr_b16 of the SAME dY image, B = X image)
+//       db_l += row sums of dY_l             VALU on the A fragments
+//   * dY never touches HBM: the rings (16 slots x 16 KiB per edge) live in the Infinity Cache and are overwritten in place.
+// Hand-off protocol (placement independent, cdna guide G16 / R1): payload stores sc1, every storing wave's stores are known
+// complete through the counted vmcnt of a LATER step's barrier, then ONE lane stores the edge's `head` counter (agent scope);
+// the consumer's control wave polls `head` (sc1 loads, two steps ahead of use) and loads the payload with sc1 LDS-DMA; it
+// returns ring slots through the edge's `tail` counter the same way.  Every spin is bounded by a wall-clock watchdog
+// (s_memrealtime): on expiry the stage raises *error, tells its workgroup through LDS and leaves -- the launch always drains.
+// Residency: grid = 7 x pipelines <= CU count, one workgroup per CU (LDS), roles taken from an arrival counter, so every pipeline
+// that processes samples is complete as soon as its last workgroup is scheduled.
+#include "eonerf_common.h"
+#include "eonerf_kernels.h"
+
+namespace {
+
+constexpr int NT = 512;
+constexpr int TS = PIPE_TS;                       // samples per step
+constexpr int IMG_B = 16 * 1024;                  // one step of a 256-feature tensor (bf16)
+constexpr int MSK_B = 1024;                       // one step of one mask slot in global memory: [32 samples][2 halves][4 dwords]
+constexpr int MSK_LDS_B = 8 * 256;                // in LDS: per wave the 64 dwords its lanes need (one per (sample, half))
+constexpr int SLOT_B = 2 * IMG_B + MSK_LDS_B;     // dY image | X image | mask dwords
+constexpr int NSLOT = 4, DEPTH = NSLOT - 1;
+constexpr int N_DMA = 5;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X + 1 mask
+constexpr int STAGE_B = 8 * TR_WAVE_B;            // slab staging (stages that also save their output rows), one buffer per wave
+constexpr int CTRL_B = 64;
+constexpr int SMEM_B = NSLOT * SLOT_B + STAGE_B + CTRL_B;
+constexpr int AUX_SC1 = 16, AUX_NT = 2;
+constexpr unsigned long long WATCHDOG_TICKS = 30000000ull;     // 0.3 s of the 100 MHz s_memrealtime clock
+
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+EO_DEV int wg_swz16(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }      // eonerf_wgrad.hip's ring swizzle
+
+// ops a wave issues per step, in program order: [CTRL: 2 flag stores, 2 flag polls] .. NST payload/slab stores .. N_DMA pieces
+template <bool CTRL, int NST> struct Cnt {
+    static constexpr int C = (CTRL ? 4 : 0) + NST + N_DMA;
+    // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s
+    static constexpr int TOP = N_DMA + C;
+};
+
+struct Stage {
+    int pipe, st, layer, n_k;
+    bool has_in;
+};
+
+// MODE 0: the output goes to the next stage's ring; 1: ring + gradient slab (layer 6: dY_5); 2: slab only (layer 1: dY_0)
+template <bool CTRL, int MODE>
+EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int tid) {
+    constexpr bool HAS_OUT = MODE != 2, SLAB = MODE != 0;
+    constexpr int NST = MODE == 1 ? 4 : 2;
+    typedef PBf16 P;
+    typedef P::U U;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
+    int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B + STAGE_B);      // [0] abort, [4..7] polled head, [8..11] polled tail
+    const int n_k = S.n_k;
+
+    // ---- stationary operands ----
+    U wt[16];
+    {
+        const uint8_t* src = a.wt + ((size_t)(S.st * 8 + wave) * 16) * 1024 + lane * 16;
+#pragma unroll
+        for (int kg = 0; kg < 16; ++kg) wt[kg] = *reinterpret_cast<const U*>(src + kg * 1024);
+        // an explicit wait the compiler's wait-count pass SEES: without it the pass treats these loads as possibly outstanding
+        // inside the loop and puts its own (stricter) vmcnt in front of the first MFMAs of every step
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+    }
+    f32x16 dw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dw[j] = zero_acc();
+    float db = 0.f;
+
+    // ---- sources ----
+    const size_t n_tiles = (size_t)a.p_pad / TS;                       // sample tiles of the slabs
+    const int x_row = ACT_ROW_X1 + 256 * (S.layer - 1);                // input of layer `layer` = output of layer - 1
+    const uint8_t* x_base = reinterpret_cast<const uint8_t*>(a.act) + (size_t)x_row * n_tiles * SEG_B;     // block start (rows x_row.., tile 0)
+    const uint8_t* m_base = reinterpret_cast<const uint8_t*>(a.masks) + (size_t)(S.layer - 1) * a.p_pad * 32;
+    uint8_t* const ring_in = a.rings + (size_t)(S.pipe * (PIPE_STAGES - 1) + (S.st - 1)) * PIPE_RING * IMG_B;
+    uint8_t* const ring_out = a.rings + (size_t)(S.pipe * (PIPE_STAGES - 1) + S.st) * PIPE_RING * IMG_B;
+    gu32* const f_in = (gu32*)(a.flags + (size_t)(S.pipe * (PIPE_STAGES - 1) + (S.st - 1)) * 64);          // [0] head, [32] tail
+    gu32* const f_out = (gu32*)(a.flags + (size_t)(S.pipe * (PIPE_STAGES - 1) + S.st) * 64);
+    // dummy flag traffic of the end stages (fixed op counts) goes to a line of the workgroup's own: 36 control waves storing to and
+    // polling ONE shared line every step serialise at the memory side and stall the whole CU's vector-memory issue
+    gu32* const my_scratch = (gu32*)(a.scratch_word + (size_t)(S.pipe * PIPE_STAGES + S.st) * 32);
+
+    // per-lane DMA source offsets of the X image: wave w stages rows 32w..32w+31, 16 rows per piece, chunks XOR-swizzled
+    int x_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 32 * wave + 16 * j + (lane >> 2);
+        x_voff[j] = row * SEG_B + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
+    }
+    auto issue = [&](int k) {      // DMA of this pipeline's k-th step (clamped by the caller) into LDS slot k & 3
+        const int g = S.pipe + k * a.n_pipes;                          // global step = sample tile
+        uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
+        // dY image: 16 pieces of 1 KiB, wave w copies pieces 2w, 2w+1
+        const uint8_t* dsrc = S.has_in ? ring_in + (size_t)(k & (PIPE_RING - 1)) * IMG_B : a.dy_in + (size_t)g * IMG_B;
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dsrc), 0, IMG_B, 0x00020000);
+        if (S.has_in) {      // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(slot + (2 * wave + j) * 1024), 16,
+                                                         lane * 16, (2 * wave + j) * 1024, 0, AUX_SC1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(slot + (2 * wave + j) * 1024), 16,
+                                                         lane * 16, (2 * wave + j) * 1024, 0, AUX_NT);
+        }
+        // X image: rows of the activation slab, written by the forward kernel of an earlier launch (streaming: nt)
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(x_base) + (size_t)g * 256 * SEG_B, 0,
+                                                                             256 * SEG_B, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(slot + IMG_B + (32 * wave + 16 * j) * SEG_B), 16,
+                                                     x_voff[j], 0, 0, AUX_NT);
+        // mask: every wave gathers the 64 dwords its own lanes need (dword wave>>1 of each (sample, half) record) into its own
+        // 256 bytes: one piece per wave (uniform op counts), 1 KiB of HBM traffic per step for the whole workgroup
+        const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(m_base) + (size_t)g * MSK_B, 0, MSK_B, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m, (__attribute__((address_space(3))) void*)(slot + 2 * IMG_B + wave * 256), 4,
+                                                 (c * 2 + h) * 16 + (wave >> 1) * 4, 0, 0, 0);
+    };
+
+    // ---- per-lane LDS read offsets ----
+    // A fragments of the dW product: transposed reads of the dY image (see the file header): 16-lane group g4, lane i = 4qq + pp
+    const int g4 = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+    const int tr_off = (2 * wave + (g4 & 1)) * 1024 + ((pp & 1) * 32 + 8 * (g4 >> 1) + qq) * 16 + (pp >> 1) * 8;     // + 64 t + 256 ks
+    // B fragments of the dW product: row 32j + c of the X image, 16-byte chunk 2ks + h
+    const int xb_off0 = IMG_B + c * SEG_B + wg_swz16(c, h), xb_off1 = IMG_B + c * SEG_B + wg_swz16(c, 2 + h);        // + 2048 j
+    const int mk_off = 2 * IMG_B + wave * 256 + lane * 4;
+
+    // ---- slab staging (stages whose output rows the remaining GEMM jobs read: dY_5, dY_0) ----
+    uint8_t* const scratch = smem + NSLOT * SLOT_B + wave * TR_WAVE_B;
+    uint8_t* const st_w = scratch + c * TR_STRIDE + h * 8;
+    const uint8_t* const st_r = scratch + (8 * g4 + qq) * TR_STRIDE + pp * 8;
+    const int st_voff = i16 * SEG_B + g4 * 16;
+    const int out_row0 = GRD_ROW_Y0 + (S.layer - 1) * 256;            // block of dY_{layer-1}: 256 rows
+    uint8_t* const grd_blk = reinterpret_cast<uint8_t*>(a.grd) + (size_t)out_row0 * n_tiles * SEG_B;
+
+    // ---- control state (wave 0) ----
+    int known_head = S.has_in ? 0 : 0x7fffffff, known_tail = HAS_OUT ? 0 : 0x7fffffff;
+    unsigned ph = 0, pt = 0;          // poll results in flight (inline asm: the compiler must not see these as loads)
+    auto poll_sync = [&](gu32* word) -> int {      // slow path: one synchronous agent-scope read
+        return (int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto wait_for = [&](gu32* word, int need, int& known) {        // bounded spin (watchdog)
+        if (known >= need) return;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            known = poll_sync(word);
+            if (known >= need) return;
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > WATCHDOG_TICKS) {
+                if (lane == 0) { atomicOr(a.error, 1 << (S.st & 7)); ctl[0] = 1; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                return;
+            }
+        }
+    };
+
+    // diagnostics: cycle sums of this wave (total loop, slow-path spins, counted wait, barrier, dX phase, dW phase)
+    const bool stamp = a.stamps != nullptr;
+    unsigned long long t_slow = 0, t_top = 0, t_bar = 0, t_dx = 0, t_ep = 0, t_is = 0, t_tr = 0, t_dw = 0, n_slow = 0;
+    const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
+
+    // ---- prologue: first DEPTH steps in flight ----
+    if (CTRL && S.has_in) wait_for(f_in, n_k < DEPTH ? n_k : DEPTH, known_head);
+    if (CTRL) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ctl[0]) return;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(d < n_k ? d : n_k - 1);
+    // step 0 only: nothing but the other two prologue steps is younger than its pieces (the loop's counted wait assumes the
+    // steady state, where two whole steps of stores and pieces are)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * N_DMA) : "memory");
+
+    for (int k = 0; k < n_k; ++k) {
+        uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
+        // ---- top of the step ----
+        if (CTRL) {
+            // flag values polled two steps ago have landed behind the counted wait below; before it, make sure (slow path only
+            // when the pipeline is starved or backed up) that what this step needs exists
+            const int need_in = (k + DEPTH < n_k ? k + DEPTH : n_k - 1) + 1;       // tiles that must be published for this step's DMA
+            const int need_out = k + 1 - PIPE_RING;                                 // tiles the consumer must have released
+            const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const bool slow = (S.has_in && known_head < need_in) || (HAS_OUT && known_tail < need_out);
+            if (S.has_in && known_head < need_in) wait_for(f_in, need_in, known_head);
+            if (HAS_OUT && known_tail < need_out) wait_for(f_out + 32, need_out, known_tail);
+            if (stamp && slow) { t_slow += __builtin_amdgcn_s_memtime() - ts0; ++n_slow; }
+        }
+        const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cnt<CTRL, NST>::TOP) : "memory");
+        const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        if (CTRL) {      // the polls of step k-2 are older than anything the wait above left outstanding
+            asm volatile("" : "+v"(ph), "+v"(pt));
+            if (k >= 2) {
+                const int vh = __builtin_amdgcn_readfirstlane((int)ph), vt = __builtin_amdgcn_readfirstlane((int)pt);
+                if (S.has_in && vh > known_head) known_head = vh;
+                if (HAS_OUT && vt > known_tail) known_tail = vt;
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");
+        const unsigned long long tt2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        if (stamp) { t_top += tt1 - tt0; t_bar += tt2 - tt1; }
+        if (ctl[0]) return;            // a watchdog fired in this workgroup: every wave leaves behind the same barrier
+        if (CTRL) {
+            // behind the barrier: every wave's share of step k has landed (=> the ring slot of tile k can go back) and every
+            // wave's stores of step k-2 are complete (=> tiles 0..k-2 are published)
+            if (lane == 0) {
+                if (S.has_in) __hip_atomic_store(f_in + 32, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_store(my_scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (HAS_OUT) __hip_atomic_store(f_out, (unsigned)(k > 0 && S.st != a.fault_stage ? k - 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_store((my_scratch + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // polls for step k+2 (always two loads: fixed op count)
+            const gu32* a_h = S.has_in ? f_in : my_scratch;
+            const gu32* a_t = HAS_OUT ? f_out + 32 : my_scratch;
+            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1"
+                         : "=&v"(ph), "=&v"(pt) : "v"(a_h), "v"(a_t) : "memory");
+        }
+
+        // ---- dX = W^T dY: 16 MFMAs, B units of the dY image 4 reads ahead ----
+        f32x16 acc = zero_acc();
+        {
+            const uint8_t* bp = slot + lane * 16;
+            U fr[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) fr[d] = lds_unit<P>(bp + d * 1024);
+#pragma unroll
+            for (int kg = 0; kg < 16; ++kg) {
+                acc = P::mma(wt[kg], fr[kg % 3], acc);
+                if (kg + 3 < 16) fr[kg % 3] = lds_unit<P>(bp + (kg + 3) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const uint32_t mword = *reinterpret_cast<const uint32_t*>(slot + mk_off);
+        const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        if (stamp) t_dx += tt3 - tt2;
+
+        // ---- epilogue: ReLU' from the mask bits, pack to bf16, hand the two units on (and stage them for the slab) ----
+        uint32_t w8[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w8[s] = mask_slice(P(), acc, s, wave, mword).w;
+        if (HAS_OUT) {
+            const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ring_out + (size_t)(k & (PIPE_RING - 1)) * IMG_B, 0, IMG_B, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
+        }
+        if (SLAB) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(st_w + 16 * q) = u32x2{w8[2 * q], w8[2 * q + 1]};
+        }
+        const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        // ---- refill the ring: step k + DEPTH into the slot step k-1 used (free behind this step's barrier) ----
+        issue(k + DEPTH < n_k ? k + DEPTH : n_k - 1);
+        const unsigned long long tt5 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        if (stamp) { t_ep += tt4 - tt3; t_is += tt5 - tt4; }
+
+        // ---- dW += dY X^T (2 K steps of 16 samples x 8 column tiles) and db += row sums ----
+        // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
+        // LDS-DMA in flight and drains it).  Stages that save their output rows read the staged tile back in the same batch
+        // (same scheme as SlabWriter) and store it before the MFMAs start.
+        u32x2 ta[2][2];
+        {
+            const uint32_t ra = (uint32_t)(uintptr_t)(slot + tr_off);
+            if (SLAB) {
+                u32x2 sa0, sa1, sb0, sb1;
+                const uint32_t rs = (uint32_t)(uintptr_t)st_r;
+                asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                             "ds_read_b64_tr_b16 %1, %8 offset:288\n\t"
+                             "ds_read_b64_tr_b16 %2, %8 offset:32\n\t"
+                             "ds_read_b64_tr_b16 %3, %8 offset:320\n\t"
+                             "ds_read_b64_tr_b16 %4, %9\n\t"
+                             "ds_read_b64_tr_b16 %5, %9 offset:64\n\t"
+                             "ds_read_b64_tr_b16 %6, %9 offset:256\n\t"
+                             "ds_read_b64_tr_b16 %7, %9 offset:320\n\t"
+                             "s_waitcnt lgkmcnt(4)"
+                             : "=&v"(sa0), "=&v"(sb0), "=&v"(sa1), "=&v"(sb1), "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1])
+                             : "v"(rs), "v"(ra) : "memory");
+                const int g = S.pipe + k * a.n_pipes;
+                const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(grd_blk + ((size_t)g * 256 + 32 * wave) * SEG_B, 0, 32 * SEG_B, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa0[0], sa0[1], sb0[0], sb0[1]}, rs_g, st_voff, 0, AUX_NT);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa1[0], sa1[1], sb1[0], sb1[1]}, rs_g, st_voff, 16 * SEG_B, AUX_NT);
+                asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(0)" : "+v"(ta[0][0]), "+v"(ta[0][1]), "+v"(ta[1][0]), "+v"(ta[1][1])::"memory");
+            } else {
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                             "ds_read_b64_tr_b16 %1, %4 offset:64\n\t"
+                             "ds_read_b64_tr_b16 %2, %4 offset:256\n\t"
+                             "ds_read_b64_tr_b16 %3, %4 offset:320\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]) : "v"(ra) : "memory");
+            }
+        }
+        const unsigned long long tt6 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        if (stamp) t_tr += tt6 - tt5;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const U af = __builtin_bit_cast(U, u32x4{ta[ks][0][0], ta[ks][0][1], ta[ks][1][0], ta[ks][1][1]});
+            const uint8_t* xb = slot + (ks ? xb_off1 : xb_off0);
+            U bf[2];
+            bf[0] = lds_unit<P>(xb);
+            bf[1] = lds_unit<P>(xb + 2048);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dw[j] = P::mma(af, bf[j & 1], dw[j]);
+                if (j + 2 < 8) bf[j & 1] = lds_unit<P>(xb + (j + 2) * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // bias gradient: this lane's 8 samples of feature 32 wave + (lane & 31)
+            const u32x4 av = __builtin_bit_cast(u32x4, af);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) db += __uint_as_float(av[e] << 16) + __uint_as_float(av[e] & 0xffff0000u);
+        }
+        if (stamp) t_dw += __builtin_amdgcn_s_memtime() - tt6;
+    }
+    if (stamp && lane == 0) {
+        unsigned long long* o = a.stamps + ((size_t)(S.pipe * PIPE_STAGES + S.st) * 8 + wave) * 16;
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_slow; o[2] = t_top; o[3] = t_bar; o[4] = t_dx; o[5] = n_slow; o[6] = (unsigned long long)n_k;
+        o[7] = t_ep; o[8] = t_is; o[9] = t_tr; o[10] = t_dw;
+    }
+    // ---- drain: the last stores become visible, the last tiles are published ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (CTRL && lane == 0 && HAS_OUT && S.st != a.fault_stage) __hip_atomic_store(f_out, (unsigned)n_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- flush the stationary gradients (fp32 atomics: one partial per pipeline and element) ----
+    float* dwp = a.d_flat + a.dw_off[S.st];
+    const int ld = a.dw_ld[S.st];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) atomicAdd(dwp + (size_t)(32 * wave + acc_row(g, h)) * ld + 32 * j + c, dw[j][g]);
+    db += __shfl_xor(db, 32, 64);
+    if (h == 0) atomicAdd(a.d_flat + a.db_off[S.st] + 32 * wave + c, db);
+}
+
+__global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B + STAGE_B);
+    if (tid == 0) { ctl[0] = 0; ctl[1] = atomicAdd(a.role_counter, 1); }
+    __syncthreads();
+    const int role = __builtin_amdgcn_readfirstlane(ctl[1]);
+    Stage S;
+    S.pipe = role / PIPE_STAGES; S.st = role % PIPE_STAGES;
+    if (S.pipe >= a.n_pipes) return;
+    S.layer = 7 - S.st;
+    const int n_pts = *a.n_pts;
+    // whole 256-sample tiles, as the chain kernels process them (dead samples carry zero gradients): the GEMM jobs that follow read
+    // the saved dY_0 / dY_5 rows of every sample tile up to that bound
+    const int n_steps = (n_pts + 255) / 256 * (256 / TS);
+    S.n_k = S.pipe < n_steps ? (n_steps - S.pipe + a.n_pipes - 1) / a.n_pipes : 0;
+    S.has_in = S.st > 0;
+    if (S.n_k == 0) return;
+    const bool ctrl = (tid >> 6) == 0;
+    if (S.layer == 6) { if (ctrl) run_stage<true, 1>(a, S, smem, tid); else run_stage<false, 1>(a, S, smem, tid); }
+    else if (S.layer == 1) { if (ctrl) run_stage<true, 2>(a, S, smem, tid); else run_stage<false, 2>(a, S, smem, tid); }
+    else { if (ctrl) run_stage<true, 0>(a, S, smem, tid); else run_stage<false, 0>(a, S, smem, tid); }
+}
+
+}  // namespace
+
+size_t eo_bwd_pipe_lds_bytes() { return SMEM_B; }
+
+hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_bwd_pipe, dim3(a.n_pipes * PIPE_STAGES), dim3(NT), SMEM_B, st, a);
+    return hipGetLastError();
+}

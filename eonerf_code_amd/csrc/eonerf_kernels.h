@@ -78,6 +78,7 @@ struct MlpBwdArgs {
     float* g_emb;                  // FULL: [p_pad][4] grad wrt the per-sample transient embedding
     const float *px, *py, *pz;     // INPUT_GRAD: positions (encoder derivative)
     float* g_pos;                  // INPUT_GRAD: [3][p_pad]
+    uint8_t* dy7_units;            // PIPE: dY_7 in B-operand unit order [step of 32 samples][16 KiB]; the trunk is left to eonerf_bwd_pipe.hip
 };
 
 // One weight-gradient GEMM job:  dW[m][col_map[n]] += sum_p  dY^T[m][p] * X^T[n][p]
@@ -95,8 +96,35 @@ struct WgradJob {
     int item0, slices;    // work items [item0, item0 + slices) = equal slices of this job's K range
 };
 
+// ---- layer-pipelined trunk backward (eonerf_bwd_pipe.hip) ----
+constexpr int PIPE_STAGES = 7;        // trunk layers 7..1, one workgroup each
+constexpr int PIPE_TS = 32;           // samples per step = one sample tile of the bf16 slabs
+constexpr int PIPE_RING = 16;         // slots (steps) of an inter-stage ring
+constexpr int PIPE_UNIT_B = 16 * 1024;   // one step of a 256-feature tensor in B-operand unit order [k-group 16][lane 64][16 B]
+struct BwdPipeArgs {
+    const int* n_pts; int p_pad;
+    int n_pipes;
+    const uint8_t* wt;        // stage-stationary W_l^T: [stage 7][m-tile 8][k-group 16][lane 64][16 B] bf16 (eonerf_pack.cpp)
+    const uint8_t* dy_in;     // dY_7 of every step in unit order [step][16 KiB] (written by the heads part of the backward chain)
+    const void* act;          // activation slab (block-major feature-major tiles, eonerf_common.h)
+    const uint32_t* masks;
+    void* grd;                // gradient slab: the stages of layers 6 and 1 also save dY_5 / dY_0 for the remaining GEMM jobs
+    uint8_t* rings;           // [pipeline][edge 6][PIPE_RING][16 KiB]
+    uint32_t* flags;          // [pipeline][edge 6][64]: head counter at [0], tail counter at [32] (own 128-B lines); zeroed per launch
+    uint32_t* scratch_word;   // [workgroup][32]: sink / source of the end stages' fixed-count dummy flag traffic (a line per workgroup)
+    int* role_counter;        // zeroed per launch
+    int* error;               // watchdog bits, zeroed per launch
+    float* d_flat;
+    size_t dw_off[PIPE_STAGES], db_off[PIPE_STAGES];
+    int dw_ld[PIPE_STAGES];
+    unsigned long long* stamps;   // diagnostics (EONERF_PIPE_STAMPS): [workgroup role][2 waves][8] cycle sums, or nullptr
+    int fault_stage;          // test hook (EONERF_PIPE_FAULT): this stage never publishes its tiles -> every watchdog downstream must fire; -1 = off
+};
+hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st);
+size_t eo_bwd_pipe_lds_bytes();
+
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);
-hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st);
+hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, bool pipe = false);
 constexpr int WGRAD_MAX_JOBS = 40;
 struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int items; };   // by value in the kernel-argument segment; jobs sorted heaviest first
 hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st);

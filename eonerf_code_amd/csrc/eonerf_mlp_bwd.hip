@@ -25,7 +25,9 @@ template <class P> EO_DEV typename P::U small_unit(const float (&v)[4], int h) {
 }
 
 // TRANS = false: the transient head is outside the autograd graph (see k_mlp_fwd MODE 2): its layers are skipped.
-template <class P, bool FULL, bool IG, bool TRANS>
+// PIPE (camera pass, bf16): the kernel stops at dY_7 and hands it, in B-operand unit order, to the layer-pipelined trunk
+// backward (eonerf_bwd_pipe.hip), which computes dY_6..dY_0 AND the trunk weight gradients without parking dY in HBM.
+template <class P, bool FULL, bool IG, bool TRANS, bool PIPE = false>
 __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     constexpr int SLOT = FwdSlot<P>::BYTES;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -135,6 +137,17 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
+            if constexpr (PIPE) {
+                run_layer<P, SLOT, HKG + 1, 8, false>(ws, mid, lane, h,
+                    [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
+                    [&](int mt, const f32x16& v, int s) { put_slice(P(), D, mt, s, mask_slice(P(), v, s, mt, mb[mt >> 1])); });
+                // this wave's 32 samples = step (tile * 8 + wave) of the pipeline: 16 units of 1 KiB
+                uint8_t* dst = a.dy7_units + ((size_t)tile * (P::TILE / 32) + wave) * 16 * 1024 + lane * 16;
+#pragma unroll
+                for (int kg = 0; kg < HKG; ++kg) *reinterpret_cast<U*>(dst + kg * 1024) = D[kg];
+                sw.drain();
+                continue;
+            }
             run_layer<P, SLOT, HKG + 1, 8, false, NST>(ws, mid, lane, h,
                 [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v, s); });
@@ -210,17 +223,17 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
 #endif
 }
 
-template <class P, bool FULL, bool IG, bool TRANS>
+template <class P, bool FULL, bool IG, bool TRANS, bool PIPE = false>
 hipError_t launch(const MlpBwdArgs& a, int grid, hipStream_t st) {
     constexpr int SMEM = 2 * FwdSlot<P>::BYTES + SlabWriter<P, GrdMap>::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG, TRANS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG, TRANS, PIPE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_mlp_bwd<P, FULL, IG, TRANS>), dim3(grid), dim3(P::NT), SMEM, st, a);
+    hipLaunchKernelGGL((k_mlp_bwd<P, FULL, IG, TRANS, PIPE>), dim3(grid), dim3(P::NT), SMEM, st, a);
     return hipGetLastError();
 }
 
@@ -234,9 +247,13 @@ template <class P> hipError_t dispatch(const MlpBwdArgs& a, bool full, bool inpu
 
 // the variants the callers need: camera pass (all heads, with / without the transient head in the graph, no input grad),
 // shadow pass / query_density (density only, with input grad) and the differentiable EONerfMLP.forward (all heads + input grad)
-hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st) {
+hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, bool pipe) {
     if (!full && !input_grad) return hipErrorInvalidValue;
     if (full && input_grad && !transient) return hipErrorInvalidValue;
+    if (pipe) {      // heads only; the trunk runs in eonerf_bwd_pipe.hip (bf16 camera pass)
+        if (!bf16 || !full || input_grad || !a.dy7_units) return hipErrorInvalidValue;
+        return transient ? launch<PBf16, true, false, true, true>(a, grid, st) : launch<PBf16, true, false, false, true>(a, grid, st);
+    }
     return bf16 ? dispatch<PBf16>(a, full, input_grad, transient, grid, st) : dispatch<PF32>(a, full, input_grad, transient, grid, st);
 }
 

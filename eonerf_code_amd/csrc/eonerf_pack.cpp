@@ -129,7 +129,7 @@ PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full) {
 }
 
 // Backward chain: dX^T = W^T dY^T.  "row" = INPUT feature of the forward layer, "slot" = OUTPUT feature.
-PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient) {
+PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient, bool heads_only) {
     PackedStream s;
     const int KF = bf16 ? 16 : 8;
     const int HKG = 256 / KF, QKG = 128 / KF;
@@ -163,6 +163,7 @@ PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool 
         append_layer(s, bf16, PackLayer{1, 8, false,
             [&](int row, int slot) { return slot == 0 ? pl.at(pl.sig_w, 0, row) : -1; }, nullptr});
     }
+    if (heads_only) return s;
     for (int l = 7; l >= 1; --l) {
         if (l == 5) {
             append_layer(s, bf16, PackLayer{HKG, input_grad ? 10 : 8, false,
@@ -178,5 +179,26 @@ PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool 
     if (input_grad)
         append_layer(s, bf16, PackLayer{HKG, 2, false,
             [&, bf16](int row, int slot) { const int c = enc_col_of_slot(bf16, row); return c >= 0 ? pl.at(pl.trunk_w[0], slot, c) : -1; }, nullptr});
+    return s;
+}
+
+// Layer-pipelined trunk backward: per stage (layer 7..1) the whole W_l^T as [m-tile 8][k-group 16] A units of 1 KiB
+// (lane (r,h): input feature 32 mt + r, output features PBf16::feat(kg, h, e)) -- loaded ONCE into the stage's registers.
+PackedStream build_pipe_stream(const ParamLayout& pl) {
+    PackedStream s;
+    for (int st = 0; st < PIPE_STAGES; ++st) {
+        const int l = 7 - st;
+        for (int mt = 0; mt < 8; ++mt)
+            for (int kg = 0; kg < 16; ++kg)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 31, h = lane >> 5;
+                    for (int e = 0; e < 8; ++e) {
+                        const int o = PBf16::feat(kg, h, e);
+                        s.e16.push_back(PackEntry{(uint32_t)(s.bytes + (size_t)(mt * 16 + kg) * 1024 + lane * 16 + e * 2), pl.at(pl.trunk_w[l], o, 32 * mt + r)});
+                    }
+                }
+        s.bytes += 8 * 16 * 1024;
+    }
+    s.chunks.push_back(ChunkDesc{0, (uint32_t)s.bytes});
     return s;
 }

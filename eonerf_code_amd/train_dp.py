@@ -58,6 +58,7 @@ def main():
             r, im, px = table.batch(epoch, i, args.batch_size)
             loss = trainer.step(r, im, px, epoch)
             if step % 1000 == 0 and rank == 0:                              # the only host sync, every 1000 steps (:173-178)
+                trainer.check_device_status()                                # raises if a device-side hand-off timed out
                 el = time.time() - tic
                 print(f"epoch={epoch} | elapsed_time={el:.2f}s | step={step} | loss={float(loss):.5f} | "
                       f"rays/s={(step + 1) * args.batch_size * world / max(el, 1e-9):.0f}", flush=True)

@@ -52,6 +52,7 @@ class FusedTrainer:
         self.max_rays = max_rays
         self._ws = {}
         self._comm_stream = None
+        self._last = None
         self.out = torch.empty(max_rays, 21, dtype=torch.float32, device=dev)
         self.d_out = torch.zeros(max_rays, 21, dtype=torch.float32, device=dev)
         self.n_samples = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -115,6 +116,7 @@ class FusedTrainer:
         self.d_flat.zero_()
         _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
                                                  _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
+        self._last = (n, flags, ws)
         gscale = self._reduce(st)
         self.step_count += 1
         if flags & _lib.F_SHADOWS:
@@ -138,6 +140,13 @@ class FusedTrainer:
             gscale = reduce_gradients(self.d_flat)
         cur.wait_stream(self._comm_stream)
         return gscale
+
+    def check_device_status(self):
+        """Synchronises and raises if a device-side hand-off of the pipelined backward timed out in the last step (see
+        eonerf_render_status); meant for the places where the host reads the loss anyway."""
+        if self._last is not None:
+            n, flags, ws = self._last
+            _lib.check(self.L.eonerf_render_status(self.ctx, n, flags, _ptr(ws), ws.numel(), _stream()))
 
     def set_noise_seed(self, seed):
         """Key of the in-kernel jitter stream; data-parallel ranks must use different seeds (train_dp.py: seed + rank)."""

@@ -24,7 +24,7 @@ extern "C" {
 
 #define EONERF_VERSION 200
 
-enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4 };
+enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4, EONERF_E_DEVICE = -5 };
 
 /* arithmetic of the MLP GEMMs */
 enum { EONERF_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (parity mode, 1e-4 vs the reference) */
@@ -157,6 +157,13 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat_params, const float
 int eonerf_render_backward(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
                            int n_rays, int flags, const float* d_out, float* d_flat_params,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* Device-side health of the last eonerf_render_backward on this workspace.  In bf16 mode the trunk backward is a persistent,
+ * layer-pipelined kernel whose workgroups hand tiles to each other inside the launch; every wait in it is bounded by a
+ * wall-clock watchdog, so a launch always drains, and a wait that expired is recorded in the workspace.  This call
+ * SYNCHRONISES `stream` and returns EONERF_E_DEVICE if that happened (0 otherwise): call it where the host synchronises anyway
+ * (the reference's loop reads the loss every 1000 steps, train_eonerf.py:173-178). */
+int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Training loss on the packed outputs and its gradient (train_eonerf.py:139-143): kind 0 = F.mse_loss(rgb, pixels),
  * kind 1 = metrics.uncertainty_aware_loss(pixels, rgb, beta) (metrics.py:17-22; the constant 3/2 of its beta term is
