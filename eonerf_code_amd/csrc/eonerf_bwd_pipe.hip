@@ -29,11 +29,9 @@ namespace {
 constexpr int NT = 512;
 constexpr int TS = PIPE_TS;                       // samples per step
 constexpr int IMG_B = 16 * 1024;                  // one step of a 256-feature tensor (bf16)
-constexpr int MSK_B = 1024;                       // one step of one mask slot in global memory: [32 samples][2 halves][4 dwords]
-constexpr int MSK_LDS_B = 8 * 256;                // in LDS: per wave the 64 dwords its lanes need (one per (sample, half))
-constexpr int SLOT_B = 2 * IMG_B + MSK_LDS_B;     // dY image | X image | mask dwords
+constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 constexpr int NSLOT = 4, DEPTH = NSLOT - 1;
-constexpr int N_DMA = 5;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X + 1 mask
+constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
 constexpr int STAGE_B = 8 * TR_WAVE_B;            // slab staging (stages that also save their output rows), one buffer per wave
 constexpr int CTRL_B = 64;
 constexpr int SMEM_B = NSLOT * SLOT_B + STAGE_B + CTRL_B;
@@ -45,10 +43,12 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 EO_DEV int wg_swz16(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }      // eonerf_wgrad.hip's ring swizzle
 
 // ops a wave issues per step, in program order: [CTRL: 2 flag stores, 2 flag polls] .. NST payload/slab stores .. N_DMA pieces
-template <bool CTRL, int NST> struct Cnt {
+// second order (waves 4..7): N_DMA pieces .. NST stores
+template <bool CTRL, int NST, bool ORDB> struct Cnt {
     static constexpr int C = (CTRL ? 4 : 0) + NST + N_DMA;
-    // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s
-    static constexpr int TOP = N_DMA + C;
+    // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s.
+    // First order: the pieces of step s-2 and all of step s-1 are younger than those stores; second order: only step s-1
+    static constexpr int TOP = ORDB ? C : N_DMA + C;
 };
 
 struct Stage {
@@ -56,11 +56,13 @@ struct Stage {
     bool has_in;
 };
 
-// MODE 0: the output goes to the next stage's ring; 1: ring + gradient slab (layer 6: dY_5); 2: slab only (layer 1: dY_0)
-template <bool CTRL, int MODE>
+// MODE 0: the output goes to the next stage's ring; 1: ring + gradient slab through an LDS transposition (layer 6: dY_5 feeds the
+// skip-column GEMM job); 2: slab only (layer 1: dY_0 feeds the layer-0 GEMM job); 3 (measured slower than 1, kept for reference):
+// ring, and the stage saves its INPUT rows straight from the transposed A fragments -- 32-byte half rows per lane, no staging
+template <bool CTRL, int MODE, bool ORDB = false>
 EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int tid) {
-    constexpr bool HAS_OUT = MODE != 2, SLAB = MODE != 0;
-    constexpr int NST = MODE == 1 ? 4 : 2;
+    constexpr bool HAS_OUT = MODE != 2, SLAB = MODE == 1 || MODE == 2, SAVE_IN = MODE == 3;
+    constexpr int NST = (MODE == 1 || MODE == 3) ? 4 : 2;
     typedef PBf16 P;
     typedef P::U U;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
@@ -86,7 +88,6 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     const size_t n_tiles = (size_t)a.p_pad / TS;                       // sample tiles of the slabs
     const int x_row = ACT_ROW_X1 + 256 * (S.layer - 1);                // input of layer `layer` = output of layer - 1
     const uint8_t* x_base = reinterpret_cast<const uint8_t*>(a.act) + (size_t)x_row * n_tiles * SEG_B;     // block start (rows x_row.., tile 0)
-    const uint8_t* m_base = reinterpret_cast<const uint8_t*>(a.masks) + (size_t)(S.layer - 1) * a.p_pad * 32;
     uint8_t* const ring_in = a.rings + (size_t)(S.pipe * (PIPE_STAGES - 1) + (S.st - 1)) * PIPE_RING * IMG_B;
     uint8_t* const ring_out = a.rings + (size_t)(S.pipe * (PIPE_STAGES - 1) + S.st) * PIPE_RING * IMG_B;
     gu32* const f_in = (gu32*)(a.flags + (size_t)(S.pipe * (PIPE_STAGES - 1) + (S.st - 1)) * 64);          // [0] head, [32] tail
@@ -126,11 +127,6 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(slot + IMG_B + (32 * wave + 16 * j) * SEG_B), 16,
                                                      x_voff[j], 0, 0, AUX_NT);
-        // mask: every wave gathers the 64 dwords its own lanes need (dword wave>>1 of each (sample, half) record) into its own
-        // 256 bytes: one piece per wave (uniform op counts), 1 KiB of HBM traffic per step for the whole workgroup
-        const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(m_base) + (size_t)g * MSK_B, 0, MSK_B, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m, (__attribute__((address_space(3))) void*)(slot + 2 * IMG_B + wave * 256), 4,
-                                                 (c * 2 + h) * 16 + (wave >> 1) * 4, 0, 0, 0);
     };
 
     // ---- per-lane LDS read offsets ----
@@ -139,7 +135,15 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     const int tr_off = (2 * wave + (g4 & 1)) * 1024 + ((pp & 1) * 32 + 8 * (g4 >> 1) + qq) * 16 + (pp >> 1) * 8;     // + 64 t + 256 ks
     // B fragments of the dW product: row 32j + c of the X image, 16-byte chunk 2ks + h
     const int xb_off0 = IMG_B + c * SEG_B + wg_swz16(c, h), xb_off1 = IMG_B + c * SEG_B + wg_swz16(c, 2 + h);        // + 2048 j
-    const int mk_off = 2 * IMG_B + wave * 256 + lane * 4;
+    // ReLU' of layer - 1 = (X_layer > 0) on the bf16 values the forward saved (the same predicate its mask bits record): this
+    // lane's 16 (feature, sample) pairs of the dX accumulator come out of the X image through 4 transposed reads -- 16-lane group
+    // g4 = samples 16 (g4 & 1) .., half h = g4 >> 1; read q covers rows 32 wave + 8q + 4h .. +3 (one swizzle class per read)
+    int xm_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * wave + 8 * q + 4 * (g4 >> 1);
+        xm_off[q] = IMG_B + (f0 + qq) * SEG_B + wg_swz16(f0, 2 * (g4 & 1) + (pp >> 1)) + (pp & 1) * 8;
+    }
 
     // ---- slab staging (stages whose output rows the remaining GEMM jobs read: dY_5, dY_0) ----
     uint8_t* const scratch = smem + NSLOT * SLOT_B + wave * TR_WAVE_B;
@@ -148,6 +152,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     const int st_voff = i16 * SEG_B + g4 * 16;
     const int out_row0 = GRD_ROW_Y0 + (S.layer - 1) * 256;            // block of dY_{layer-1}: 256 rows
     uint8_t* const grd_blk = reinterpret_cast<uint8_t*>(a.grd) + (size_t)out_row0 * n_tiles * SEG_B;
+    uint8_t* const in_blk = reinterpret_cast<uint8_t*>(a.grd) + (size_t)(GRD_ROW_Y0 + S.layer * 256) * n_tiles * SEG_B;      // block of dY_layer
 
     // ---- control state (wave 0) ----
     int known_head = S.has_in ? 0 : 0x7fffffff, known_tail = HAS_OUT ? 0 : 0x7fffffff;
@@ -172,7 +177,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 
     // diagnostics: cycle sums of this wave (total loop, slow-path spins, counted wait, barrier, dX phase, dW phase)
     const bool stamp = a.stamps != nullptr;
-    unsigned long long t_slow = 0, t_top = 0, t_bar = 0, t_dx = 0, t_ep = 0, t_is = 0, t_tr = 0, t_dw = 0, n_slow = 0;
+    unsigned long long t_slow = 0, t_top = 0, t_bar = 0, t_dx = 0, t_is = 0, t_dw = 0, n_slow = 0;
     const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---- prologue: first DEPTH steps in flight ----
@@ -201,7 +206,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             if (stamp && slow) { t_slow += __builtin_amdgcn_s_memtime() - ts0; ++n_slow; }
         }
         const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cnt<CTRL, NST>::TOP) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cnt<CTRL, NST, ORDB>::TOP) : "memory");
         const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         if (CTRL) {      // the polls of step k-2 are older than anything the wait above left outstanding
             asm volatile("" : "+v"(ph), "+v"(pt));
@@ -231,51 +236,64 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                          : "=&v"(ph), "=&v"(pt) : "v"(a_h), "v"(a_t) : "memory");
         }
 
-        // ---- dX = W^T dY: 16 MFMAs, B units of the dY image 4 reads ahead ----
-        f32x16 acc = zero_acc();
-        {
-            const uint8_t* bp = slot + lane * 16;
-            U fr[3];
+        // ---- the three phases of a step; waves 4..7 (ORDB) run them in another order than waves 0..3, so that on every SIMD one
+        //      wave's matrix phase meets its partner's LDS / VALU / vector-memory phase (after the barrier both would otherwise
+        //      multiply at the same time and then both idle the matrix pipe at the same time) ----
+        auto phase_dx = [&]() {        // dX = W^T dY (16 MFMAs, B units of the dY image 3 reads ahead), ReLU', pack, hand on
+            f32x16 acc = zero_acc();
+            {
+                const uint8_t* bp = slot + lane * 16;
+                U fr[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) fr[d] = lds_unit<P>(bp + d * 1024);
+                for (int d = 0; d < 3; ++d) fr[d] = lds_unit<P>(bp + d * 1024);
 #pragma unroll
-            for (int kg = 0; kg < 16; ++kg) {
-                acc = P::mma(wt[kg], fr[kg % 3], acc);
-                if (kg + 3 < 16) fr[kg % 3] = lds_unit<P>(bp + (kg + 3) * 1024);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int kg = 0; kg < 16; ++kg) {
+                    acc = P::mma(wt[kg], fr[kg % 3], acc);
+                    if (kg + 3 < 16) fr[kg % 3] = lds_unit<P>(bp + (kg + 3) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
-        const uint32_t mword = *reinterpret_cast<const uint32_t*>(slot + mk_off);
-        const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        if (stamp) t_dx += tt3 - tt2;
-
-        // ---- epilogue: ReLU' from the mask bits, pack to bf16, hand the two units on (and stage them for the slab) ----
-        uint32_t w8[8];
+            u32x2 xm[4];
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                         "ds_read_b64_tr_b16 %1, %5\n\t"
+                         "ds_read_b64_tr_b16 %2, %6\n\t"
+                         "ds_read_b64_tr_b16 %3, %7\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(xm[0]), "=&v"(xm[1]), "=&v"(xm[2]), "=&v"(xm[3])
+                         : "v"((uint32_t)(uintptr_t)(slot + xm_off[0])), "v"((uint32_t)(uintptr_t)(slot + xm_off[1])),
+                           "v"((uint32_t)(uintptr_t)(slot + xm_off[2])), "v"((uint32_t)(uintptr_t)(slot + xm_off[3])) : "memory");
+            uint32_t w8[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) w8[s] = mask_slice(P(), acc, s, wave, mword).w;
-        if (HAS_OUT) {
-            const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ring_out + (size_t)(k & (PIPE_RING - 1)) * IMG_B, 0, IMG_B, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
-        }
-        if (SLAB) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(st_w + 16 * q) = u32x2{w8[2 * q], w8[2 * q + 1]};
-        }
-        const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        // ---- refill the ring: step k + DEPTH into the slot step k-1 used (free behind this step's barrier) ----
-        issue(k + DEPTH < n_k ? k + DEPTH : n_k - 1);
-        const unsigned long long tt5 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        if (stamp) { t_ep += tt4 - tt3; t_is += tt5 - tt4; }
-
-        // ---- dW += dY X^T (2 K steps of 16 samples x 8 column tiles) and db += row sums ----
-        // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
-        // LDS-DMA in flight and drains it).  Stages that save their output rows read the staged tile back in the same batch
-        // (same scheme as SlabWriter) and store it before the MFMAs start.
-        u32x2 ta[2][2];
-        {
-            const uint32_t ra = (uint32_t)(uintptr_t)(slot + tr_off);
+            for (int s = 0; s < 8; ++s) {      // word s = accumulator registers 2s, 2s+1 <-> activation word s of the transposed reads
+                uint32_t flags, r;
+                const uint32_t xw = xm[s >> 1][s & 1];
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(flags) : "v"(xw), "v"(0x00010001u));        // post-ReLU bf16 >= 0: 1 where > 0
+                asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(cvt_pk_bf16(acc[2 * s], acc[2 * s + 1])), "v"(flags));
+                w8[s] = r;
+            }
+            if (HAS_OUT) {
+                const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ring_out + (size_t)(k & (PIPE_RING - 1)) * IMG_B, 0, IMG_B, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
+            }
             if (SLAB) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(st_w + 16 * q) = u32x2{w8[2 * q], w8[2 * q + 1]};
+            }
+        };
+        auto slab_store = [&](const u32x2& sa0, const u32x2& sb0, const u32x2& sa1, const u32x2& sb1) {
+            const int g = S.pipe + k * a.n_pipes;
+            const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(grd_blk + ((size_t)g * 256 + 32 * wave) * SEG_B, 0, 32 * SEG_B, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa0[0], sa0[1], sb0[0], sb0[1]}, rs_g, st_voff, 0, AUX_NT);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa1[0], sa1[1], sb1[0], sb1[1]}, rs_g, st_voff, 16 * SEG_B, AUX_NT);
+        };
+        auto phase_dw = [&]() {        // dW += dY X^T (2 K steps of 16 samples x 8 column tiles), db += row sums
+            // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
+            // LDS-DMA in flight and drains it).  In the first order a stage that saves its output rows reads the staged tile back in
+            // the same batch (same scheme as SlabWriter) and stores it before the MFMAs start.
+            u32x2 ta[2][2];
+            const uint32_t ra = (uint32_t)(uintptr_t)(slot + tr_off);
+            if (SLAB && !ORDB) {
                 u32x2 sa0, sa1, sb0, sb1;
                 const uint32_t rs = (uint32_t)(uintptr_t)st_r;
                 asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
@@ -289,10 +307,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                              "s_waitcnt lgkmcnt(4)"
                              : "=&v"(sa0), "=&v"(sb0), "=&v"(sa1), "=&v"(sb1), "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1])
                              : "v"(rs), "v"(ra) : "memory");
-                const int g = S.pipe + k * a.n_pipes;
-                const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(grd_blk + ((size_t)g * 256 + 32 * wave) * SEG_B, 0, 32 * SEG_B, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa0[0], sa0[1], sb0[0], sb0[1]}, rs_g, st_voff, 0, AUX_NT);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa1[0], sa1[1], sb1[0], sb1[1]}, rs_g, st_voff, 16 * SEG_B, AUX_NT);
+                slab_store(sa0, sb0, sa1, sb1);
                 asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(0)" : "+v"(ta[0][0]), "+v"(ta[0][1]), "+v"(ta[1][0]), "+v"(ta[1][1])::"memory");
             } else {
                 asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
@@ -302,33 +317,58 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                              "s_waitcnt lgkmcnt(0)"
                              : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]) : "v"(ra) : "memory");
             }
-        }
-        const unsigned long long tt6 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        if (stamp) t_tr += tt6 - tt5;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const U af = __builtin_bit_cast(U, u32x4{ta[ks][0][0], ta[ks][0][1], ta[ks][1][0], ta[ks][1][1]});
-            const uint8_t* xb = slot + (ks ? xb_off1 : xb_off0);
-            U bf[2];
-            bf[0] = lds_unit<P>(xb);
-            bf[1] = lds_unit<P>(xb + 2048);
+            for (int ks = 0; ks < 2; ++ks) {
+                const U af = __builtin_bit_cast(U, u32x4{ta[ks][0][0], ta[ks][0][1], ta[ks][1][0], ta[ks][1][1]});
+                const uint8_t* xb = slot + (ks ? xb_off1 : xb_off0);
+                U bf[2];
+                bf[0] = lds_unit<P>(xb);
+                bf[1] = lds_unit<P>(xb + 2048);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                dw[j] = P::mma(af, bf[j & 1], dw[j]);
-                if (j + 2 < 8) bf[j & 1] = lds_unit<P>(xb + (j + 2) * 2048);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 8; ++j) {
+                    dw[j] = P::mma(af, bf[j & 1], dw[j]);
+                    if (j + 2 < 8) bf[j & 1] = lds_unit<P>(xb + (j + 2) * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // bias gradient: this lane's 8 samples of feature 32 wave + (lane & 31)
+                const u32x4 av = __builtin_bit_cast(u32x4, af);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) db += __uint_as_float(av[e] << 16) + __uint_as_float(av[e] & 0xffff0000u);
             }
-            // bias gradient: this lane's 8 samples of feature 32 wave + (lane & 31)
-            const u32x4 av = __builtin_bit_cast(u32x4, af);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) db += __uint_as_float(av[e] << 16) + __uint_as_float(av[e] & 0xffff0000u);
+        };
+        const int k_next = k + DEPTH < n_k ? k + DEPTH : n_k - 1;       // refill: into the slot step k-1 used (free behind this step's barrier)
+        if (!ORDB) {
+            phase_dx();
+            const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            issue(k_next);
+            const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            phase_dw();
+            if (stamp) { t_dx += tt3 - tt2; t_is += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
+        } else {
+            issue(k_next);
+            const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            phase_dw();
+            const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            phase_dx();
+            if (SLAB) {      // the staged tile goes out at the end of the step
+                u32x2 sa0, sa1, sb0, sb1;
+                const uint32_t rs = (uint32_t)(uintptr_t)st_r;
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                             "ds_read_b64_tr_b16 %1, %4 offset:288\n\t"
+                             "ds_read_b64_tr_b16 %2, %4 offset:32\n\t"
+                             "ds_read_b64_tr_b16 %3, %4 offset:320\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(sa0), "=&v"(sb0), "=&v"(sa1), "=&v"(sb1) : "v"(rs) : "memory");
+                slab_store(sa0, sb0, sa1, sb1);
+                asm volatile("s_nop 1" ::: "memory");
+            }
+            if (stamp) { t_is += tt3 - tt2; t_dw += tt4 - tt3; t_dx += __builtin_amdgcn_s_memtime() - tt4; }
         }
-        if (stamp) t_dw += __builtin_amdgcn_s_memtime() - tt6;
     }
     if (stamp && lane == 0) {
         unsigned long long* o = a.stamps + ((size_t)(S.pipe * PIPE_STAGES + S.st) * 8 + wave) * 16;
         o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_slow; o[2] = t_top; o[3] = t_bar; o[4] = t_dx; o[5] = n_slow; o[6] = (unsigned long long)n_k;
-        o[7] = t_ep; o[8] = t_is; o[9] = t_tr; o[10] = t_dw;
+        o[7] = 0; o[8] = t_is; o[9] = 0; o[10] = t_dw;
     }
     // ---- drain: the last stores become visible, the last tiles are published ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -364,10 +404,15 @@ __global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
     S.n_k = S.pipe < n_steps ? (n_steps - S.pipe + a.n_pipes - 1) / a.n_pipes : 0;
     S.has_in = S.st > 0;
     if (S.n_k == 0) return;
-    const bool ctrl = (tid >> 6) == 0;
-    if (S.layer == 6) { if (ctrl) run_stage<true, 1>(a, S, smem, tid); else run_stage<false, 1>(a, S, smem, tid); }
-    else if (S.layer == 1) { if (ctrl) run_stage<true, 2>(a, S, smem, tid); else run_stage<false, 2>(a, S, smem, tid); }
-    else { if (ctrl) run_stage<true, 0>(a, S, smem, tid); else run_stage<false, 0>(a, S, smem, tid); }
+    const int wv = tid >> 6;
+    // wave 0: control wave (first order); waves 1..3: first order; waves 4..7 (the second wave of every SIMD): second order
+    if (S.layer == 6) {
+        if (wv == 0) run_stage<true, 1>(a, S, smem, tid); else if (wv < 4) run_stage<false, 1>(a, S, smem, tid); else run_stage<false, 1, true>(a, S, smem, tid);
+    } else if (S.layer == 1) {
+        if (wv == 0) run_stage<true, 2>(a, S, smem, tid); else if (wv < 4) run_stage<false, 2>(a, S, smem, tid); else run_stage<false, 2, true>(a, S, smem, tid);
+    } else {
+        if (wv == 0) run_stage<true, 0>(a, S, smem, tid); else if (wv < 4) run_stage<false, 0>(a, S, smem, tid); else run_stage<false, 0, true>(a, S, smem, tid);
+    }
 }
 
 }  // namespace
