@@ -194,15 +194,30 @@ def main():
             prof = trainer.profile_read()
             trainer.profile_enable(0)
             dead = MAC_TRANSIENT if wl == "rgb" else 0          # transient head outside the graph when epoch_idx < 2 (s = 1, MSE on rgb)
-            flop_of = {"fwd_chain_camera": 2.0 * MAC_FWD * n_cam, "bwd_chain_camera": 2.0 * (MAC_BWD - dead) * n_cam,
-                       "wgrad_gemm": 2.0 * ((MAC_WGRAD - dead) * n_cam + MAC_DENS * n_sun),
+            # bf16: the camera pass's trunk backward is layer-pipelined (csrc/eonerf_bwd_pipe.hip): ONE kernel does the dX chain AND the
+            # 256 x 256 weight gradients of layers 1..7; the chain kernel keeps the heads, the GEMM the jobs the pipeline leaves
+            piped = prof["bwd_pipe_camera"][1] > 0
+            mac_trunk_dx, mac_trunk_dw = 7 * 65536, 7 * 65536
+            flop_of = {"fwd_chain_camera": 2.0 * MAC_FWD * n_cam,
+                       "bwd_chain_camera": 2.0 * (MAC_BWD - dead - (mac_trunk_dx if piped else 0)) * n_cam,
+                       "bwd_pipe_camera": 2.0 * (mac_trunk_dx + mac_trunk_dw) * n_cam,
+                       "wgrad_gemm": 2.0 * ((MAC_WGRAD - dead - (mac_trunk_dw if piped else 0)) * n_cam + MAC_DENS * n_sun),
                        "fwd_chain_sun": 2.0 * MAC_DENS * n_sun, "bwd_chain_sun": 2.0 * MAC_DENS * n_sun}
             # HBM bytes the design moves per launch (bf16 slabs): saved rows x element size (+ 32 B ReLU masks per slot)
             rows_w = 2496 if wl == "rgb" else 3012              # forward chain writes: enc 64 + X1..X8 2048 + bottleneck 256 + A1 128 (+ T 512 + emb 4)
             rows_g = 2180 if wl == "rgb" else 2694              # backward chain writes: dY0..7 2048 + dA1 128 + d sigma 1 + d albedo 3 (+ dT 512 + 2)
             rows_rd = (2564 + 2816) if wl == "rgb" else (3334 + 3972)     # weight-gradient GEMM reads both operands of every job once
             masks = 9 if wl == "rgb" else 13
+            rows_pipe = 0
+            if piped:
+                # heads chain: writes dY_7 in unit order (256 rows) + the head gradient rows (A1 128, A2 32, sigma 32 [+ T 512 + 32]);
+                # pipeline: reads dY_7 (256) and X1..X7 (7 x 256), writes dY_5 and dY_0 (2 x 256) for the GEMM jobs it leaves;
+                # GEMM: layer 0 and the skip columns of layer 5 (2 x (256 + 64)), sigma (32 + 256), bottleneck factors and head jobs
+                rows_g = 256 + 192 + (0 if wl == "rgb" else 544)
+                rows_pipe = 256 + 7 * 256 + 2 * 256
+                rows_rd = 2 * 320 + 288 + 384 + 384 + 160 + (0 if wl == "rgb" else 384 + 384 + 132 + 3 * 256 + 2 * 160)
             bytes_of = {"fwd_chain_camera": (rows_w * elt + masks * 32) * n_cam, "bwd_chain_camera": (rows_g * elt + masks * 32) * n_cam,
+                        "bwd_pipe_camera": (rows_pipe * elt if piped else 0) * n_cam,
                         "wgrad_gemm": rows_rd * elt * n_cam + (2305 + 2176) * elt * n_sun,
                         "fwd_chain_sun": (2112 * elt + 8 * 32) * n_sun, "bwd_chain_sun": ((2048 + 1) * elt + 8 * 32) * n_sun}
             for name, flop in flop_of.items():

@@ -67,7 +67,7 @@ struct eonerf_ctx {
     int n_cu;
     int wgrad_items;      // target number of weight-gradient work items per launch (EONERF_WGRAD_ITEMS, default 48 per job)
     ParamLayout pl;
-    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig, pipe_wt, bwd_full_heads, bwd_rgb_heads;
+    DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig, pipe_wt, bwd_full_heads, bwd_rgb_heads, bwd_dens_heads, ig_tail_wt;
     bool pipe = false;               // layer-pipelined trunk backward (bf16 camera pass; EONERF_PIPE=0 switches back to chain + GEMM)
     int n_pipes = 0;
     int pipe_fault_stage = -1;       // test hook (EONERF_PIPE_FAULT)
@@ -79,8 +79,8 @@ struct eonerf_ctx {
     bool dens_dirty = false;         // density-only streams are re-packed lazily (only the shadow pass reads them)
     // measurement hooks
     int prof_cap = 0;
-    std::vector<hipEvent_t> prof_ev[5][2];
-    int prof_n[5] = {0, 0, 0, 0, 0};
+    std::vector<hipEvent_t> prof_ev[6][2];
+    int prof_n[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -137,7 +137,7 @@ int pack(std::initializer_list<const DevStream*> streams, const float* flat, hip
 
 struct ProfScope {      // brackets one kernel launch with events when profiling is on
     eonerf_ctx* c; int k; hipStream_t st; bool on;
-    ProfScope(eonerf_ctx* ctx, int kernel, hipStream_t s) : c(ctx), k(kernel), st(s), on(ctx->prof_cap > 0 && ctx->prof_n[kernel] < ctx->prof_cap) {
+    ProfScope(eonerf_ctx* ctx, int kernel, hipStream_t s) : c(ctx), k(kernel), st(s), on(kernel >= 0 && ctx->prof_cap > 0 && ctx->prof_n[kernel] < ctx->prof_cap) {
         if (on) (void)hipEventRecord(c->prof_ev[k][0][c->prof_n[k]], st);
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(c->prof_ev[k][1][c->prof_n[k]], st); c->prof_n[k]++; } }
@@ -204,7 +204,8 @@ AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
 
 int ensure_density_streams(eonerf_ctx* ctx, const float* flat, hipStream_t st) {
     if (!ctx->dens_dirty) return 0;
-    const int rc = pack({&ctx->fwd_dens, &ctx->bwd_dens}, flat, st);
+    const int rc = ctx->pipe ? pack({&ctx->fwd_dens, &ctx->bwd_dens, &ctx->bwd_dens_heads, &ctx->ig_tail_wt}, flat, st)
+                             : pack({&ctx->fwd_dens, &ctx->bwd_dens}, flat, st);
     if (!rc) ctx->dens_dirty = false;
     return rc;
 }
@@ -227,11 +228,38 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
 }
 
 
+// trunk layers 7..1 of one pass: dX chain + weight gradients, layer-pipelined (eonerf_bwd_pipe.hip).  Reads dY_7 from w.pipe.dy_in
+// (written by the heads part of the backward chain), accumulates dW / db of the trunk into d_flat, saves dY_5 / dY_0 in b.grd.
+// The error word ([1] of the sync block) is only cleared by the FIRST launch of a backward call (clear_error) so that a watchdog
+// raised in either pass survives until eonerf_render_status reads it.
+int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, bool clear_error = true) {
+    const ParamLayout& pl = ctx->pl;
+    if (clear_error) HIP_TRY(hipMemsetAsync(w.pipe.sync, 0, w.pipe.sync_bytes, st));
+    else {
+        HIP_TRY(hipMemsetAsync(w.pipe.sync, 0, sizeof(uint32_t), st));                                            // role counter
+        HIP_TRY(hipMemsetAsync(w.pipe.sync + 64, 0, w.pipe.sync_bytes - 64 * sizeof(uint32_t), st));               // scratch lines + edge flags
+    }
+    ProfScope ps(ctx, prof_id, st);
+    BwdPipeArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.n_pts = b.n_pts; pa.p_pad = p_cap; pa.n_pipes = ctx->n_pipes;
+    pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in; pa.act = b.act; pa.masks = b.masks; pa.grd = b.grd;
+    pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(w.pipe.sync); pa.error = reinterpret_cast<int*>(w.pipe.sync) + 1;
+    pa.scratch_word = w.pipe.sync + 64; pa.flags = w.pipe.sync + 64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32;
+    pa.d_flat = d_flat; pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
+    for (int s = 0; s < PIPE_STAGES; ++s) {
+        const int l = 7 - s;
+        pa.dw_off[s] = pl.t[pl.trunk_w[l]].offset; pa.db_off[s] = pl.t[pl.trunk_b[l]].offset; pa.dw_ld[s] = l == 5 ? 319 : 256;
+    }
+    return (int)eo_launch_bwd_pipe(pa, st);
+}
+
 // Weight gradients of up to two MLP passes in ONE split-K launch (eonerf_wgrad.hip) + the bottleneck factor product:
 //   full: a pass through the whole field (camera pass / EONerfMLP.forward), with or without the transient head in the graph;
 //   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
-                         const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false) {
+                         const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false,
+                         bool dens_trunk_done = false) {
     const ParamLayout& pl = ctx->pl;
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
@@ -280,13 +308,16 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
             add(c, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
         }
     }
-    if (dens) trunk_jobs(*dens, false);
+    if (dens) trunk_jobs(*dens, dens_trunk_done);
     // every work item = one slice of one job's sample range.  Equal slices: a K step costs about the same for every job shape
     // (the loop is latency-bound); default 48 slices per job (measured: flat from ~2.4 to 6.5 items per CU, clearly slower below 2)
     tab.items = 0;
     for (int k = 0; k < tab.n; ++k) {
         WgradJob& j = tab.j[k];
-        const int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : 48;
+        // ... but never fewer than ~4 items per CU in the launch: with the trunk's 256 x 256 products gone to the pipelined backward only
+        // 6-9 jobs are left, and 48 slices each would leave most CUs with one item and a few with two
+        const int fill = (4 * ctx->n_cu + tab.n - 1) / tab.n;
+        const int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : (fill > 48 ? (fill > 256 ? 256 : fill) : 48);
         j.slices = sl < 1 ? 1 : sl;
         j.item0 = tab.items;
         tab.items += j.slices;
@@ -347,6 +378,8 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
         if (!rc && ctx->pipe) rc = upload(ctx->pipe_wt, build_pipe_stream(ctx->pl));
         if (!rc && ctx->pipe) rc = upload(ctx->bwd_full_heads, build_bwd_stream(ctx->pl, true, true, false, true, true));
         if (!rc && ctx->pipe) rc = upload(ctx->bwd_rgb_heads, build_bwd_stream(ctx->pl, true, true, false, false, true));
+        if (!rc && ctx->pipe) rc = upload(ctx->bwd_dens_heads, build_bwd_stream(ctx->pl, true, false, true, false, true));
+        if (!rc && ctx->pipe) rc = upload(ctx->ig_tail_wt, build_ig_tail_stream(ctx->pl));
         { const char* f = getenv("EONERF_PIPE_FAULT"); ctx->pipe_fault_stage = f ? atoi(f) : -1; }
         { const char* f = getenv("EONERF_PIPE_STAMPS");
           if (!rc && ctx->pipe && f && atoi(f)) rc = (int)hipMalloc(&ctx->pipe_stamps, (size_t)ctx->n_pipes * PIPE_STAGES * 128 * sizeof(unsigned long long)); }
@@ -364,7 +397,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
 
 int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches) {
     if (!ctx || max_launches < 0) return EONERF_E_ARG;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
         for (int s = 0; s < 2; ++s) {
             for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
             ctx->prof_ev[k][s].clear();
@@ -377,7 +410,7 @@ int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches) {
 }
 
 int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launches) {
-    if (!ctx || kernel < 0 || kernel >= 5 || !total_ms || !launches) return EONERF_E_ARG;
+    if (!ctx || kernel < 0 || kernel >= 6 || !total_ms || !launches) return EONERF_E_ARG;
     float sum = 0.f;
     for (int i = 0; i < ctx->prof_n[kernel]; ++i) {
         HIP_TRY(hipEventSynchronize(ctx->prof_ev[kernel][1][i]));
@@ -391,8 +424,8 @@ int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launc
 
 int eonerf_destroy(eonerf_ctx* ctx) {
     if (!ctx) return EONERF_E_ARG;
-    for (int k = 0; k < 5; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
-    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads);
+    for (int k = 0; k < 6; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
+    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads); release(ctx->bwd_dens_heads); release(ctx->ig_tail_wt);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     if (ctx->pipe_stamps) (void)hipFree(ctx->pipe_stamps);
     delete ctx;
@@ -762,7 +795,22 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         ms.stream = ctx->bwd_dens.data; ms.chunks = ctx->bwd_dens.chunks; ms.n_chunks = ctx->bwd_dens.n_chunks;
         ms.sigma = w.sun.sigma; ms.g_sigma = w.sun.g_sigma; ms.masks = w.sun.masks; ms.grd = w.sun.grd;
         ms.px = w.sun.px; ms.py = w.sun.py; ms.pz = w.sun.pz; ms.g_pos = w.sun.g_pos;
-        { ProfScope ps(ctx, 4, st); HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, false, grid, st)); }
+        const bool pipe_sun = ctx->pipe && w.pipe.dy_in;
+        if (pipe_sun) {      // heads (sigma row) -> pipelined trunk -> input-gradient tail
+            ms.stream = ctx->bwd_dens_heads.data; ms.chunks = ctx->bwd_dens_heads.chunks; ms.n_chunks = ctx->bwd_dens_heads.n_chunks;
+            ms.dy7_units = w.pipe.dy_in;
+            ProfScope ps(ctx, 4, st);
+            HIP_TRY(eo_launch_mlp_bwd(ms, true, false, true, false, grid, st, true));
+            const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, -1, st);
+            if (rcp) return rcp;
+            IgTailArgs ta;
+            ta.n_pts = w.sun.n_pts; ta.p_pad = p_cap; ta.grd = w.sun.grd; ta.wt = ctx->ig_tail_wt.data;
+            ta.px = w.sun.px; ta.py = w.sun.py; ta.pz = w.sun.pz; ta.g_pos = w.sun.g_pos;
+            HIP_TRY(eo_launch_ig_tail(ta, ctx->n_cu, st));
+        } else {
+            ProfScope ps(ctx, 4, st);
+            HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, false, grid, st));
+        }
         HIP_TRY(eo_launch_sun_depth_grad(cs, st));
     }
 
@@ -782,28 +830,11 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
     mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
     mc.dy7_units = pipe ? w.pipe.dy_in : nullptr;
-    {
-        ProfScope ps(ctx, 1, st);
-        HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st, pipe));
-        if (pipe) {      // trunk layers 7..1: dX chain + weight gradients, layer-pipelined (eonerf_bwd_pipe.hip)
-            HIP_TRY(hipMemsetAsync(w.pipe.sync, 0, w.pipe.sync_bytes, st));
-            BwdPipeArgs pa;
-            memset(&pa, 0, sizeof(pa));
-            pa.n_pts = w.cam.n_pts; pa.p_pad = p_cap; pa.n_pipes = ctx->n_pipes;
-            pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in; pa.act = w.cam.act; pa.masks = w.cam.masks; pa.grd = w.cam.grd;
-            pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(w.pipe.sync); pa.error = reinterpret_cast<int*>(w.pipe.sync) + 1;
-            pa.scratch_word = w.pipe.sync + 64; pa.flags = w.pipe.sync + 64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32;
-            pa.d_flat = d_flat; pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
-            for (int s = 0; s < PIPE_STAGES; ++s) {
-                const int l = 7 - s;
-                pa.dw_off[s] = pl.t[pl.trunk_w[l]].offset; pa.db_off[s] = pl.t[pl.trunk_b[l]].offset; pa.dw_ld[s] = l == 5 ? 319 : 256;
-            }
-            HIP_TRY(eo_launch_bwd_pipe(pa, st));
-        }
-    }
+    { ProfScope ps(ctx, 1, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st, pipe)); }
+    if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, 5, st, !shadows); if (rcp) return rcp; }
 
     {
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.flags + 2, st, pipe);
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.flags + 2, st, pipe, pipe && shadows);
         if (rcw) return rcw;
     }
 

@@ -121,6 +121,15 @@ struct BwdPipeArgs {
     int fault_stage;          // test hook (EONERF_PIPE_FAULT): this stage never publishes its tiles -> every watchdog downstream must fire; -1 = off
 };
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st);
+// input-gradient tail of a pipelined density pass (eonerf_ig_tail.hip)
+struct IgTailArgs {
+    const int* n_pts; int p_pad;
+    const void* grd;          // gradient slab holding the saved dY_0 / dY_5 rows
+    const uint8_t* wt;        // [source 2: W_0^T, W_5 skip^T][m-tile 2][k-group 16][lane 64][16 B] bf16 (eonerf_pack.cpp)
+    const float *px, *py, *pz;
+    float* g_pos;             // [3][p_pad]
+};
+hipError_t eo_launch_ig_tail(const IgTailArgs& a, int n_wg, hipStream_t st);
 size_t eo_bwd_pipe_lds_bytes();
 
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);

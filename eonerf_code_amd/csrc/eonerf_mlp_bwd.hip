@@ -154,6 +154,15 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         } else {
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
+            if constexpr (PIPE) {      // density pass: dY_7 = W_sigma^T d sigma_pre .* relu'; trunk and input gradient follow elsewhere
+                run_layer<P, SLOT, 1, 8, false>(ws, mid, lane, h, [&](int) { return u_sg; },
+                    [&](int mt, const f32x16& v, int s) { put_slice(P(), D, mt, s, mask_slice(P(), v, s, mt, mb[mt >> 1])); });
+                uint8_t* dst = a.dy7_units + ((size_t)tile * (P::TILE / 32) + wave) * 16 * 1024 + lane * 16;
+#pragma unroll
+                for (int kg = 0; kg < HKG; ++kg) *reinterpret_cast<U*>(dst + kg * 1024) = D[kg];
+                sw.drain();
+                continue;
+            }
             run_layer<P, SLOT, 1, 8, false, NST>(ws, mid, lane, h, [&](int) { return u_sg; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v, s); });
         }
@@ -250,8 +259,9 @@ template <class P> hipError_t dispatch(const MlpBwdArgs& a, bool full, bool inpu
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, bool pipe) {
     if (!full && !input_grad) return hipErrorInvalidValue;
     if (full && input_grad && !transient) return hipErrorInvalidValue;
-    if (pipe) {      // heads only; the trunk runs in eonerf_bwd_pipe.hip (bf16 camera pass)
-        if (!bf16 || !full || input_grad || !a.dy7_units) return hipErrorInvalidValue;
+    if (pipe) {      // heads only; the trunk runs in eonerf_bwd_pipe.hip (bf16), the input gradient in eonerf_ig_tail.hip
+        if (!bf16 || !a.dy7_units || (full && input_grad)) return hipErrorInvalidValue;
+        if (!full) return launch<PBf16, false, true, false, true>(a, grid, st);
         return transient ? launch<PBf16, true, false, true, true>(a, grid, st) : launch<PBf16, true, false, false, true>(a, grid, st);
     }
     return bf16 ? dispatch<PBf16>(a, full, input_grad, transient, grid, st) : dispatch<PF32>(a, full, input_grad, transient, grid, st);

@@ -202,3 +202,23 @@ PackedStream build_pipe_stream(const ParamLayout& pl) {
     s.chunks.push_back(ChunkDesc{0, (uint32_t)s.bytes});
     return s;
 }
+
+// Input-gradient tail: rows = encoding slots (64 = 2 m-tiles), K = the 256 outputs of layer 0 (source 0) / layer 5 (source 1)
+PackedStream build_ig_tail_stream(const ParamLayout& pl) {
+    PackedStream s;
+    for (int src = 0; src < 2; ++src)
+        for (int mt = 0; mt < 2; ++mt)
+            for (int kg = 0; kg < 16; ++kg)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 31, h = lane >> 5;
+                    for (int e = 0; e < 8; ++e) {
+                        const int o = PBf16::feat(kg, h, e);
+                        const int col = enc_col_of_slot(true, 32 * mt + r);
+                        const int idx = col < 0 ? -1 : (src == 0 ? pl.at(pl.trunk_w[0], o, col) : pl.at(pl.trunk_w[5], o, 256 + col));
+                        s.e16.push_back(PackEntry{(uint32_t)(((size_t)((src * 2 + mt) * 16 + kg)) * 1024 + lane * 16 + e * 2), idx});
+                    }
+                }
+    s.bytes = 2 * 2 * 16 * 1024;
+    s.chunks.push_back(ChunkDesc{0, (uint32_t)s.bytes});
+    return s;
+}

@@ -46,4 +46,5 @@ PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full);
 // to eonerf_bwd_pipe.hip; the stream is consumed cyclically, so it must hold exactly the layers one tile walks)
 PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient = true, bool heads_only = false);
 PackedStream build_pipe_stream(const ParamLayout& pl);      // stage-stationary W_l^T of trunk layers 7..1 (eonerf_bwd_pipe.hip), bf16
+PackedStream build_ig_tail_stream(const ParamLayout& pl);   // W_0^T and the skip columns of W_5^T as A units (eonerf_ig_tail.hip), bf16
 int enc_col_of_slot(bool bf16, int slot);      // reference encoding column (mlp.py:190-208) of an encoding slot, -1 = pad

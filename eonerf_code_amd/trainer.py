@@ -157,7 +157,7 @@ class FusedTrainer:
         _lib.check(self.L.eonerf_profile_enable(self.ctx, max_launches))
 
     def profile_read(self):
-        names = ("fwd_chain_camera", "bwd_chain_camera", "wgrad_gemm", "fwd_chain_sun", "bwd_chain_sun")
+        names = ("fwd_chain_camera", "bwd_chain_camera", "wgrad_gemm", "fwd_chain_sun", "bwd_chain_sun", "bwd_pipe_camera")
         res = {}
         for k, name in enumerate(names):
             ms, cnt = C.c_float(), C.c_int()

@@ -186,7 +186,8 @@ int eonerf_param_is_late(const eonerf_ctx* ctx, int index);
 
 /* Measurement hooks (no reference counterpart): with profiling enabled every launch of the three MFMA kernels is
  * bracketed by hipEvents on the caller's stream.  kernel: 0 = forward chain (camera), 1 = backward chain (camera),
- * 2 = weight-gradient GEMM, 3 = forward chain (shadow pass), 4 = backward chain (shadow pass).
+ * 2 = weight-gradient GEMM, 3 = forward chain (shadow pass), 4 = backward chain (shadow pass), 5 = layer-pipelined trunk
+ * backward of the camera pass (bf16: kernel 1 is then the heads part only, kernel 2 the GEMM jobs the pipeline leaves).
  * eonerf_profile_read synchronises on the recorded events and returns the summed duration and launch count. */
 int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches_per_kernel);
 int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launches);
