@@ -50,8 +50,16 @@ struct PipeWs {            // layer-pipelined trunk backward (eonerf_bwd_pipe.hi
     size_t sync_bytes;
 };
 
+struct DetWs {             // EONERF_DETERMINISTIC: partial sums instead of atomics
+    float* pipe_part;      // [n_pipes * 7][256 * 256 + 256]
+    float* wgrad_part;     // [WGRAD_MAX_JOBS * 48 items][256 * 256 + 256]
+    float* rad_rays;       // [R][6]
+    float* emb_rays;       // [R][4]
+};
+
 struct RenderWs {
     PipeWs pipe;
+    DetWs det;
     int *cnt_first, *cnt_retry, *flags;
     float* ray_rec; float* g_ray; float* amb_save;
     float* m_bott;        // [2][128][256] fp32: dA1^T X8 and dT1^T X8 (factors of the bottleneck weight gradient)
@@ -71,6 +79,7 @@ struct eonerf_ctx {
     bool pipe = false;               // layer-pipelined trunk backward (bf16 camera pass; EONERF_PIPE=0 switches back to chain + GEMM)
     int n_pipes = 0;
     int pipe_fault_stage = -1;       // test hook (EONERF_PIPE_FAULT)
+    bool deterministic = false;      // EONERF_DETERMINISTIC=1: every atomic flush of the backward is replaced by partials + a fixed-order sum
     unsigned long long* pipe_stamps = nullptr;   // diagnostics (EONERF_PIPE_STAMPS=1): cycle sums per stage, read by eonerf_debug_pipe_stamps
     uint64_t noise_seed = 0x5eed5eedULL; uint32_t noise_call = 0;   // in-kernel Philox jitter (eonerf_set_noise_seed)
     bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
@@ -191,6 +200,13 @@ RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) 
         w.pipe.sync_bytes = (64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32 + (size_t)ctx->n_pipes * (PIPE_STAGES - 1) * 64) * sizeof(uint32_t);
         w.pipe.sync = c.take<uint32_t>(w.pipe.sync_bytes / sizeof(uint32_t));
     }
+    memset(&w.det, 0, sizeof(w.det));
+    if (train && ctx->deterministic) {
+        if (ctx->pipe) w.det.pipe_part = c.take<float>((size_t)ctx->n_pipes * PIPE_STAGES * WGRAD_PART_F);
+        w.det.wgrad_part = c.take<float>((size_t)WGRAD_MAX_JOBS * 48 * WGRAD_PART_F);
+        w.det.rad_rays = c.take<float>((size_t)n_rays * 6);
+        w.det.emb_rays = c.take<float>((size_t)n_rays * 4);
+    }
     carve_pass(c, w.cam, n_rays, p_cap, !od, train, false, ab);
     if (shadows && !od) carve_pass(c, w.sun, n_rays, p_cap, false, train, true, ab); else memset(&w.sun, 0, sizeof(w.sun));
     w.bytes = c.off + 256;
@@ -251,7 +267,10 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
         const int l = 7 - s;
         pa.dw_off[s] = pl.t[pl.trunk_w[l]].offset; pa.db_off[s] = pl.t[pl.trunk_b[l]].offset; pa.dw_ld[s] = l == 5 ? 319 : 256;
     }
-    return (int)eo_launch_bwd_pipe(pa, st);
+    pa.partials = w.det.pipe_part;
+    HIP_TRY(eo_launch_bwd_pipe(pa, st));
+    if (pa.partials) HIP_TRY(eo_launch_pipe_reduce(pa, st));
+    return 0;
 }
 
 // Weight gradients of up to two MLP passes in ONE split-K launch (eonerf_wgrad.hip) + the bottleneck factor product:
@@ -259,7 +278,7 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
 //   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
                          const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false,
-                         bool dens_trunk_done = false) {
+                         bool dens_trunk_done = false, float* det_partials = nullptr) {
     const ParamLayout& pl = ctx->pl;
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
@@ -317,12 +336,13 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         // ... but never fewer than ~4 items per CU in the launch: with the trunk's 256 x 256 products gone to the pipelined backward only
         // 6-9 jobs are left, and 48 slices each would leave most CUs with one item and a few with two
         const int fill = (4 * ctx->n_cu + tab.n - 1) / tab.n;
-        const int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : (fill > 48 ? (fill > 256 ? 256 : fill) : 48);
+        int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : (fill > 48 ? (fill > 256 ? 256 : fill) : 48);
+        if (det_partials && sl > 48) sl = 48;       // the partial buffer holds WGRAD_MAX_JOBS x 48 items
         j.slices = sl < 1 ? 1 : sl;
         j.item0 = tab.items;
         tab.items += j.slices;
     }
-    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st)); }
+    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials)); }
     if (full) {   // bottleneck layer: dW = W_A1^T M_a (+ W_T1^T M_t) from the two factors the GEMM above accumulated
         BottWgradArgs bw;
         bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_a1 = dptr(pl.a1_b);
@@ -359,6 +379,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     if (!ctx) return EONERF_E_ARG;
     ctx->cfg = *cfg;
     ctx->bf16 = cfg->precision == EONERF_BF16;
+    { const char* e = getenv("EONERF_DETERMINISTIC"); ctx->deterministic = e && atoi(e) != 0; }
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete ctx; return (int)hipErrorNoDevice; }
@@ -777,7 +798,9 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     sb.d_radiometric = ctx->cfg.radiometric ? dptr(pl.rad) : nullptr;
     sb.g_ray = w.g_ray; sb.n_rays = n_rays; sb.use_shadow = shadows ? 1 : 0; sb.eval = (flags & EONERF_F_EVAL) ? 1 : 0;
     sb.lds_images = ctx->cfg.n_images <= 2048 ? ctx->cfg.n_images : 0;
+    sb.d_rad_rays = sb.d_radiometric ? w.det.rad_rays : nullptr;
     HIP_TRY(eo_launch_shade_bwd(sb, st));
+    if (sb.d_rad_rays) HIP_TRY(eo_launch_table_reduce(sb.d_rad_rays, img_idx, n_rays, 6, 9, ctx->cfg.n_images, sb.eval, sb.d_radiometric, st));
 
     CompositeBwdArgs cb;
     memset(&cb, 0, sizeof(cb));
@@ -834,7 +857,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, 5, st, !shadows); if (rcp) return rcp; }
 
     {
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.flags + 2, st, pipe, pipe && shadows);
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.flags + 2, st, pipe, pipe && shadows, w.det.wgrad_part);
         if (rcw) return rcw;
     }
 
@@ -842,13 +865,15 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     if (transient) {
         EmbGradArgs eg;
         eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays; eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0;
+        eg.d_emb_rays = w.det.emb_rays;
         HIP_TRY(eo_launch_emb_grad(eg, st));
+        if (eg.d_emb_rays) HIP_TRY(eo_launch_table_reduce(eg.d_emb_rays, img_idx, n_rays, 4, 4, ctx->cfg.n_images, 0, eg.d_emb, st));
     }
     if (!shadows) return EONERF_OK;      // s == 1: rgb = albedo, the ambient head is outside the graph (sat_rendering.py:269-276,294)
     AmbientBwdArgs ag;
     ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
     ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
-    HIP_TRY(eo_launch_ambient_bwd(ag, st));
+    HIP_TRY(eo_launch_ambient_bwd(ag, st, ctx->deterministic));
     return EONERF_OK;
 }
 

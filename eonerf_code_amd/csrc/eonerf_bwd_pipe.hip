@@ -375,14 +375,24 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     __syncthreads();
     if (CTRL && lane == 0 && HAS_OUT && S.st != a.fault_stage) __hip_atomic_store(f_out, (unsigned)n_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    // ---- flush the stationary gradients (fp32 atomics: one partial per pipeline and element) ----
+    // ---- flush the stationary gradients: fp32 atomics (one partial per pipeline and element), or, in deterministic mode, plain
+    //      stores of this workgroup's partial, summed in pipeline order by k_pipe_reduce ----
+    db += __shfl_xor(db, 32, 64);
+    if (a.partials) {
+        float* pt = a.partials + (size_t)(S.pipe * PIPE_STAGES + S.st) * (256 * 256 + 256);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) pt[(32 * wave + acc_row(g, h)) * 256 + 32 * j + c] = dw[j][g];
+        if (h == 0) pt[256 * 256 + 32 * wave + c] = db;
+        return;
+    }
     float* dwp = a.d_flat + a.dw_off[S.st];
     const int ld = a.dw_ld[S.st];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int g = 0; g < 16; ++g) atomicAdd(dwp + (size_t)(32 * wave + acc_row(g, h)) * ld + 32 * j + c, dw[j][g]);
-    db += __shfl_xor(db, 32, 64);
     if (h == 0) atomicAdd(a.d_flat + a.db_off[S.st] + 32 * wave + c, db);
 }
 
@@ -415,7 +425,27 @@ __global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
     }
 }
 
+// deterministic mode: block = (stage, row), thread = column; pipelines that had no step wrote nothing and are skipped
+__global__ __launch_bounds__(256) void k_pipe_reduce(BwdPipeArgs a) {
+    const int st = blockIdx.y, row = blockIdx.x, col = threadIdx.x;
+    const int n_steps = (*a.n_pts + 255) / 256 * (256 / TS);
+    const int live = n_steps < a.n_pipes ? n_steps : a.n_pipes;
+    float acc = 0.f, accb = 0.f;
+    for (int p = 0; p < live; ++p) {
+        const float* pt = a.partials + (size_t)(p * PIPE_STAGES + st) * (256 * 256 + 256);
+        acc += pt[row * 256 + col];
+        if (col == 0) accb += pt[256 * 256 + row];
+    }
+    a.d_flat[a.dw_off[st] + (size_t)row * a.dw_ld[st] + col] += acc;
+    if (col == 0) a.d_flat[a.db_off[st] + row] += accb;
+}
+
 }  // namespace
+
+hipError_t eo_launch_pipe_reduce(const BwdPipeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_pipe_reduce, dim3(256, PIPE_STAGES), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
 
 size_t eo_bwd_pipe_lds_bytes() { return SMEM_B; }
 

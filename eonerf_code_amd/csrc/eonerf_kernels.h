@@ -118,6 +118,7 @@ struct BwdPipeArgs {
     size_t dw_off[PIPE_STAGES], db_off[PIPE_STAGES];
     int dw_ld[PIPE_STAGES];
     unsigned long long* stamps;   // diagnostics (EONERF_PIPE_STAMPS): [workgroup role][2 waves][8] cycle sums, or nullptr
+    float* partials;          // deterministic mode: [pipeline][stage][256 x 256 dW | 256 db] instead of the atomic flush (reduced in pipeline order)
     int fault_stage;          // test hook (EONERF_PIPE_FAULT): this stage never publishes its tiles -> every watchdog downstream must fire; -1 = off
 };
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st);
@@ -136,4 +137,8 @@ hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, bool pipe = false);
 constexpr int WGRAD_MAX_JOBS = 40;
 struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int items; };   // by value in the kernel-argument segment; jobs sorted heaviest first
-hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st);
+// partials != nullptr (deterministic mode): every work item stores its tile to partials[item] ([256][256] dW | [256] db) instead of
+// adding it atomically, and a second kernel sums the items of a job in slice order
+constexpr int WGRAD_PART_F = 256 * 256 + 256;
+hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st, float* partials = nullptr);
+hipError_t eo_launch_pipe_reduce(const BwdPipeArgs& a, hipStream_t st);

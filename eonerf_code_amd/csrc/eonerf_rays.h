@@ -59,6 +59,7 @@ struct ShadeBwdArgs {
     float* g_ray;               // [R][RAY_REC] gradient of the per-ray record
     int n_rays, use_shadow, eval;
     int lds_images;             // > 0: accumulate d_radiometric[n_img][6] in LDS first (n_img <= 2048)
+    float* d_rad_rays;          // deterministic mode: [R][6] per-ray contributions instead of atomics (summed in ray order afterwards)
 };
 
 struct CompositeBwdArgs {
@@ -93,6 +94,7 @@ struct EmbGradArgs {
     float* d_emb;            // [n_img][4] inside the flat gradient buffer
     int n_rays;
     int lds_images;          // > 0: accumulate per block in LDS first
+    float* d_emb_rays;       // deterministic mode: [R][4] per-ray sums instead of atomics (summed in ray order afterwards)
 };
 
 struct PackedArgs {        // flattened samples handed in by the caller (EONerfMLP.rendering / render_depth)
@@ -112,7 +114,10 @@ hipError_t eo_launch_shade_bwd(const ShadeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
-hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st);
+hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st, bool deterministic = false);
+// out[idx[r] * stride + w] += contrib[r * width + w], summed over the rays in ray order by ONE thread per (table row, w)
+hipError_t eo_launch_table_reduce(const float* contrib, const int64_t* idx, int n_rays, int width, int stride, int n_rows, int eval_first,
+                                  float* out, hipStream_t st);
 hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st);
 hipError_t eo_launch_field_grads_to_soa(const float* g_sigma, const float* g_albedo, const float* g_ts, const float* g_tb, int n, int p_pad,
                                        float* o_sigma, float* o_albedo, float* o_ts, float* o_tb, hipStream_t st);

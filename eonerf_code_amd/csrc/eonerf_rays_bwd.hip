@@ -10,7 +10,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_shade_bwd(ShadeBwdArgs a) {
     extern __shared__ float s_dT[];                    // [n_img][6] block-local radiometric gradient (0 floats if unused)
     const int ray = blockIdx.x * 256 + threadIdx.x;
-    const bool lds_acc = a.d_radiometric && a.lds_images > 0;
+    const bool lds_acc = a.d_radiometric && a.lds_images > 0 && !a.d_rad_rays;
     if (lds_acc) {
         for (int i = threadIdx.x; i < a.lds_images * 6; i += 256) s_dT[i] = 0.f;
         __syncthreads();
@@ -34,7 +34,10 @@ __global__ __launch_bounds__(256) void k_shade_bwd(ShadeBwdArgs a) {
             const float lin = A * pre + b;
             const float g_lin = (lin >= 0.f && lin <= 1.f) ? go[c] : 0.f;        // torch.clip backward (inclusive bounds)
             const float g_shl = go[18 + c];
-            if (a.d_radiometric) {
+            if (a.d_rad_rays) {
+                a.d_rad_rays[(size_t)ray * 6 + c] = g_lin * pre + g_shl * alb;
+                a.d_rad_rays[(size_t)ray * 6 + 3 + c] = g_lin + g_shl;
+            } else if (a.d_radiometric) {
                 const float dA = g_lin * pre + g_shl * alb, db = g_lin + g_shl;
                 if (lds_acc) { atomicAdd(&s_dT[img * 6 + c], dA); atomicAdd(&s_dT[img * 6 + 3 + c], db); }
                 else { atomicAdd(a.d_radiometric + img * 9 + c, dA); atomicAdd(a.d_radiometric + img * 9 + 3 + c, db); }
@@ -177,14 +180,17 @@ __global__ __launch_bounds__(128 * AMB_STREAMS) void k_ambient_bwd(AmbientBwdArg
 #pragma unroll
         for (int i = 0; i < 27; ++i) r[i] = dw1[i];
         r[27] = db1; r[28] = dw2[0]; r[29] = dw2[1]; r[30] = dw2[2];
-    }
-    // db2 is the same for every hidden unit of a stream: one thread per stream adds it
-    if (j == 0) {
-#pragma unroll
-        for (int o = 0; o < 3; ++o) if (db2[o] != 0.f) atomicAdd(a.d_b2 + o, db2[o]);
+        // db2 is the same for every hidden unit of a stream: units 0..2 hand one component each to stream 0 (slot 31)
+        if (j < 3) r[31] = j == 0 ? db2[0] : (j == 1 ? db2[1] : db2[2]);
     }
     __syncthreads();
     if (q > 0) return;
+    if (j < 3) {      // one add per component and block, the streams summed in a fixed order
+        float v = j == 0 ? db2[0] : (j == 1 ? db2[1] : db2[2]);
+#pragma unroll
+        for (int s = 0; s < AMB_STREAMS - 1; ++s) v += red[s][j][31];
+        if (v != 0.f) atomicAdd(a.d_b2 + j, v);
+    }
 #pragma unroll
     for (int s = 0; s < AMB_STREAMS - 1; ++s) {
         const float* r = red[s][j];
@@ -270,6 +276,20 @@ __global__ __launch_bounds__(256) void k_ambient_points_bwd(AmbientW w, const fl
     }
 }
 
+// ---- deterministic mode: table[idx[r]][w] += contrib[r][w], one thread per (table row, w), rays in order ----
+__global__ void k_table_reduce(const float* contrib, const int64_t* idx, int n_rays, int width, int stride, int n_rows, int eval_first, float* out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * width) return;
+    const int row = t / width, w = t % width;
+    float acc = 0.f;
+    const long first = eval_first ? idx[0] : 0;
+    for (int r = 0; r < n_rays; ++r) {
+        const long i = eval_first ? first : idx[r];
+        if (i == row) acc += contrib[(size_t)r * width + w];
+    }
+    out[(size_t)row * stride + w] += acc;
+}
+
 // ---- bottleneck layer weight gradient from the two factors (fp32): block = input feature i of the heads' first layers =
 //      output feature (row) of the bottleneck layer, thread = column j ----
 __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
 __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
     extern __shared__ float s_de[];                     // [n_img][4] block-local accumulation (0 floats if unused)
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK * 8 + (threadIdx.x >> 6);
-    const bool lds_acc = a.lds_images > 0;
+    const bool lds_acc = a.lds_images > 0 && !a.d_emb_rays;
     if (lds_acc) {
         for (int i = threadIdx.x; i < a.lds_images * 4; i += 256) s_de[i] = 0.f;
         __syncthreads();
@@ -317,7 +337,8 @@ __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
         for (int e = 0; e < 4; ++e) acc[e] = wave_sum(acc[e]);
         if (lane < 4) {
             const float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
-            if (lds_acc) atomicAdd(&s_de[a.img_idx[rr] * 4 + lane], v);
+            if (a.d_emb_rays) a.d_emb_rays[(size_t)rr * 4 + lane] = v;
+            else if (lds_acc) atomicAdd(&s_de[a.img_idx[rr] * 4 + lane], v);
             else atomicAdd(a.d_emb + a.img_idx[rr] * 4 + lane, v);
         }
     }
@@ -413,8 +434,14 @@ hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_bott_wgrad, dim3(256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
-hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_ambient_bwd, dim3(a.n_rays < 256 ? (a.n_rays + 3) / 4 : 64), dim3(128 * AMB_STREAMS), 0, st, a);
+hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st, bool deterministic) {
+    // deterministic mode: ONE block -- every address is then added by exactly one thread, its rays in a fixed order
+    hipLaunchKernelGGL(k_ambient_bwd, dim3(deterministic ? 1 : (a.n_rays < 256 ? (a.n_rays + 3) / 4 : 64)), dim3(128 * AMB_STREAMS), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_table_reduce(const float* contrib, const int64_t* idx, int n_rays, int width, int stride, int n_rows, int eval_first,
+                                  float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_table_reduce, dim3((n_rows * width + 63) / 64), dim3(64), 0, st, contrib, idx, n_rays, width, stride, n_rows, eval_first, out);
     return hipGetLastError();
 }
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {

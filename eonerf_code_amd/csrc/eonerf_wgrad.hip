@@ -29,7 +29,7 @@ constexpr int WMAX = 4, NMAX = 2;
 EO_DEV int wg_swz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }
 
 template <class P>
-__global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_pad, int* queue) {
+__global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_pad, int* queue, float* partials) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef typename P::U U;
     constexpr int BK = ROW_B / P::ACT_BYTES;             // samples per K step
@@ -166,7 +166,16 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
                     const int col = (wn_idx * wn + j) * 32 + r;
                     int cm = col;
                     if (col < job.n_rows && job.col_map) cm = job.col_map[col];
-                    if (col < job.n_rows && cm >= 0) {
+                    if (partials) {      // deterministic mode: the tile as it stands ([row][256 columns]), reduced by k_wgrad_reduce
+                        if (col < job.n_rows) {
+                            float* pt = partials + (size_t)item * WGRAD_PART_F;
+#pragma unroll
+                            for (int g = 0; g < 16; ++g) {
+                                const int row = (wm_idx * wm + i) * 32 + acc_row(g, h);
+                                if (row < job.m_rows) pt[row * 256 + col] = acc[i][j][g];
+                            }
+                        }
+                    } else if (col < job.n_rows && cm >= 0) {
 #pragma unroll
                         for (int g = 0; g < 16; ++g) {
                             const int row = (wm_idx * wm + i) * 32 + acc_row(g, h);
@@ -179,14 +188,40 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int row = (wm_idx * wm + wn_idx) * 32 + acc_row(g, h);
-            if (row < job.m_rows) atomicAdd(job.db + row, accb[g]);
+            if (row < job.m_rows) {
+                if (partials) partials[(size_t)item * WGRAD_PART_F + 256 * 256 + row] = accb[g];
+                else atomicAdd(job.db + row, accb[g]);
+            }
         }
     }
     }
   }
 }
 
-template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, hipStream_t st) {
+// deterministic mode: block = (job, row), thread = column: the job's non-empty slices are summed in slice order
+template <class P>
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradJobTable tab, const float* partials) {
+    const WgradJob job = tab.j[blockIdx.y];
+    const int row = blockIdx.x, col = threadIdx.x;
+    if (row >= job.m_rows) return;
+    const int n_pts = *job.n_pts;
+    const int steps = (n_pts + P::TILE - 1) / P::TILE * P::TILE / (ROW_B / P::ACT_BYTES);
+    float acc = 0.f, accb = 0.f;
+    for (int w = 0; w < job.slices; ++w) {
+        const int s0 = (int)((long long)w * steps / job.slices), s1 = (int)((long long)(w + 1) * steps / job.slices);
+        if (s0 >= s1) continue;
+        const float* pt = partials + (size_t)(job.item0 + w) * WGRAD_PART_F;
+        if (col < job.n_rows) acc += pt[row * 256 + col];
+        if (col == 0 && job.db) accb += pt[256 * 256 + row];
+    }
+    if (col < job.n_rows) {
+        const int cm = job.col_map ? job.col_map[col] : col;
+        if (cm >= 0) job.dw[(size_t)row * job.dw_ld + cm] += acc;      // the only writer of this element in this launch
+    }
+    if (col == 0 && job.db) job.db[row] += accb;
+}
+
+template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, hipStream_t st, float* partials) {
     constexpr int SMEM = NS * SLOT_B + 16;
     static bool attr_done = false;
     if (!attr_done) {
@@ -194,14 +229,15 @@ template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_wgrad<P>), dim3(n_wg), dim3(WG_NT), SMEM, st, jobs, p_pad, queue);
+    hipLaunchKernelGGL((k_wgrad<P>), dim3(n_wg), dim3(WG_NT), SMEM, st, jobs, p_pad, queue, partials);
+    if (partials) hipLaunchKernelGGL((k_wgrad_reduce<P>), dim3(256, jobs.n), dim3(256), 0, st, jobs, partials);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st) {
+hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st, float* partials) {
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
-    return bf16 ? launch<PBf16>(jobs, n_wg, p_pad, queue, st) : launch<PF32>(jobs, n_wg, p_pad, queue, st);
+    return bf16 ? launch<PBf16>(jobs, n_wg, p_pad, queue, st, partials) : launch<PF32>(jobs, n_wg, p_pad, queue, st, partials);
 }

@@ -123,3 +123,36 @@ def test_gradient_run_to_run_difference_is_bounded(precision):
     assert abs(l0 - l1) <= 1e-6 * abs(l0)
     for (name, p), a, b in zip(f.named_parameters(), f.grad_views(g0), f.grad_views(g1)):
         assert (a - b).norm().item() <= 2e-6 * a.norm().item() + 1e-12, (name, (a - b).norm().item(), a.norm().item())
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_deterministic_mode_reproduces_gradients_bit_for_bit(precision):
+    """EONERF_DETERMINISTIC=1 (read when the context is created): every atomic flush of the backward -- the pipelined trunk's dW,
+    the weight-gradient GEMM, the embedding / radiometric / ambient reductions -- is replaced by partial sums + a fixed-order
+    reduction, so two backward passes of the same batch give BIT-IDENTICAL gradients (what "identical replicas" in
+    data-parallel training rests on), and they agree with the default (atomic) mode to reduction noise."""
+    import os
+    from eonerf_code_amd.trainer import FusedTrainer
+    os.environ["EONERF_DETERMINISTIC"] = "1"
+    try:
+        f, rays, img, rgbs, noise = _setup(precision, seed=17)
+        f._context()
+    finally:
+        os.environ.pop("EONERF_DETERMINISTIC", None)
+    tr = FusedTrainer(f, lr=0.0, max_rays=R)
+    grads = []
+    for _ in range(3):
+        before = f.flat_params().clone()
+        tr.step(rays, img, rgbs, 3, noise=noise)
+        tr.check_device_status()
+        grads.append(tr.d_flat.clone())
+        f.flat_params().copy_(before)
+        f._packed_version = None
+    differing = [name for (name, p), a, b, c in zip(f.named_parameters(), f.grad_views(grads[0]), f.grad_views(grads[1]), f.grad_views(grads[2]))
+                 if not (torch.equal(a, b) and torch.equal(a, c))]
+    assert not differing, differing
+    f2, _, _, _, _ = _setup(precision, seed=17)
+    tr2 = FusedTrainer(f2, lr=0.0, max_rays=R)
+    tr2.step(rays, img, rgbs, 3, noise=noise)
+    for (name, p), a, b in zip(f.named_parameters(), f.grad_views(grads[0]), f2.grad_views(tr2.d_flat)):
+        assert (a - b).norm().item() <= 2e-6 * a.norm().item() + 1e-12, name
