@@ -24,6 +24,13 @@
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
 
+// Diagnostic builds only (scripts/pipe_ablate.sh): EO_PABL bit 0 drops the dW MFMAs, bit 1 the dX MFMAs, bit 2 the B-fragment LDS reads of
+// both products, bit 3 the LDS-DMA refill, bit 4 the ring / slab stores, bit 5 the epilogue's VALU work and the bias sums.  Results are
+// WRONG with any bit set; the shipped library is built with EO_PABL == 0.
+#ifndef EO_PABL
+#define EO_PABL 0
+#endif
+
 namespace {
 
 constexpr int NT = 512;
@@ -104,6 +111,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         x_voff[j] = row * SEG_B + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
     }
     auto issue = [&](int k) {      // DMA of this pipeline's k-th step (clamped by the caller) into LDS slot k & 3
+        if ((EO_PABL & 8) && k >= DEPTH) return;
         const int g = S.pipe + k * a.n_pipes;                          // global step = sample tile
         uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
         // dY image: 16 pieces of 1 KiB, wave w copies pieces 2w, 2w+1
@@ -248,8 +256,8 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 for (int d = 0; d < 3; ++d) fr[d] = lds_unit<P>(bp + d * 1024);
 #pragma unroll
                 for (int kg = 0; kg < 16; ++kg) {
-                    acc = P::mma(wt[kg], fr[kg % 3], acc);
-                    if (kg + 3 < 16) fr[kg % 3] = lds_unit<P>(bp + (kg + 3) * 1024);
+                    if (!(EO_PABL & 2)) acc = P::mma(wt[kg], fr[kg % 3], acc);
+                    if (!(EO_PABL & 4) && kg + 3 < 16) fr[kg % 3] = lds_unit<P>(bp + (kg + 3) * 1024);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -265,13 +273,14 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             uint32_t w8[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) {      // word s = accumulator registers 2s, 2s+1 <-> activation word s of the transposed reads
+                if (EO_PABL & 32) { w8[s] = xm[s >> 1][s & 1]; continue; }
                 uint32_t flags, r;
                 const uint32_t xw = xm[s >> 1][s & 1];
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(flags) : "v"(xw), "v"(0x00010001u));        // post-ReLU bf16 >= 0: 1 where > 0
                 asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(cvt_pk_bf16(acc[2 * s], acc[2 * s + 1])), "v"(flags));
                 w8[s] = r;
             }
-            if (HAS_OUT) {
+            if (HAS_OUT && !(EO_PABL & 16)) {
                 const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ring_out + (size_t)(k & (PIPE_RING - 1)) * IMG_B, 0, IMG_B, 0x00020000);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
@@ -326,14 +335,14 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 bf[1] = lds_unit<P>(xb + 2048);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    dw[j] = P::mma(af, bf[j & 1], dw[j]);
-                    if (j + 2 < 8) bf[j & 1] = lds_unit<P>(xb + (j + 2) * 2048);
+                    if (!(EO_PABL & 1)) dw[j] = P::mma(af, bf[j & 1], dw[j]);
+                    if (!(EO_PABL & 4) && j + 2 < 8) bf[j & 1] = lds_unit<P>(xb + (j + 2) * 2048);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // bias gradient: this lane's 8 samples of feature 32 wave + (lane & 31)
                 const u32x4 av = __builtin_bit_cast(u32x4, af);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) db += __uint_as_float(av[e] << 16) + __uint_as_float(av[e] & 0xffff0000u);
+                for (int e = 0; e < 4; ++e) if (!(EO_PABL & 32)) db += __uint_as_float(av[e] << 16) + __uint_as_float(av[e] & 0xffff0000u);
             }
         };
         const int k_next = k + DEPTH < n_k ? k + DEPTH : n_k - 1;       // refill: into the slot step k-1 used (free behind this step's barrier)
