@@ -227,7 +227,9 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         asm volatile("s_barrier" ::: "memory");
         const unsigned long long tt2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         if (stamp) { t_top += tt1 - tt0; t_bar += tt2 - tt1; }
-        if (ctl[0]) return;            // a watchdog fired in this workgroup: every wave leaves behind the same barrier
+        // a watchdog fired in this workgroup: every wave leaves behind the same barrier (looked at every 8th step: the LDS round trip
+        // costs every wave ~100 cycles, and a stalled pipeline is in no hurry)
+        if ((k & 7) == 0 && ctl[0]) return;
         if (CTRL) {
             // behind the barrier: every wave's share of step k has landed (=> the ring slot of tile k can go back) and every
             // wave's stores of step k-2 are complete (=> tiles 0..k-2 are published)
