@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one complete optimisation step of the launcher's loop (eonerf_code_amd/train_dp.py) on rays that are already
-resident in HBM: on-device batch gather from the ray table (RayTable.batch) -> render forward (sampler
+resident in HBM: the batch of the GPU-resident, per-epoch shuffled ray table (RayTable.batch) -> render forward (sampler
 with in-kernel jitter, fused MLP chain, compositing, shading) -> loss -> backward (compositing, backward chain,
 weight-gradient GEMM) -> [RCCL all-reduce of the flat gradient] -> Adam + weight re-pack.
 
@@ -269,7 +269,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": names[workloads[0]], "rays_per_gpu": RAYS, "n_samples": 128, "n_images": N_IMG, "parallelism": f"dp{world}",
-                       "batching": "on-device gather from a GPU-resident ray table (RayTable.batch), in-kernel Philox jitter",
+                       "batching": "GPU-resident ray table, shuffled on the device once per epoch, batches = slices (RayTable.batch); in-kernel Philox jitter",
                        "camera_samples_per_step": head["camera_samples_per_step"], "final_loss": head["final_loss"]},
             "roofline": head.get("roofline"),
             "kernels": head.get("kernels"),
