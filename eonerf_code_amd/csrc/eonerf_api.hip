@@ -295,6 +295,11 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         j.a_stride = (uint32_t)(ba.r * SEG_B);       // consecutive sample tiles of a block are contiguous
         j.b_stride = (uint32_t)(bb.r * SEG_B);
         j.m_rows = m_rows; j.n_rows = n_rows; j.dw_ld = dw_ld; j.gm = gm; j.gn = gn; j.wm = wm; j.wn = wn;
+        j.dw2 = nullptr; j.db2 = nullptr; j.split = m_rows; j.dw2_ld = 0;
+    };
+    auto split_at = [&](int row, float* dw2, int dw2_ld, float* db2) {      // rows >= row of the job just added go to a second layer's gradient
+        WgradJob& j = tab.j[tab.n - 1];
+        j.split = row; j.dw2 = dw2; j.dw2_ld = dw2_ld; j.db2 = db2;
     };
     // pipelined: the 256 x 256 products of layers 1..7 (and their biases) were accumulated by the layer-pipelined trunk backward;
     // what is left are the two 256 x 64 products against the encoding (layer 0, skip columns of layer 5) and the sigma row
@@ -314,17 +319,23 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         trunk_jobs(c, full_trunk_done);
         // bottleneck layer: factor M_a = dA1^T X8 (and M_t = dT1^T X8), finished by eo_launch_bott_wgrad below
         HIP_TRY(hipMemsetAsync(m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
-        add(c, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, nullptr, nullptr, 2, 4, 2, 2);
-        if (transient) add(c, GRD_ROW_T1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott + 128 * 256, 256, nullptr, nullptr, 2, 4, 2, 2);
-        add(c, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
+        // dY A1 and dY T1 are the two halves of one 256-row block of the gradient slab: with the transient head both factors (and both
+        // first-layer gradients against the bottleneck output) are ONE job each -- every operand block is read once, not twice
+        if (transient) {
+            add(c, GRD_ROW_A1, 256, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, nullptr, nullptr, 2, 4, 4, 2);          // [M_a; M_t]
+            add(c, GRD_ROW_A1, 256, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 4, 2);
+            split_at(128, dptr(pl.t_w[0]), 260, dptr(pl.t_b[0]));
+        } else {
+            add(c, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, nullptr, nullptr, 2, 4, 2, 2);
+            add(c, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
+        }
         add(c, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
         if (transient) {
-            add(c, GRD_ROW_T1, 128, ACT_ROW_BOTT, 256, dptr(pl.t_w[0]), 260, dptr(pl.t_b[0]), nullptr, 2, 4, 2, 2);
             add(c, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
             for (int l = 1; l < 4; ++l)
                 add(c, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
-            add(c, GRD_ROW_T5, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);
-            add(c, GRD_ROW_T5 + 1, 1, ACT_ROW_T1 + 384, 128, dptr(pl.tbe_w), 128, dptr(pl.tbe_b), nullptr, 1, 4, 1, 1);
+            add(c, GRD_ROW_T5, 2, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);     // row 0: d ts_pre, row 1: d tb_pre
+            split_at(1, dptr(pl.tbe_w), 128, dptr(pl.tbe_b));
         }
     }
     if (dens) trunk_jobs(*dens, dens_trunk_done);

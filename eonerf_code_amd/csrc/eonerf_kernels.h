@@ -18,9 +18,10 @@ constexpr int ACT_ROWS_DENSITY = ACT_ROW_BOTT;      // 2112 (trunk only)
 constexpr int GRD_ROW_Y0 = 0;                       // dY of trunk layers 0..7 (pre-activation grads), 256 rows each
 constexpr int GRD_ROW_BOTT = 8 * 256;               // 2048: d bottleneck (256)
 constexpr int GRD_ROW_SIG = GRD_ROW_BOTT + 256;     // 2304: d sigma_pre (1 row used of 32)
-constexpr int GRD_ROW_A1 = GRD_ROW_SIG + 32;        // 2336: dY albedo hidden (128)
-constexpr int GRD_ROW_A2 = GRD_ROW_A1 + 128;        // 2464: d albedo_pre (3 rows used of 32)
-constexpr int GRD_ROW_T1 = GRD_ROW_A2 + 32;         // 2496: dY T1..T4 (4 x 128)
+constexpr int GRD_ROW_A2 = GRD_ROW_SIG + 32;        // 2336: d albedo_pre (3 rows used of 32)
+constexpr int GRD_ROW_A1 = GRD_ROW_A2 + 32;         // 2368: dY albedo hidden (128) ...
+constexpr int GRD_ROW_T1 = GRD_ROW_A1 + 128;        // 2496: ... and dY T1 (128) share ONE 256-row block (both multiply X8 and the bottleneck output:
+                                                    //       one weight-gradient job each instead of two), then dY T2..T4 (3 x 128)
 constexpr int GRD_ROW_T5 = GRD_ROW_T1 + 512;        // 3008: d {ts_pre, tb_pre} (2 rows used of 32)
 constexpr int GRD_ROWS_FULL = GRD_ROW_T5 + 32;      // 3040
 constexpr int GRD_ROWS_DENSITY = GRD_ROW_SIG + 32;  // 2336
@@ -37,10 +38,10 @@ struct ActMap {
 struct GrdMap {
     __host__ __device__ static constexpr SlabBlk block(int row) {
         if (row < GRD_ROW_SIG) return SlabBlk{row / 256 * 256, 256};                                 // dY0..dY7, d bottleneck
-        if (row < GRD_ROW_A1) return SlabBlk{GRD_ROW_SIG, 32};
-        if (row < GRD_ROW_A2) return SlabBlk{GRD_ROW_A1, 128};
-        if (row < GRD_ROW_T1) return SlabBlk{GRD_ROW_A2, 32};
-        if (row < GRD_ROW_T5) return SlabBlk{GRD_ROW_T1 + (row - GRD_ROW_T1) / 128 * 128, 128};      // dY T1..T4
+        if (row < GRD_ROW_A2) return SlabBlk{GRD_ROW_SIG, 32};
+        if (row < GRD_ROW_A1) return SlabBlk{GRD_ROW_A2, 32};
+        if (row < GRD_ROW_T1 + 128) return SlabBlk{GRD_ROW_A1, 256};                                 // dY A1 | dY T1
+        if (row < GRD_ROW_T5) return SlabBlk{GRD_ROW_T1 + (row - GRD_ROW_T1) / 128 * 128, 128};      // dY T2..T4
         return SlabBlk{GRD_ROW_T5, 32};
     }
 };
@@ -88,6 +89,9 @@ struct WgradJob {
     uint32_t a_stride, b_stride;   // bytes between consecutive sample tiles (= slab rows x 64)
     float* dw;            // destination inside the flat gradient buffer
     float* db;            // bias gradient or nullptr
+    float* dw2;           // rows >= split go to a second destination (row - split): two layers that share BOTH operand blocks
+    float* db2;           //   (dY A1 | dY T1 against the bottleneck output; d ts_pre | d tb_pre against T4) are one job
+    int split, dw2_ld;    // split == m_rows: none
     const int* col_map;   // nullptr = identity; -1 entries are dropped
     const int* n_pts;     // device scalar: live samples of the pass these slabs belong to
     int m_rows, n_rows;   // valid rows of a / b
@@ -135,7 +139,8 @@ size_t eo_bwd_pipe_lds_bytes();
 
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, bool pipe = false);
-constexpr int WGRAD_MAX_JOBS = 40;
+constexpr int WGRAD_MAX_JOBS = 32;     // <= 31 used (fp32 chain + GEMM path, full model); the table must fit the 4-KiB kernel-argument segment
+static_assert(sizeof(WgradJob) * WGRAD_MAX_JOBS + 8 <= 4096, "job table exceeds the kernel-argument segment");
 struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int items; };   // by value in the kernel-argument segment; jobs sorted heaviest first
 // partials != nullptr (deterministic mode): every work item stores its tile to partials[item] ([256][256] dW | [256] db) instead of
 // adding it atomically, and a second kernel sums the items of a job in slice order

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
 #pragma unroll
                         for (int g = 0; g < 16; ++g) {
                             const int row = (wm_idx * wm + i) * 32 + acc_row(g, h);
-                            if (row < job.m_rows) atomicAdd(job.dw + (size_t)row * job.dw_ld + cm, acc[i][j][g]);
+                            if (row < job.split) atomicAdd(job.dw + (size_t)row * job.dw_ld + cm, acc[i][j][g]);
+                            else if (row < job.m_rows) atomicAdd(job.dw2 + (size_t)(row - job.split) * job.dw2_ld + cm, acc[i][j][g]);
                         }
                     }
                 }
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
             const int row = (wm_idx * wm + wn_idx) * 32 + acc_row(g, h);
             if (row < job.m_rows) {
                 if (partials) partials[(size_t)item * WGRAD_PART_F + 256 * 256 + row] = accb[g];
-                else atomicAdd(job.db + row, accb[g]);
+                else atomicAdd(row < job.split ? job.db + row : job.db2 + (row - job.split), accb[g]);
             }
         }
     }
@@ -214,11 +215,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradJobTable tab, c
         if (col < job.n_rows) acc += pt[row * 256 + col];
         if (col == 0 && job.db) accb += pt[256 * 256 + row];
     }
+    const bool second = row >= job.split;
     if (col < job.n_rows) {
         const int cm = job.col_map ? job.col_map[col] : col;
-        if (cm >= 0) job.dw[(size_t)row * job.dw_ld + cm] += acc;      // the only writer of this element in this launch
+        if (cm >= 0) (second ? job.dw2 + (size_t)(row - job.split) * job.dw2_ld : job.dw + (size_t)row * job.dw_ld)[cm] += acc;      // the only writer of this element in this launch
     }
-    if (col == 0 && job.db) job.db[row] += accb;
+    if (col == 0 && job.db) (second ? job.db2 + (row - job.split) : job.db + row)[0] += accb;
 }
 
 template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, hipStream_t st, float* partials) {
