@@ -295,7 +295,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         j.a_stride = (uint32_t)(ba.r * SEG_B);       // consecutive sample tiles of a block are contiguous
         j.b_stride = (uint32_t)(bb.r * SEG_B);
         j.m_rows = m_rows; j.n_rows = n_rows; j.dw_ld = dw_ld; j.gm = gm; j.gn = gn; j.wm = wm; j.wn = wn;
-        j.dw2 = nullptr; j.db2 = nullptr; j.split = m_rows; j.dw2_ld = 0;
+        j.dw2 = nullptr; j.db2 = nullptr; j.split = m_rows; j.dw2_ld = 0; j.a_units = 0;
     };
     auto split_at = [&](int row, float* dw2, int dw2_ld, float* db2) {      // rows >= row of the job just added go to a second layer's gradient
         WgradJob& j = tab.j[tab.n - 1];
@@ -304,13 +304,15 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     // pipelined: the 256 x 256 products of layers 1..7 (and their biases) were accumulated by the layer-pipelined trunk backward;
     // what is left are the two 256 x 64 products against the encoding (layer 0, skip columns of layer 5) and the sigma row
     auto trunk_jobs = [&](const PassBuffers& b, bool pipelined) {
+        // (pipelined: dY_0 and dY_5 lie in their slab tiles in unit order -- written once by the stages of layers 1 and 6)
         add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
+        tab.j[tab.n - 1].a_units = pipelined;
         for (int l = 1; l < 8; ++l) {
             const int in_ld = l == 5 ? 319 : 256;
             if (!pipelined)
                 add(b, GRD_ROW_Y0 + 256 * l, 256, ACT_ROW_X1 + 256 * (l - 1), 256, dptr(pl.trunk_w[l]), in_ld, dptr(pl.trunk_b[l]), nullptr, 2, 4, 4, 2);
             if (l == 5)   // skip columns 256..318 <- encoding slots
-                add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1);
+                { add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1); tab.j[tab.n - 1].a_units = pipelined; }
         }
         add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
     };

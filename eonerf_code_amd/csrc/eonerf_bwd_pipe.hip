@@ -13,7 +13,11 @@
 //       dY_{l-1} = dX .* relu'(mask)         packed to two 1-KiB units, stored write-through (sc1) into the output ring
 //       dW_l += dY_l X_l^T                   16 MFMAs per wave  (A = ds_read_b64_tr_b16 of the SAME dY image, B = X image)
 //       db_l += row sums of dY_l             VALU on the A fragments
-//   * dY never touches HBM: the rings (16 slots x 16 KiB per edge) live in the Infinity Cache and are overwritten in place.
+//   * dY_6 .. dY_1 never touch HBM: the rings (16 slots x 16 KiB per edge) live in the Infinity Cache and are overwritten in place.
+//     The two gradients the remaining GEMM jobs need against the encoding (dY_5: skip columns of layer 5, dY_0: layer 0) are written
+//     ONCE, in the same unit order, into their tiles of the gradient slab: the layer-6 stage's "ring" towards layer 5 IS that linear
+//     buffer (never overwritten, so no back-pressure on this edge), the layer-1 stage just stores there; eonerf_wgrad.hip reads these
+//     two operands through transposed LDS reads (WgradJob::a_units), eonerf_ig_tail.hip takes them as B units as they are.
 // Hand-off protocol (placement independent, cdna guide G16 / R1): payload stores sc1, every storing wave's stores are known
 // complete through the counted vmcnt of a LATER step's barrier, then ONE lane stores the edge's `head` counter (agent scope);
 // the consumer's control wave polls `head` (sc1 loads, two steps ahead of use) and loads the payload with sc1 LDS-DMA; it
@@ -39,9 +43,8 @@ constexpr int IMG_B = 16 * 1024;                  // one step of a 256-feature t
 constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 constexpr int NSLOT = 4, DEPTH = NSLOT - 1;
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
-constexpr int STAGE_B = 8 * TR_WAVE_B;            // slab staging (stages that also save their output rows), one buffer per wave
 constexpr int CTRL_B = 64;
-constexpr int SMEM_B = NSLOT * SLOT_B + STAGE_B + CTRL_B;
+constexpr int SMEM_B = NSLOT * SLOT_B + CTRL_B;
 constexpr int AUX_SC1 = 16, AUX_NT = 2;
 constexpr unsigned long long WATCHDOG_TICKS = 30000000ull;     // 0.3 s of the 100 MHz s_memrealtime clock
 
@@ -49,9 +52,10 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 
 EO_DEV int wg_swz16(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16; }      // eonerf_wgrad.hip's ring swizzle
 
-// ops a wave issues per step, in program order: [CTRL: 2 flag stores, 2 flag polls] .. NST payload/slab stores .. N_DMA pieces
-// second order (waves 4..7): N_DMA pieces .. NST stores
-template <bool CTRL, int NST, bool ORDB> struct Cnt {
+// ops a wave issues per step, in program order: [CTRL: 2 flag stores, 2 flag polls] .. 2 payload stores .. N_DMA pieces
+// second order (waves 4..7): N_DMA pieces .. 2 payload stores
+constexpr int NST = 2;
+template <bool CTRL, bool ORDB> struct Cnt {
     static constexpr int C = (CTRL ? 4 : 0) + NST + N_DMA;
     // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s.
     // First order: the pieces of step s-2 and all of step s-1 are younger than those stores; second order: only step s-1
@@ -63,17 +67,17 @@ struct Stage {
     bool has_in;
 };
 
-// MODE 0: the output goes to the next stage's ring; 1: ring + gradient slab through an LDS transposition (layer 6: dY_5 feeds the
-// skip-column GEMM job); 2: slab only (layer 1: dY_0 feeds the layer-0 GEMM job); 3 (measured slower than 1, kept for reference):
-// ring, and the stage saves its INPUT rows straight from the transposed A fragments -- 32-byte half rows per lane, no staging
+// MODE 0: the output goes to the next stage's ring; 1 (layer 6): the output goes, write-through like a ring slot, to its tile of the
+// dY_5 block of the gradient slab, which the layer-5 stage reads as its "ring" and the skip-column GEMM job reads later; 2 (layer 1): the
+// output dY_0 goes to its tile of the dY_0 block (streaming stores, nobody in this launch reads it)
 template <bool CTRL, int MODE, bool ORDB = false>
 EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int tid) {
-    constexpr bool HAS_OUT = MODE != 2, SLAB = MODE == 1 || MODE == 2, SAVE_IN = MODE == 3;
-    constexpr int NST = (MODE == 1 || MODE == 3) ? 4 : 2;
+    constexpr bool HAS_OUT = MODE != 2;        // a consumer inside this launch (flags)
+    constexpr bool RING_OUT = MODE == 0;       // ... whose ring slots come back through the tail counter
     typedef PBf16 P;
     typedef P::U U;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
-    int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B + STAGE_B);      // [0] abort, [4..7] polled head, [8..11] polled tail
+    int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B);      // [0] abort, [4..7] polled head, [8..11] polled tail
     const int n_k = S.n_k;
 
     // ---- stationary operands ----
@@ -103,6 +107,11 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     // polling ONE shared line every step serialise at the memory side and stall the whole CU's vector-memory issue
     gu32* const my_scratch = (gu32*)(a.scratch_word + (size_t)(S.pipe * PIPE_STAGES + S.st) * 32);
 
+    // unit-order tiles inside the gradient slab (one 16-KiB tile of a 256-row block per 32 samples, same footprint as the feature-major
+    // tile the chain + GEMM path keeps there): dY_{layer-1} as this stage's output (MODE 1, 2), dY_layer as its input (layer 5)
+    uint8_t* const grd_blk = reinterpret_cast<uint8_t*>(a.grd) + (size_t)(GRD_ROW_Y0 + (S.layer - 1) * 256) * n_tiles * SEG_B;
+    const uint8_t* const in_blk = reinterpret_cast<const uint8_t*>(a.grd) + (size_t)(GRD_ROW_Y0 + S.layer * 256) * n_tiles * SEG_B;
+
     // per-lane DMA source offsets of the X image: wave w stages rows 32w..32w+31, 16 rows per piece, chunks XOR-swizzled
     int x_voff[2];
 #pragma unroll
@@ -115,7 +124,8 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         const int g = S.pipe + k * a.n_pipes;                          // global step = sample tile
         uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
         // dY image: 16 pieces of 1 KiB, wave w copies pieces 2w, 2w+1
-        const uint8_t* dsrc = S.has_in ? ring_in + (size_t)(k & (PIPE_RING - 1)) * IMG_B : a.dy_in + (size_t)g * IMG_B;
+        const uint8_t* dsrc = !S.has_in ? a.dy_in + (size_t)g * IMG_B
+                            : (S.layer == 5 ? in_blk + (size_t)g * IMG_B : ring_in + (size_t)(k & (PIPE_RING - 1)) * IMG_B);
         const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dsrc), 0, IMG_B, 0x00020000);
         if (S.has_in) {      // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
 #pragma unroll
@@ -153,17 +163,8 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         xm_off[q] = IMG_B + (f0 + qq) * SEG_B + wg_swz16(f0, 2 * (g4 & 1) + (pp >> 1)) + (pp & 1) * 8;
     }
 
-    // ---- slab staging (stages whose output rows the remaining GEMM jobs read: dY_5, dY_0) ----
-    uint8_t* const scratch = smem + NSLOT * SLOT_B + wave * TR_WAVE_B;
-    uint8_t* const st_w = scratch + c * TR_STRIDE + h * 8;
-    const uint8_t* const st_r = scratch + (8 * g4 + qq) * TR_STRIDE + pp * 8;
-    const int st_voff = i16 * SEG_B + g4 * 16;
-    const int out_row0 = GRD_ROW_Y0 + (S.layer - 1) * 256;            // block of dY_{layer-1}: 256 rows
-    uint8_t* const grd_blk = reinterpret_cast<uint8_t*>(a.grd) + (size_t)out_row0 * n_tiles * SEG_B;
-    uint8_t* const in_blk = reinterpret_cast<uint8_t*>(a.grd) + (size_t)(GRD_ROW_Y0 + S.layer * 256) * n_tiles * SEG_B;      // block of dY_layer
-
     // ---- control state (wave 0) ----
-    int known_head = S.has_in ? 0 : 0x7fffffff, known_tail = HAS_OUT ? 0 : 0x7fffffff;
+    int known_head = S.has_in ? 0 : 0x7fffffff, known_tail = RING_OUT ? 0 : 0x7fffffff;
     unsigned ph = 0, pt = 0;          // poll results in flight (inline asm: the compiler must not see these as loads)
     auto poll_sync = [&](gu32* word) -> int {      // slow path: one synchronous agent-scope read
         return (int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -208,20 +209,20 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             const int need_in = (k + DEPTH < n_k ? k + DEPTH : n_k - 1) + 1;       // tiles that must be published for this step's DMA
             const int need_out = k + 1 - PIPE_RING;                                 // tiles the consumer must have released
             const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            const bool slow = (S.has_in && known_head < need_in) || (HAS_OUT && known_tail < need_out);
+            const bool slow = (S.has_in && known_head < need_in) || (RING_OUT && known_tail < need_out);
             if (S.has_in && known_head < need_in) wait_for(f_in, need_in, known_head);
-            if (HAS_OUT && known_tail < need_out) wait_for(f_out + 32, need_out, known_tail);
+            if (RING_OUT && known_tail < need_out) wait_for(f_out + 32, need_out, known_tail);
             if (stamp && slow) { t_slow += __builtin_amdgcn_s_memtime() - ts0; ++n_slow; }
         }
         const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cnt<CTRL, NST, ORDB>::TOP) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cnt<CTRL, ORDB>::TOP) : "memory");
         const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         if (CTRL) {      // the polls of step k-2 are older than anything the wait above left outstanding
             asm volatile("" : "+v"(ph), "+v"(pt));
             if (k >= 2) {
                 const int vh = __builtin_amdgcn_readfirstlane((int)ph), vt = __builtin_amdgcn_readfirstlane((int)pt);
                 if (S.has_in && vh > known_head) known_head = vh;
-                if (HAS_OUT && vt > known_tail) known_tail = vt;
+                if (RING_OUT && vt > known_tail) known_tail = vt;
             }
         }
         asm volatile("s_barrier" ::: "memory");
@@ -241,7 +242,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             }
             // polls for step k+2 (always two loads: fixed op count)
             const gu32* a_h = S.has_in ? f_in : my_scratch;
-            const gu32* a_t = HAS_OUT ? f_out + 32 : my_scratch;
+            const gu32* a_t = RING_OUT ? f_out + 32 : my_scratch;
             asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1"
                          : "=&v"(ph), "=&v"(pt) : "v"(a_h), "v"(a_t) : "memory");
         }
@@ -282,52 +283,34 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(cvt_pk_bf16(acc[2 * s], acc[2 * s + 1])), "v"(flags));
                 w8[s] = r;
             }
-            if (HAS_OUT && !(EO_PABL & 16)) {
-                const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ring_out + (size_t)(k & (PIPE_RING - 1)) * IMG_B, 0, IMG_B, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
+            if (!(EO_PABL & 16)) {
+                if (MODE == 0) {
+                    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ring_out + (size_t)(k & (PIPE_RING - 1)) * IMG_B, 0, IMG_B, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
+                } else {
+                    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(grd_blk + (size_t)(S.pipe + k * a.n_pipes) * IMG_B, 0, IMG_B, 0x00020000);
+                    if (MODE == 1) {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_NT);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_NT);
+                    }
+                }
             }
-            if (SLAB) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(st_w + 16 * q) = u32x2{w8[2 * q], w8[2 * q + 1]};
-            }
-        };
-        auto slab_store = [&](const u32x2& sa0, const u32x2& sb0, const u32x2& sa1, const u32x2& sb1) {
-            const int g = S.pipe + k * a.n_pipes;
-            const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(grd_blk + ((size_t)g * 256 + 32 * wave) * SEG_B, 0, 32 * SEG_B, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa0[0], sa0[1], sb0[0], sb0[1]}, rs_g, st_voff, 0, AUX_NT);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{sa1[0], sa1[1], sb1[0], sb1[1]}, rs_g, st_voff, 16 * SEG_B, AUX_NT);
         };
         auto phase_dw = [&]() {        // dW += dY X^T (2 K steps of 16 samples x 8 column tiles), db += row sums
             // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
-            // LDS-DMA in flight and drains it).  In the first order a stage that saves its output rows reads the staged tile back in
-            // the same batch (same scheme as SlabWriter) and stores it before the MFMAs start.
+            // LDS-DMA in flight and drains it)
             u32x2 ta[2][2];
             const uint32_t ra = (uint32_t)(uintptr_t)(slot + tr_off);
-            if (SLAB && !ORDB) {
-                u32x2 sa0, sa1, sb0, sb1;
-                const uint32_t rs = (uint32_t)(uintptr_t)st_r;
-                asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
-                             "ds_read_b64_tr_b16 %1, %8 offset:288\n\t"
-                             "ds_read_b64_tr_b16 %2, %8 offset:32\n\t"
-                             "ds_read_b64_tr_b16 %3, %8 offset:320\n\t"
-                             "ds_read_b64_tr_b16 %4, %9\n\t"
-                             "ds_read_b64_tr_b16 %5, %9 offset:64\n\t"
-                             "ds_read_b64_tr_b16 %6, %9 offset:256\n\t"
-                             "ds_read_b64_tr_b16 %7, %9 offset:320\n\t"
-                             "s_waitcnt lgkmcnt(4)"
-                             : "=&v"(sa0), "=&v"(sb0), "=&v"(sa1), "=&v"(sb1), "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1])
-                             : "v"(rs), "v"(ra) : "memory");
-                slab_store(sa0, sb0, sa1, sb1);
-                asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(0)" : "+v"(ta[0][0]), "+v"(ta[0][1]), "+v"(ta[1][0]), "+v"(ta[1][1])::"memory");
-            } else {
-                asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
-                             "ds_read_b64_tr_b16 %1, %4 offset:64\n\t"
-                             "ds_read_b64_tr_b16 %2, %4 offset:256\n\t"
-                             "ds_read_b64_tr_b16 %3, %4 offset:320\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]) : "v"(ra) : "memory");
-            }
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                         "ds_read_b64_tr_b16 %1, %4 offset:64\n\t"
+                         "ds_read_b64_tr_b16 %2, %4 offset:256\n\t"
+                         "ds_read_b64_tr_b16 %3, %4 offset:320\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]) : "v"(ra) : "memory");
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const U af = __builtin_bit_cast(U, u32x4{ta[ks][0][0], ta[ks][0][1], ta[ks][1][0], ta[ks][1][1]});
@@ -361,18 +344,6 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             phase_dw();
             const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             phase_dx();
-            if (SLAB) {      // the staged tile goes out at the end of the step
-                u32x2 sa0, sa1, sb0, sb1;
-                const uint32_t rs = (uint32_t)(uintptr_t)st_r;
-                asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
-                             "ds_read_b64_tr_b16 %1, %4 offset:288\n\t"
-                             "ds_read_b64_tr_b16 %2, %4 offset:32\n\t"
-                             "ds_read_b64_tr_b16 %3, %4 offset:320\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(sa0), "=&v"(sb0), "=&v"(sa1), "=&v"(sb1) : "v"(rs) : "memory");
-                slab_store(sa0, sb0, sa1, sb1);
-                asm volatile("s_nop 1" ::: "memory");
-            }
             if (stamp) { t_is += tt3 - tt2; t_dw += tt4 - tt3; t_dx += __builtin_amdgcn_s_memtime() - tt4; }
         }
     }
@@ -410,7 +381,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 __global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
-    int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B + STAGE_B);
+    int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B);
     if (tid == 0) { ctl[0] = 0; ctl[1] = atomicAdd(a.role_counter, 1); }
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(ctl[1]);

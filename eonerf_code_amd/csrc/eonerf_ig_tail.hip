@@ -3,8 +3,8 @@
 //     d sigma / d position = sum over encoding slots of  d enc . d enc / d x      (encoder derivative 2^k cos(2^k x [+ pi/2]),
 //                                                                                  radiance_fields/mlp.py:190-208)
 // -- what the chain kernel's INPUT_GRAD variant computes at its end (eonerf_mlp_bwd.hip); sat_rendering.py:90 keeps the rendered
-// depth attached, so this gradient flows on into the camera pass.  dY_0 and dY_5 are the rows the pipeline's stages of layers 1
-// and 6 saved in the gradient slab (feature-major tiles); they become MFMA B operands through transposed LDS reads.
+// depth attached, so this gradient flows on into the camera pass.  dY_0 and dY_5 are the tiles the pipeline's stages of layers 1
+// and 6 wrote into the gradient slab in B-operand unit order: MFMA B operands as they are.
 // Memory-bound (1 KiB per sample, 32 K MACs): one wave per 32-sample tile, 4 waves per workgroup, one per SIMD with the whole
 // W^T operand (64 A units) in registers.
 #include "eonerf_common.h"
@@ -33,11 +33,6 @@ __global__ __launch_bounds__(256) void k_ig_tail(IgTailArgs a) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int kg = 0; kg < 16; ++kg) wt[s][mt][kg] = *reinterpret_cast<const U*>(a.wt + ((size_t)((s * 2 + mt) * 16 + kg)) * 1024 + lane * 16);
-    // transposed reads of a feature-major image: 16-lane group g4 covers samples 16 (g4 & 1) .., lane half g4 >> 1; a read takes rows
-    // (features) f0 .. f0 + 3 and returns, per lane, one sample's four features = half a B unit (PBf16::feat order)
-    const int g4 = lane >> 4, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
-    const int tr_base = (4 * (g4 >> 1) + qq) * SEG_B + (16 * (g4 & 1) + 4 * pp) * 2;          // + 16 kg rows, + 8 rows for the second half
-
     for (int t = blockIdx.x * 4 + wave; t < n_tiles_live; t += gridDim.x * 4) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -52,13 +47,7 @@ __global__ __launch_bounds__(256) void k_ig_tail(IgTailArgs a) {
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int kg = 0; kg < 16; ++kg) {
-                u32x2 b0, b1;
-                const uint32_t ra = (uint32_t)(uintptr_t)(img + s * IMG + tr_base + kg * 16 * SEG_B);
-                asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
-                             "ds_read_b64_tr_b16 %1, %2 offset:512\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(b0), "=&v"(b1) : "v"(ra) : "memory");
-                const U bu = __builtin_bit_cast(U, u32x4{b0[0], b0[1], b1[0], b1[1]});
+                const U bu = lds_unit<P>(img + s * IMG + kg * 1024 + lane * 16);
                 acc[0] = P::mma(wt[s][0][kg], bu, acc[0]);
                 acc[1] = P::mma(wt[s][1][kg], bu, acc[1]);
             }

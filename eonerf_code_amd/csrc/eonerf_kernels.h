@@ -98,6 +98,7 @@ struct WgradJob {
     int dw_ld;            // row stride of dw
     int gm, gn, wm, wn;   // wave grid and tiles per wave: (gm*wm*32) x (gn*wn*32) >= m_rows x n_rows
     int item0, slices;    // work items [item0, item0 + slices) = equal slices of this job's K range
+    int a_units;          // bf16: a's tiles are in B-operand unit order (written by eonerf_bwd_pipe.hip), not feature-major rows
 };
 
 // ---- layer-pipelined trunk backward (eonerf_bwd_pipe.hip) ----

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
         const int row = 32 * wid + 16 * j + (lane >> 2);
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);
         const int ra = row < job.m_rows ? row : job.m_rows - 1, rb = row < job.n_rows ? row : job.n_rows - 1;
-        voff_a[j] = ra * SEG_B + chunk * 16;
+        // a_units: the A operand of this job is a 16-KiB tile in B-operand unit order (the layer-pipelined backward wrote dY_5 / dY_0
+        // that way, eonerf_bwd_pipe.hip): the tile is copied as it is, the fragments come out of it through transposed reads
+        voff_a[j] = job.a_units ? (32 * wid + 16 * j) * SEG_B + lane * 16 : ra * SEG_B + chunk * 16;
         voff_b[j] = rb * SEG_B + chunk * 16;
         on_a[j] = 32 * wid + 16 * j < job.m_rows;
         on_b[j] = 32 * wid + 16 * j < job.n_rows;
@@ -108,7 +110,14 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
 #pragma unroll
-        for (int i = 0; i < WMAX; ++i) { const int row = (wm_idx * wm + i) * 32 + r; off_a[i][kg] = row * ROW_B + wg_swz(row, 2 * kg + h); }
+        for (int i = 0; i < WMAX; ++i) {
+            const int row = (wm_idx * wm + i) * 32 + r;
+            off_a[i][kg] = row * ROW_B + wg_swz(row, 2 * kg + h);
+            if (job.a_units) {      // units 2 mt, 2 mt + 1 hold features 32 mt ..; the 16-lane group / lane split of ds_read_b64_tr_b16 (see eonerf_bwd_pipe.hip)
+                const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+                off_a[i][kg] = (2 * (wm_idx * wm + i) + (g4 & 1)) * 1024 + ((pp & 1) * 32 + 8 * (g4 >> 1) + qq) * 16 + (pp >> 1) * 8 + 256 * kg;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NMAX; ++j) { const int row = (wn_idx * wn + j) * 32 + r; off_b[j][kg] = OPND_B + row * ROW_B + wg_swz(row, 2 * kg + h); }
     }
@@ -117,8 +126,9 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
     for (int d = 0; d < DEPTH; ++d) issue(s0 + d < s1 ? s0 + d : s1 - 1, d);
     // the loop is instantiated per number of LDS-DMA pieces this wave issues per step (the counted vmcnt needs an immediate);
     // waves of one workgroup may run different instantiations, they all meet at the same s_barrier once per step
-    auto k_loop = [&](auto n_dma_c) {
+    auto k_loop = [&](auto n_dma_c, auto units_c) {
         constexpr int N_DMA = decltype(n_dma_c)::value;
+        constexpr bool UNITS = decltype(units_c)::value;
         for (int s = s0; s < s1; ++s) {
             const int slot = (s - s0) & (NS - 1);
             // this wave's share of step s has landed once at most (DEPTH-1) younger steps are outstanding; the barrier then
@@ -127,6 +137,33 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
             issue(s + DEPTH < s1 ? s + DEPTH : s1 - 1, (slot + DEPTH) & (NS - 1));
             if (active) {
                 const uint8_t* T = smem + slot * SLOT_B;
+                if constexpr (UNITS) {
+                    // A tile in unit order (always the 256 x 64 shape, two m-tiles per wave): the four fragments of the step come out of
+                    // eight transposed reads issued back to back behind ONE wait (inline asm: for the intrinsic the wait-count pass
+                    // assumes aliasing with the LDS-DMA in flight and drains it)
+                    u32x2 t[8];
+                    asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                                 "ds_read_b64_tr_b16 %1, %8 offset:64\n\t"
+                                 "ds_read_b64_tr_b16 %2, %9\n\t"
+                                 "ds_read_b64_tr_b16 %3, %9 offset:64\n\t"
+                                 "ds_read_b64_tr_b16 %4, %8 offset:256\n\t"
+                                 "ds_read_b64_tr_b16 %5, %8 offset:320\n\t"
+                                 "ds_read_b64_tr_b16 %6, %9 offset:256\n\t"
+                                 "ds_read_b64_tr_b16 %7, %9 offset:320\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                                 : "v"((uint32_t)(uintptr_t)(T + off_a[0][0])), "v"((uint32_t)(uintptr_t)(T + off_a[1][0])) : "memory");
+#pragma unroll
+                    for (int kg = 0; kg < 2; ++kg) {
+                        const U bf0 = lds_unit<P>(T + off_b[0][kg]);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const U af = __builtin_bit_cast(U, u32x4{t[4 * kg + 2 * i][0], t[4 * kg + 2 * i][1], t[4 * kg + 2 * i + 1][0], t[4 * kg + 2 * i + 1][1]});
+                            acc[i][0] = P::mma(af, bf0, acc[i][0]);
+                            if (do_bias && i == wn_idx) accb = P::mma(af, ones, accb);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int kg = 0; kg < 2; ++kg) {
                     U af[WMAX], bf[NMAX];
@@ -143,15 +180,20 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
                             if (do_bias && i == wn_idx) accb = P::mma(af[i], ones, accb);
                         }
                 }
+                }
             }
         }
     };
-    switch (n_dma) {
-        case 0: k_loop(std::integral_constant<int, 0>()); break;
-        case 1: k_loop(std::integral_constant<int, 1>()); break;
-        case 2: k_loop(std::integral_constant<int, 2>()); break;
-        case 3: k_loop(std::integral_constant<int, 3>()); break;
-        default: k_loop(std::integral_constant<int, 4>()); break;
+    typedef std::integral_constant<bool, false> Rows;
+    typedef std::integral_constant<bool, P::IS_BF16> Units;
+    if (job.a_units) {      // A = a whole 256-row tile (two pieces per wave), B = the 64 encoding rows (two pieces on waves 0 and 1)
+        if (n_dma == 4) k_loop(std::integral_constant<int, 4>(), Units()); else k_loop(std::integral_constant<int, 2>(), Units());
+    } else switch (n_dma) {
+        case 0: k_loop(std::integral_constant<int, 0>(), Rows()); break;
+        case 1: k_loop(std::integral_constant<int, 1>(), Rows()); break;
+        case 2: k_loop(std::integral_constant<int, 2>(), Rows()); break;
+        case 3: k_loop(std::integral_constant<int, 3>(), Rows()); break;
+        default: k_loop(std::integral_constant<int, 4>(), Rows()); break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail prefetches before the LDS is released
 
