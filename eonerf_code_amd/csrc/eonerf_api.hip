@@ -246,21 +246,19 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
 
 // trunk layers 7..1 of one pass: dX chain + weight gradients, layer-pipelined (eonerf_bwd_pipe.hip).  Reads dY_7 from w.pipe.dy_in
 // (written by the heads part of the backward chain), accumulates dW / db of the trunk into d_flat, saves dY_5 / dY_0 in b.grd.
-// The error word ([1] of the sync block) is only cleared by the FIRST launch of a backward call (clear_error) so that a watchdog
+// The error word ([0] of the sync block) is only cleared by the FIRST launch of a backward call (clear_error) so that a watchdog
 // raised in either pass survives until eonerf_render_status reads it.
 int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, bool clear_error = true) {
     const ParamLayout& pl = ctx->pl;
+    // sync block: [0] error word | [32] role counter | [64..] scratch lines, edge flags -- one memset either way
     if (clear_error) HIP_TRY(hipMemsetAsync(w.pipe.sync, 0, w.pipe.sync_bytes, st));
-    else {
-        HIP_TRY(hipMemsetAsync(w.pipe.sync, 0, sizeof(uint32_t), st));                                            // role counter
-        HIP_TRY(hipMemsetAsync(w.pipe.sync + 64, 0, w.pipe.sync_bytes - 64 * sizeof(uint32_t), st));               // scratch lines + edge flags
-    }
+    else HIP_TRY(hipMemsetAsync(w.pipe.sync + 32, 0, w.pipe.sync_bytes - 32 * sizeof(uint32_t), st));
     ProfScope ps(ctx, prof_id, st);
     BwdPipeArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.n_pts = b.n_pts; pa.p_pad = p_cap; pa.n_pipes = ctx->n_pipes;
     pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in; pa.act = b.act; pa.masks = b.masks; pa.grd = b.grd;
-    pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(w.pipe.sync); pa.error = reinterpret_cast<int*>(w.pipe.sync) + 1;
+    pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(w.pipe.sync) + 32; pa.error = reinterpret_cast<int*>(w.pipe.sync);
     pa.scratch_word = w.pipe.sync + 64; pa.flags = w.pipe.sync + 64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32;
     pa.d_flat = d_flat; pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
     for (int s = 0; s < PIPE_STAGES; ++s) {
@@ -907,7 +905,7 @@ int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* ws, size_
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     if (!w.pipe.sync) return EONERF_OK;
     int err = 0;
-    HIP_TRY(hipMemcpyAsync(&err, w.pipe.sync + 1, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(&err, w.pipe.sync, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return err ? EONERF_E_DEVICE : EONERF_OK;
 }

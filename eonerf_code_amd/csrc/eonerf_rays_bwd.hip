@@ -149,15 +149,18 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
 constexpr int AMB_STREAMS = 4;
 __global__ __launch_bounds__(128 * AMB_STREAMS) void k_ambient_bwd(AmbientBwdArgs a) {
     __shared__ float red[AMB_STREAMS - 1][128][32];
-    const int j = threadIdx.x & 127, q = threadIdx.x >> 7;
+    // q is wave-uniform (two waves per stream): through readfirstlane the per-ray record, gradient and sun encoding become scalar loads
+    const int j = threadIdx.x & 127, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
     float dw1[27], dw2[3] = {0.f, 0.f, 0.f}, db1 = 0.f, db2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 27; ++i) dw1[i] = 0.f;
     const float w2[3] = {a.w.w2[j], a.w.w2[128 + j], a.w.w2[256 + j]};
+    // (no early exit for rays outside the graph -- s == 1, all three gradients zero: they add exact zeros -- so that the loop
+    //  unrolls and the loads of four rays are in flight at once: the loop is a chain of dependent global loads otherwise)
+#pragma unroll 4
     for (int ray = blockIdx.x * AMB_STREAMS + q; ray < a.n_rays; ray += gridDim.x * AMB_STREAMS) {
         const float* rec = a.ray_rec + (size_t)ray * RAY_REC;
         const float* g = a.g_ray + (size_t)ray * RAY_REC;
-        if (g[RR_AMB] == 0.f && g[RR_AMB + 1] == 0.f && g[RR_AMB + 2] == 0.f) continue;      // outside the graph (s == 1)
         const float* sv = a.amb_save + (size_t)ray * 160;       // sun encoding and hidden activations saved by the forward
         const float hid = sv[32 + j];
         float gpre[3], ghid = 0.f;
@@ -320,21 +323,30 @@ __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
         for (int i = threadIdx.x; i < a.lds_images * 4; i += 256) s_de[i] = 0.f;
         __syncthreads();
     }
-    for (int k8 = 0; k8 < 8; ++k8) {                    // 32 rays per block
-        const int rr = ray + 4 * k8;
-        if (rr >= a.n_rays) break;
-        const int off = a.offsets[rr], n = a.counts[rr];
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // 32 rays per block, 8 per wave.  Two passes without early exits, so that the eight (offset, count) loads and then the sixteen
+    // gradient loads of a wave are in flight together (one dependent chain per ray otherwise)
+    int off8[8], n8[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+        const int rr = ray + 4 * k8, rc = rr < a.n_rays ? rr : a.n_rays - 1;
+        off8[k8] = a.offsets[rc];
+        n8[k8] = rr < a.n_rays ? a.counts[rc] : 0;
+    }
+    f32x4 v8[8][2];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = lane + 64 * k;
-            if (i < n) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a.g_emb + 4 * (size_t)(off + i));
-                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
-            }
+            v8[k8][k] = i < n8[k8] ? *reinterpret_cast<const f32x4*>(a.g_emb + 4 * (size_t)(off8[k8] + i)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = wave_sum(acc[e]);
+    for (int k8 = 0; k8 < 8; ++k8) {
+        const int rr = ray + 4 * k8;
+        if (rr >= a.n_rays) break;
+        float acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = wave_sum(v8[k8][0][e] + v8[k8][1][e]);
         if (lane < 4) {
             const float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
             if (a.d_emb_rays) a.d_emb_rays[(size_t)rr * 4 + lane] = v;
