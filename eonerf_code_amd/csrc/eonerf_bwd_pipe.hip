@@ -20,7 +20,7 @@
 //     two operands through transposed LDS reads (WgradJob::a_units), eonerf_ig_tail.hip takes them as B units as they are.
 // Hand-off protocol (placement independent, cdna guide G16 / R1): payload stores sc1, every storing wave's stores are known
 // complete through the counted vmcnt of a LATER step's barrier, then ONE lane stores the edge's `head` counter (agent scope);
-// the consumer's control wave polls `head` (sc1 loads, two steps ahead of use) and loads the payload with sc1 LDS-DMA; it
+// the consumer's control wave polls `head` (sc1 loads, one step ahead of use) and loads the payload with sc1 LDS-DMA; it
 // returns ring slots through the edge's `tail` counter the same way.  Every spin is bounded by a wall-clock watchdog
 // (s_memrealtime): on expiry the stage raises *error, tells its workgroup through LDS and leaves -- the launch always drains.
 // Residency: grid = 7 x pipelines <= CU count, one workgroup per CU (LDS), roles taken from an arrival counter, so every pipeline
@@ -60,6 +60,9 @@ template <bool CTRL, bool ORDB> struct Cnt {
     // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s.
     // First order: the pieces of step s-2 and all of step s-1 are younger than those stores; second order: only step s-1
     static constexpr int TOP = ORDB ? C : N_DMA + C;
+    // control wave (first order): tighter -- only the payload stores and the pieces of step s-1 stay outstanding, so the flag polls
+    // of step s-1 are in (one step of latency instead of two: every stage then runs one step closer behind its producer)
+    static constexpr int TOP_CTRL = NST + N_DMA;
 };
 
 struct Stage {
@@ -203,9 +206,18 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     for (int k = 0; k < n_k; ++k) {
         uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
         // ---- top of the step ----
+        const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTRL ? Cnt<CTRL, ORDB>::TOP_CTRL : Cnt<CTRL, ORDB>::TOP) : "memory");
+        const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         if (CTRL) {
-            // flag values polled two steps ago have landed behind the counted wait below; before it, make sure (slow path only
-            // when the pipeline is starved or backed up) that what this step needs exists
+            // the flag values polled in the previous step have landed behind the counted wait
+            asm volatile("" : "+v"(ph), "+v"(pt));
+            if (k >= 1) {
+                const int vh = __builtin_amdgcn_readfirstlane((int)ph), vt = __builtin_amdgcn_readfirstlane((int)pt);
+                if (S.has_in && vh > known_head) known_head = vh;
+                if (RING_OUT && vt > known_tail) known_tail = vt;
+            }
+            // make sure (slow path only when the pipeline is starved or backed up) that what this step needs exists
             const int need_in = (k + DEPTH < n_k ? k + DEPTH : n_k - 1) + 1;       // tiles that must be published for this step's DMA
             const int need_out = k + 1 - PIPE_RING;                                 // tiles the consumer must have released
             const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
@@ -213,17 +225,6 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             if (S.has_in && known_head < need_in) wait_for(f_in, need_in, known_head);
             if (RING_OUT && known_tail < need_out) wait_for(f_out + 32, need_out, known_tail);
             if (stamp && slow) { t_slow += __builtin_amdgcn_s_memtime() - ts0; ++n_slow; }
-        }
-        const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cnt<CTRL, ORDB>::TOP) : "memory");
-        const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        if (CTRL) {      // the polls of step k-2 are older than anything the wait above left outstanding
-            asm volatile("" : "+v"(ph), "+v"(pt));
-            if (k >= 2) {
-                const int vh = __builtin_amdgcn_readfirstlane((int)ph), vt = __builtin_amdgcn_readfirstlane((int)pt);
-                if (S.has_in && vh > known_head) known_head = vh;
-                if (RING_OUT && vt > known_tail) known_tail = vt;
-            }
         }
         asm volatile("s_barrier" ::: "memory");
         const unsigned long long tt2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
