@@ -41,7 +41,11 @@ constexpr int NT = 512;
 constexpr int TS = PIPE_TS;                       // samples per step
 constexpr int IMG_B = 16 * 1024;                  // one step of a 256-feature tensor (bf16)
 constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
-constexpr int NSLOT = 4, DEPTH = NSLOT - 1;
+#ifndef EO_PIPE_DEPTH
+#define EO_PIPE_DEPTH 3
+#endif
+constexpr int NSLOT = 4, DEPTH = EO_PIPE_DEPTH;      // LDS ring slots; steps of DMA in flight ahead of the one being multiplied (<= NSLOT - 1)
+static_assert(DEPTH >= 2 && DEPTH <= NSLOT - 1, "prefetch distance");
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
 constexpr int CTRL_B = 64;
 constexpr int SMEM_B = NSLOT * SLOT_B + CTRL_B;
@@ -59,7 +63,9 @@ template <bool CTRL, bool ORDB> struct Cnt {
     static constexpr int C = (CTRL ? 4 : 0) + NST + N_DMA;
     // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s.
     // First order: the pieces of step s-2 and all of step s-1 are younger than those stores; second order: only step s-1
-    static constexpr int TOP = ORDB ? C : N_DMA + C;
+    // (first order, DMA side: the pieces of step s were issued DEPTH steps ago behind that step's stores, so DEPTH - 1 whole steps are
+    //  younger; the stricter of the two conditions counts)
+    static constexpr int TOP = ORDB ? C : ((DEPTH - 1) * C < N_DMA + C ? (DEPTH - 1) * C : N_DMA + C);
     // control wave (first order): tighter -- only the payload stores and the pieces of step s-1 stay outstanding, so the flag polls
     // of step s-1 are in (one step of latency instead of two: every stage then runs one step closer behind its producer)
     static constexpr int TOP_CTRL = NST + N_DMA;
