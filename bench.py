@@ -215,10 +215,13 @@ def main():
                 # GEMM: layer 0 and the skip columns of layer 5 (2 x (256 + 64)), sigma (32 + 256), bottleneck factors and head jobs
                 rows_g = 256 + 192 + (0 if wl == "rgb" else 544)
                 rows_pipe = 256 + 7 * 256 + 2 * 256
-                rows_rd = 2 * 320 + 288 + 384 + 384 + 160 + (0 if wl == "rgb" else 384 + 384 + 132 + 3 * 256 + 2 * 160)
+                # (rows actually fetched: layer 0 and skip columns 2 x (256 + 64), sigma 1 + 256, a2 3 + 128; rgb: bottleneck factor and
+                #  albedo layer 1 (128 + 256 each); full: dY A1 | dY T1 share one block, so [M_a; M_t] and the two first head layers are
+                #  one 256 + 256 job each, + embedding columns 128 + 4, T2..T4 3 x 256, the two one-row heads 2 + 128)
+                rows_rd = 2 * 320 + 257 + 131 + (2 * 384 if wl == "rgb" else 2 * 512 + 132 + 3 * 256 + 130)
             bytes_of = {"fwd_chain_camera": (rows_w * elt + masks * 32) * n_cam, "bwd_chain_camera": (rows_g * elt + masks * 32) * n_cam,
                         "bwd_pipe_camera": (rows_pipe * elt if piped else 0) * n_cam,
-                        "wgrad_gemm": rows_rd * elt * n_cam + (2305 + 2176) * elt * n_sun,
+                        "wgrad_gemm": rows_rd * elt * n_cam + ((2 * 320 + 257) if piped else (2305 + 2176)) * elt * n_sun,
                         "fwd_chain_sun": (2112 * elt + 8 * 32) * n_sun, "bwd_chain_sun": ((2048 + 1) * elt + 8 * 32) * n_sun}
             for name, flop in flop_of.items():
                 ms, cnt = prof[name]
