@@ -115,3 +115,39 @@ def test_adam_late_parameters_follow_torch_adam_with_none_grads():
     got = flat.detach().cpu()
     assert (got[main] - p_main.detach()).abs().max().item() < 1e-6
     assert (got[late] - p_late.detach()).abs().max().item() < 1e-6
+
+
+def test_without_radiometric_normalization_matches_the_oracle():
+    """radiometric_normalization=False is the reference's constructor default (radiance_fields/eonerf.py:70-77, train_eonerf.py:60-61):
+    no radiometricT_enc parameter, rgb is not passed through the per-image affine map (eonerf.py:239-245).  Forward at the 1e-4 bar
+    and one optimisation step against torch autograd on the oracle, fp32 mode."""
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    from eonerf_code_amd.sat_rendering import render_image
+    from eonerf_code_amd.datasets.satellite import define_satrays_from_tensors
+    from eonerf_code_amd.trainer import FusedTrainer
+    step = 2.0 / 128
+    sd = orc.random_state_dict(N_IMG, seed=23, bias_scale=0.05)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    del sd["radiometricT_enc.weight"]
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R, N_IMG, seed=24)
+    with torch.no_grad():
+        ref, n_ref = orc.render_rays(orc.Field(sd), orc.define_satrays_from_tensors(rays, ts), u_cam, u_sun, 3, step)
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ref_loss, _ = orc.train_step(sdg, rays, ts, rgbs, u_cam, u_sun, 3, step)
+    f = EONerfMLP(N_IMG, precision="fp32")                       # default: radiometric_normalization=False
+    assert "radiometricT_enc.weight" not in f.state_dict()
+    f.load_state_dict(sd, strict=True)
+    f = f.cuda()
+    with torch.no_grad():
+        res, n = render_image(f, None, define_satrays_from_tensors(rays.cuda(), ts.cuda()), None, None, epoch_idx=3, chunk=4096,
+                              render_step_size=step, noise=[(u_cam, None, u_sun)])
+    assert n == n_ref
+    assert (res["rgb"].cpu() - ref[:, 0:3]).abs().max().item() < 1e-4
+    assert (res["depth"].cpu() - ref[:, 3:4]).abs().max().item() < 1e-4
+    tr = FusedTrainer(f, lr=5e-4, max_rays=R)
+    loss = float(tr.step(rays.cuda(), ts.reshape(-1).cuda(), rgbs.cuda(), 3, noise=(u_cam.cuda(), None, u_sun.cuda())))
+    assert abs(loss - float(ref_loss)) < 1e-4 * max(1.0, abs(float(ref_loss)))
+    for (name, p), g in zip(f.named_parameters(), f.grad_views(tr.d_flat)):
+        rg = sdg[name].grad
+        if rg is not None and rg.norm() > 0:
+            assert ((g.cpu() - rg).norm() / rg.norm()).item() < 5e-3, name
