@@ -41,6 +41,13 @@ constexpr int NT = 512;
 constexpr int TS = PIPE_TS;                       // samples per step
 constexpr int IMG_B = 16 * 1024;                  // one step of a 256-feature tensor (bf16)
 constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
+// EO_PIPE_DW16 = 1: the weight-gradient product runs on v_mfma_f32_16x16x32_bf16 (one K step = the 32 samples of a pipeline step; the
+// wave's 32 x 256 block = 2 x 16 tiles of 16 x 16), 0 (default): on v_mfma_f32_32x32x16_bf16 like the dX product.  Same MFMA cycles and
+// LDS bytes; measured on the same box (parity green): 1.4 % fewer cycles per step, 1 % MORE wall time for the kernel (0.848 vs 0.839 ms)
+// -- the higher sustained clock the guide reports for the 16x16x32 shape in MFMA-bound loops does not show in this 50 %-busy loop.
+#ifndef EO_PIPE_DW16
+#define EO_PIPE_DW16 0
+#endif
 #ifndef EO_PIPE_DEPTH
 #define EO_PIPE_DEPTH 3
 #endif
@@ -99,10 +106,19 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         // inside the loop and puts its own (stricter) vmcnt in front of the first MFMAs of every step
         __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
     }
+#if EO_PIPE_DW16
+    f32x4 dw[2][16];       // [m-subtile of 16 rows][n-subtile of 16 columns]: row 4 (lane >> 4) + reg, column lane & 15
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < 16; ++ns) dw[ms][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db[2] = {0.f, 0.f};
+#else
     f32x16 dw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) dw[j] = zero_acc();
     float db = 0.f;
+#endif
 
     // ---- sources ----
     const size_t n_tiles = (size_t)a.p_pad / TS;                       // sample tiles of the slabs
@@ -162,6 +178,14 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     const int tr_off = (2 * wave + (g4 & 1)) * 1024 + ((pp & 1) * 32 + 8 * (g4 >> 1) + qq) * 16 + (pp >> 1) * 8;     // + 64 t + 256 ks
     // B fragments of the dW product: row 32j + c of the X image, 16-byte chunk 2ks + h
     const int xb_off0 = IMG_B + c * SEG_B + wg_swz16(c, h), xb_off1 = IMG_B + c * SEG_B + wg_swz16(c, 2 + h);        // + 2048 j
+#if EO_PIPE_DW16
+    // 16x16x32 operands.  A (lane = feature row lane & 15 of the m-subtile, K chunk lane >> 4 = samples 8 g4 .. 8 g4 + 7): two transposed
+    // reads (4 samples each) of unit 2 wave + ms; lane 4 qq + pp of the group supplies sample 8 g4 + qq (+ 4), features 4 pp .. 4 pp + 3
+    // of the unit = lane half pp & 1, elements 4 (pp >> 1) ..  B (lane = feature row lane & 15 of the n-subtile, same K chunk): one
+    // 16-byte chunk g4 of row 16 ns + (lane & 15) of the X image; the swizzle class (row >> 2) & 3 does not depend on ns
+    const int tr16_off = (2 * wave) * 1024 + ((pp & 1) * 32 + 8 * g4 + qq) * 16 + (pp >> 1) * 8;           // + 1024 ms, + 64 for samples + 4
+    const int xb16_off = IMG_B + i16 * SEG_B + wg_swz16(i16, g4);                                           // + 1024 ns
+#endif
     // ReLU' of layer - 1 = (X_layer > 0) on the bf16 values the forward saved (the same predicate its mask bits record): this
     // lane's 16 (feature, sample) pairs of the dX accumulator come out of the X image through 4 transposed reads -- 16-lane group
     // g4 = samples 16 (g4 & 1) .., half h = g4 >> 1; read q covers rows 32 wave + 8q + 4h .. +3 (one swizzle class per read)
@@ -307,7 +331,43 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 }
             }
         };
-        auto phase_dw = [&]() {        // dW += dY X^T (2 K steps of 16 samples x 8 column tiles), db += row sums
+        auto phase_dw = [&]() {        // dW += dY X^T over the 32 samples of the step, db += row sums
+#if EO_PIPE_DW16
+            // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
+            // LDS-DMA in flight and drains it)
+            u32x2 ta[2][2];
+            const uint32_t ra = (uint32_t)(uintptr_t)(slot + tr16_off);
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                         "ds_read_b64_tr_b16 %1, %4 offset:64\n\t"
+                         "ds_read_b64_tr_b16 %2, %4 offset:1024\n\t"
+                         "ds_read_b64_tr_b16 %3, %4 offset:1088\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]) : "v"(ra) : "memory");
+            const U af0 = __builtin_bit_cast(U, u32x4{ta[0][0][0], ta[0][0][1], ta[0][1][0], ta[0][1][1]});
+            const U af1 = __builtin_bit_cast(U, u32x4{ta[1][0][0], ta[1][0][1], ta[1][1][0], ta[1][1][1]});
+            const uint8_t* xb = slot + xb16_off;
+            U bf[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) bf[d] = lds_unit<P>(xb + d * 1024);
+#pragma unroll
+            for (int ns = 0; ns < 16; ++ns) {
+                if (!(EO_PABL & 1)) {
+                    dw[0][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf[ns % 3], dw[0][ns], 0, 0, 0);
+                    dw[1][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf[ns % 3], dw[1][ns], 0, 0, 0);
+                }
+                if (!(EO_PABL & 4) && ns + 3 < 16) bf[ns % 3] = lds_unit<P>(xb + (ns + 3) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // bias gradient: this lane's 8 samples of features 32 wave + 16 ms + (lane & 15)
+            if (!(EO_PABL & 32)) {
+                const u32x4 a0 = __builtin_bit_cast(u32x4, af0), a1 = __builtin_bit_cast(u32x4, af1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    db[0] += __uint_as_float(a0[e] << 16) + __uint_as_float(a0[e] & 0xffff0000u);
+                    db[1] += __uint_as_float(a1[e] << 16) + __uint_as_float(a1[e] & 0xffff0000u);
+                }
+            }
+#else
             // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
             // LDS-DMA in flight and drains it)
             u32x2 ta[2][2];
@@ -336,6 +396,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (!(EO_PABL & 32)) db += __uint_as_float(av[e] << 16) + __uint_as_float(av[e] & 0xffff0000u);
             }
+#endif
         };
         const int k_next = k + DEPTH < n_k ? k + DEPTH : n_k - 1;       // refill: into the slot step k-1 used (free behind this step's barrier)
         if (!ORDB) {
@@ -366,6 +427,35 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 
     // ---- flush the stationary gradients: fp32 atomics (one partial per pipeline and element), or, in deterministic mode, plain
     //      stores of this workgroup's partial, summed in pipeline order by k_pipe_reduce ----
+#if EO_PIPE_DW16
+    // element (row 32 wave + 16 ms + 4 g4 + reg, column 16 ns + i16) = dw[ms][ns][reg]; the bias sums of a feature sit in the four lanes
+    // i16, i16 + 16, i16 + 32, i16 + 48 (one K chunk each)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) { db[ms] += __shfl_xor(db[ms], 16, 64); db[ms] += __shfl_xor(db[ms], 32, 64); }
+    if (a.partials) {
+        float* pt = a.partials + (size_t)(S.pipe * PIPE_STAGES + S.st) * (256 * 256 + 256);
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < 16; ++ns)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pt[(32 * wave + 16 * ms + 4 * g4 + g) * 256 + 16 * ns + i16] = dw[ms][ns][g];
+        if (g4 == 0) { pt[256 * 256 + 32 * wave + i16] = db[0]; pt[256 * 256 + 32 * wave + 16 + i16] = db[1]; }
+        return;
+    }
+    float* dwp = a.d_flat + a.dw_off[S.st];
+    const int ld = a.dw_ld[S.st];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < 16; ++ns)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) atomicAdd(dwp + (size_t)(32 * wave + 16 * ms + 4 * g4 + g) * ld + 16 * ns + i16, dw[ms][ns][g]);
+    if (g4 == 0) {
+        atomicAdd(a.d_flat + a.db_off[S.st] + 32 * wave + i16, db[0]);
+        atomicAdd(a.d_flat + a.db_off[S.st] + 32 * wave + 16 + i16, db[1]);
+    }
+#else
     db += __shfl_xor(db, 32, 64);
     if (a.partials) {
         float* pt = a.partials + (size_t)(S.pipe * PIPE_STAGES + S.st) * (256 * 256 + 256);
@@ -383,6 +473,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #pragma unroll
         for (int g = 0; g < 16; ++g) atomicAdd(dwp + (size_t)(32 * wave + acc_row(g, h)) * ld + 32 * j + c, dw[j][g]);
     if (h == 0) atomicAdd(a.d_flat + a.db_off[S.st] + 32 * wave + c, db);
+#endif
 }
 
 __global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
