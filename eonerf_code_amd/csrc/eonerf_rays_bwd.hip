@@ -1,5 +1,6 @@
 // Backward of the per-ray kernels (H10 of SURVEY.md 8a: autograd of sat_rendering.py:264-306 and of the nerfacc
 // compositing calls at radiance_fields/eonerf.py:229-243, sat_rendering.py:106-116), plus the fused Adam update.
+#include <stdlib.h>
 #include "eonerf_common.h"
 #include "eonerf_rays.h"
 #include "eonerf_rays_dev.h"
@@ -143,41 +144,72 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
     }
 }
 
-// ---- ambient head backward (radiance_fields/eonerf.py:132-139): thread = (hidden unit j, ray stream q); the block's rays
-//      are dealt to AMB_STREAMS streams, whose partial sums meet in LDS before ONE set of atomics per block (256 blocks
-//      each adding into the same 3.9k addresses took 125 us: same-address atomics serialise) ----
-constexpr int AMB_STREAMS = 4;
+// ---- ambient head backward (radiance_fields/eonerf.py:132-139): thread = (hidden unit j, ray stream q).  A block owns a contiguous
+//      range of rays and walks it in batches of AMB_BATCH: the batch's records (sun encoding + hidden activations saved by the
+//      forward, output and its gradient) are staged in LDS by ONE coalesced pass of the whole block, then every stream takes
+//      every AMB_STREAMS-th ray of the batch out of LDS (per-ray global loads made the loop a chain of dependent L2 round trips:
+//      0.67 us per ray and thread; from LDS 0.11 us, which is the loop's VALU / LDS instruction time on the few CUs in use).
+//      The streams' partial sums meet in LDS before ONE set of atomics per block (every block adds into the same 3.9k addresses:
+//      ~0.7 us per block, hence few blocks) ----
+constexpr int AMB_STREAMS = 4, AMB_BATCH = 64, AMB_REC = 168;       // per staged ray: 160 saved floats, 3 outputs, 3 gradients, pad
 __global__ __launch_bounds__(128 * AMB_STREAMS) void k_ambient_bwd(AmbientBwdArgs a) {
-    __shared__ float red[AMB_STREAMS - 1][128][32];
-    // q is wave-uniform (two waves per stream): through readfirstlane the per-ray record, gradient and sun encoding become scalar loads
-    const int j = threadIdx.x & 127, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+    __shared__ __attribute__((aligned(16))) float lds[AMB_BATCH * AMB_REC > (AMB_STREAMS - 1) * 128 * 32 ? AMB_BATCH * AMB_REC : (AMB_STREAMS - 1) * 128 * 32];
+    const int j = threadIdx.x & 127, q = threadIdx.x >> 7;
     float dw1[27], dw2[3] = {0.f, 0.f, 0.f}, db1 = 0.f, db2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 27; ++i) dw1[i] = 0.f;
     const float w2[3] = {a.w.w2[j], a.w.w2[128 + j], a.w.w2[256 + j]};
-    // (no early exit for rays outside the graph -- s == 1, all three gradients zero: they add exact zeros -- so that the loop
-    //  unrolls and the loads of four rays are in flight at once: the loop is a chain of dependent global loads otherwise)
-#pragma unroll 4
-    for (int ray = blockIdx.x * AMB_STREAMS + q; ray < a.n_rays; ray += gridDim.x * AMB_STREAMS) {
-        const float* rec = a.ray_rec + (size_t)ray * RAY_REC;
-        const float* g = a.g_ray + (size_t)ray * RAY_REC;
-        const float* sv = a.amb_save + (size_t)ray * 160;       // sun encoding and hidden activations saved by the forward
-        const float hid = sv[32 + j];
-        float gpre[3], ghid = 0.f;
+    const int per = (a.n_rays + gridDim.x - 1) / gridDim.x;
+    const int r_lo = blockIdx.x * per, r_hi = r_lo + per < a.n_rays ? r_lo + per : a.n_rays;
+    // software pipeline: the loads of batch b + 1 (20 + 1 per thread) are in flight while batch b is consumed out of LDS -- one batch
+    // at a time would expose a full memory round trip (~2-3 us with so few workgroups on the chip) per 64 rays
+    constexpr int NT = 128 * AMB_STREAMS, NL = AMB_BATCH * 160 / NT;
+    static_assert(AMB_BATCH * 160 % NT == 0 && AMB_BATCH * 6 <= NT, "staging loop shape");
+    float v[NL], v6 = 0.f;
+    const int r6 = threadIdx.x / 6, k6 = threadIdx.x - 6 * r6;
+    auto fetch = [&](int b0) {
+        const int nb = r_hi - b0 < AMB_BATCH ? r_hi - b0 : AMB_BATCH;
+        const float* src = a.amb_save + (size_t)b0 * 160;           // the batch's saved records are one contiguous run
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const float out = rec[RR_AMB + o];
-            gpre[o] = g[RR_AMB + o] * out * (1.f - out);
-            dw2[o] += gpre[o] * hid;
-            db2[o] += gpre[o];
-            ghid += w2[o] * gpre[o];
+        for (int u = 0; u < NL; ++u) { const int i = threadIdx.x + u * NT; v[u] = i < nb * 160 ? src[i] : 0.f; }
+        v6 = 0.f;
+        if (r6 < nb) v6 = k6 < 3 ? a.ray_rec[(size_t)(b0 + r6) * RAY_REC + RR_AMB + k6] : a.g_ray[(size_t)(b0 + r6) * RAY_REC + RR_AMB + k6 - 3];
+    };
+    if (r_lo < r_hi) fetch(r_lo);
+    for (int b0 = r_lo; b0 < r_hi; b0 += AMB_BATCH) {
+        const int nb = r_hi - b0 < AMB_BATCH ? r_hi - b0 : AMB_BATCH;
+        __syncthreads();                                    // the previous batch is consumed
+#pragma unroll
+        for (int u = 0; u < NL; ++u) { const int i = threadIdx.x + u * NT, r = i / 160; lds[r * AMB_REC + (i - 160 * r)] = v[u]; }
+        if (r6 < AMB_BATCH) lds[r6 * AMB_REC + 160 + k6] = v6;
+        __syncthreads();
+        if (b0 + AMB_BATCH < r_hi) fetch(b0 + AMB_BATCH);
+        for (int r = q; r < nb; r += AMB_STREAMS) {        // rays outside the graph (s == 1: all three gradients zero) add exact zeros
+            const float* sv = lds + r * AMB_REC;
+            const float hid = sv[32 + j];
+            // the ray's shared values as 16-byte broadcast reads
+            f32x4 e4[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) e4[i] = *reinterpret_cast<const f32x4*>(sv + 4 * i);
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(sv + 160), o1 = *reinterpret_cast<const f32x4*>(sv + 164);
+            const float outv[3] = {o0[0], o0[1], o0[2]}, gv[3] = {o0[3], o1[0], o1[1]};
+            float gpre[3], ghid = 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                gpre[o] = gv[o] * outv[o] * (1.f - outv[o]);
+                dw2[o] += gpre[o] * hid;
+                db2[o] += gpre[o];
+                ghid += w2[o] * gpre[o];
+            }
+            if (hid <= 0.f) ghid = 0.f;
+            db1 += ghid;
+#pragma unroll
+            for (int i = 0; i < 27; ++i) dw1[i] += ghid * e4[i >> 2][i & 3];
         }
-        if (hid <= 0.f) ghid = 0.f;
-        db1 += ghid;
-#pragma unroll
-        for (int i = 0; i < 27; ++i) dw1[i] += ghid * sv[i];
     }
+    __syncthreads();                                        // the staging area becomes the reduction area
     // streams 1.. hand their sums to stream 0 through LDS: slots 0..26 dw1, 27 db1, 28..30 dw2
+    float (*red)[128][32] = reinterpret_cast<float (*)[128][32]>(lds);
     if (q > 0) {
         float* r = red[q - 1][j];
 #pragma unroll
@@ -447,8 +479,11 @@ hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st, bool deterministic) {
+    static int blocks = 0;
+    if (!blocks) { const char* e = getenv("EONERF_AMB_BLOCKS"); blocks = e && atoi(e) > 0 ? atoi(e) : 32; }      // measured (4096 rays): 64 blocks 46 us, 32: 37, 16: 39, 8: 58
     // deterministic mode: ONE block -- every address is then added by exactly one thread, its rays in a fixed order
-    hipLaunchKernelGGL(k_ambient_bwd, dim3(deterministic ? 1 : (a.n_rays < 256 ? (a.n_rays + 3) / 4 : 64)), dim3(128 * AMB_STREAMS), 0, st, a);
+    const int want = deterministic ? 1 : (a.n_rays + AMB_BATCH - 1) / AMB_BATCH;
+    hipLaunchKernelGGL(k_ambient_bwd, dim3(want < blocks ? want : blocks), dim3(128 * AMB_STREAMS), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_table_reduce(const float* contrib, const int64_t* idx, int n_rays, int width, int stride, int n_rows, int eval_first,
