@@ -7,10 +7,10 @@
 //   * W_l^T (128 KB bf16) is STATIONARY in the registers of the stage (wave w owns output m-tile w: 16 A units = 64 VGPRs);
 //   * dW_l (256 x 256 fp32) is STATIONARY in registers for the whole launch (wave w owns rows 32w..32w+31: 128 VGPRs);
 //   * per step of 32 samples the stage takes dY_l from its input ring (B-operand "unit" order [k-group 16][lane 64][16 B],
-//     exactly what the producer's accumulators pack to), the layer input X_l from the activation slab (feature-major rows ARE the
-//     B fragments of the dW product) and the 1-KiB ReLU-mask record, all by LDS-DMA into a 4-slot LDS ring, 3 steps in flight;
+//     exactly what the producer's accumulators pack to) and the layer input X_l from the activation slab (feature-major rows ARE the
+//     B fragments of the dW product, and X_l > 0 is the ReLU' predicate), both by LDS-DMA into a 4-slot LDS ring, 3 steps in flight;
 //       dX = W_l^T dY_l                      16 MFMAs per wave  (A registers, B ds_read_b128 of the dY image)
-//       dY_{l-1} = dX .* relu'(mask)         packed to two 1-KiB units, stored write-through (sc1) into the output ring
+//       dY_{l-1} = dX .* (X_l > 0)           packed to two 1-KiB units, stored write-through (sc1) into the output ring
 //       dW_l += dY_l X_l^T                   16 MFMAs per wave  (A = ds_read_b64_tr_b16 of the SAME dY image, B = X image)
 //       db_l += row sums of dY_l             VALU on the A fragments
 //   * dY_6 .. dY_1 never touch HBM: the rings (16 slots x 16 KiB per edge) live in the Infinity Cache and are overwritten in place.
