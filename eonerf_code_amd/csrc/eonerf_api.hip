@@ -154,6 +154,10 @@ struct ProfScope {      // brackets one kernel launch with events when profiling
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int p_cap_of(int n_rays) { return round_up(std::max(n_rays, 1) * 127, 256); }
+// a 256-row block of a training slab ([sample tile][256 rows][64 B]) is addressed through ONE buffer descriptor with 32-bit byte offsets
+// (SlabWriter, the GEMM's and the pipeline's operand loads): p_cap / samples-per-tile x 16 KiB must stay below 4 GiB --
+// 66,051 rays (8.39 M samples) per call in bf16 mode, 33,025 in fp32 mode.  Larger batches are chunked by the caller (render_image does)
+inline bool slabs_addressable(const eonerf_ctx* ctx, size_t p_cap) { return p_cap / (ctx->bf16 ? 32 : 16) * 256 * SEG_B < (1ull << 32); }
 
 void carve_pass(Carver& c, PassBuffers& b, int n_rays, int p_cap, bool full, bool train, bool input_grad, int act_bytes) {
     b.counts = c.take<int>(n_rays);
@@ -565,7 +569,9 @@ int eonerf_field_forward_train(eonerf_ctx* ctx, const float* flat, const float* 
     if (!density_only && (!sun || !img || !albedo || !ambient || !ts || !tb)) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n == 0) return EONERF_OK;
+    if (n > (1 << 30)) return EONERF_E_UNSUPPORTED;
     const int p_cap = round_up(n, 256);
+    if (!slabs_addressable(ctx, (size_t)p_cap)) return EONERF_E_UNSUPPORTED;
     const bool full = !density_only;
     FieldTrainWs w = carve_field_train(ctx, ws, p_cap, full);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
@@ -588,7 +594,9 @@ int eonerf_field_backward(eonerf_ctx* ctx, const float* flat, const float* sun, 
     if (!density_only && g_ambient && !sun) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n == 0) return EONERF_OK;
+    if (n > (1 << 30)) return EONERF_E_UNSUPPORTED;
     const int p_cap = round_up(n, 256);
+    if (!slabs_addressable(ctx, (size_t)p_cap)) return EONERF_E_UNSUPPORTED;
     const bool full = !density_only;
     FieldTrainWs w = carve_field_train(ctx, ws, p_cap, full);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
@@ -729,6 +737,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     const bool philox = u_cam == nullptr;       // production: no noise buffers, the sampler draws its own jitter
     if (philox ? (u_retry || u_sun) : (shadows && !u_sun)) return EONERF_E_ARG;
     if (train && od) return EONERF_E_UNSUPPORTED;
+    if (n_rays > (1 << 24) || (train && !slabs_addressable(ctx, (size_t)p_cap_of(n_rays)))) return EONERF_E_UNSUPPORTED;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     const int p_cap = p_cap_of(n_rays);

@@ -113,3 +113,27 @@ def test_pipelined_path_with_empty_rays_and_an_all_empty_batch(epoch):
             grads[(pipe, tag)] = tr.d_flat.clone()
     a, b = grads[(False, "mixed")], grads[(True, "mixed")]
     assert (a - b).norm().item() <= 1e-4 * a.norm().item() + 1e-10
+
+
+def test_four_times_the_bench_batch_and_the_size_guard():
+    """16384 rays x 128 samples (2.1 M samples: the training slabs pass 12 GB, byte offsets inside them pass 2^32; every 256-row block is
+    addressed through its own descriptor): pipelined path against chain + GEMM.  Beyond 66,051 rays a 256-row block would outgrow the
+    32-bit offsets of its descriptor: the C ABI refuses (EONERF_E_UNSUPPORTED) instead of wrapping around."""
+    import ctypes as C
+    from eonerf_code_amd import _lib
+    R = 16384
+    f_old, f_new = _field(False), _field(True)
+    l0, g0, _ = _grads(f_old, R, 3)
+    torch.cuda.empty_cache()
+    l1, g1, tr = _grads(f_new, R, 3)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0) and torch.isfinite(g1).all()
+    for (name, p), a, b in zip(f_old.named_parameters(), f_old.grad_views(g0), f_new.grad_views(g1)):
+        assert (a - b).norm().item() <= 1e-4 * a.norm().item() + 1e-10, (name, (a - b).norm().item(), a.norm().item())
+    L = _lib.lib()
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    big = 70000
+    dummy = torch.zeros(16, device="cuda")
+    rc = L.eonerf_render_forward(tr.ctx, C.c_void_p(tr.flat.data_ptr()), C.c_void_p(dummy.data_ptr()), C.c_void_p(dummy.data_ptr()),
+                                 C.c_void_p(tr.zsteps.data_ptr()), None, None, None, big, _lib.F_TRAIN | _lib.F_RGB_LOSS,
+                                 C.c_void_p(dummy.data_ptr()), None, C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), None)
+    assert rc == -4, rc                                   # EONERF_E_UNSUPPORTED, before anything is launched
