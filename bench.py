@@ -122,8 +122,8 @@ def cpu_baseline(workloads, n_rays=1024, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=("both", "rgb", "full"), default="both",
                     help="both: the metric's configuration (rgb) as the headline + the full EO-NeRF configuration under \"full\"")
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
