@@ -136,11 +136,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # rehearsal of the N > 1 path on a one-GPU box (not a measurement): EONERF_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses the
+    # gloo backend; run it with EONERF_PIPE=0 (the pipelined backward assumes the card to itself)
+    rehearsal = os.environ.get("EONERF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from eonerf_code_amd.synthetic import synthetic_batch
     from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
