@@ -2,7 +2,6 @@
 // streams, workspace carving and kernel sequencing.  No device memory is allocated after eonerf_create.
 #include <hip/hip_runtime.h>
 #include <string.h>
-#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -350,7 +349,10 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         WgradJob& j = tab.j[k];
         // ... but never fewer than ~4 items per CU in the launch: with the trunk's 256 x 256 products gone to the pipelined backward only
         // 6-9 jobs are left, and 48 slices each would leave most CUs with one item and a few with two
-        const int fill = (4 * ctx->n_cu + tab.n - 1) / tab.n;
+        // Few jobs (the rgb state: 6): exactly two rounds -- just UNDER 2 items per CU, so that no workgroup starts a third item
+        // (scripts/wgrad_items_sweep.sh: 0.33-0.35 ms at 504-512 items against 0.39 at ~1,024 and 0.36-0.37 at 448 / 640)
+        int fill = (4 * ctx->n_cu + tab.n - 1) / tab.n;
+        if (tab.n <= 8) fill = 2 * ctx->n_cu / tab.n;
         int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : (fill > 48 ? (fill > 256 ? 256 : fill) : 48);
         if (det_partials && sl > 48) sl = 48;       // the partial buffer holds WGRAD_MAX_JOBS x 48 items
         j.slices = sl < 1 ? 1 : sl;
