@@ -334,9 +334,16 @@ __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
     if (j < 128) s_w[j] = a.w_a1[j * 256 + i];
     else s_w[j] = a.w_t1 ? a.w_t1[(j - 128) * 260 + i] : 0.f;
     __syncthreads();
-    for (int k = 0; k < 128; ++k) acc += s_w[k] * a.m_a[k * 256 + j];
-    if (a.w_t1)
-        for (int k = 0; k < 128; ++k) acc += s_w[128 + k] * a.m_t[k * 256 + j];
+    // (unrolled: the 128 loads of a column are independent, 32 of them in flight instead of the few the compiler keeps by itself;
+    //  four partial sums keep the adds off one dependency chain)
+    float p4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 32
+    for (int k = 0; k < 128; ++k) p4[k & 3] += s_w[k] * a.m_a[k * 256 + j];
+    if (a.w_t1) {
+#pragma unroll 32
+        for (int k = 0; k < 128; ++k) p4[k & 3] += s_w[128 + k] * a.m_t[k * 256 + j];
+    }
+    acc = (p4[0] + p4[1]) + (p4[2] + p4[3]);
     a.d_w[i * 256 + j] += acc;                      // the only writer of this block of the gradient buffer
     if (j == 0) {
         for (int k = 0; k < 128; ++k) accb += s_w[k] * a.db_a1[k];
