@@ -62,6 +62,7 @@ struct RenderWs {
     int *cnt_first, *cnt_retry, *flags;
     float* ray_rec; float* g_ray; float* amb_save;
     float* m_bott;        // [2][128][256] fp32: dA1^T X8 and dT1^T X8 (factors of the bottleneck weight gradient)
+    int* queue;           // work-item counter of the weight-gradient GEMM (behind m_bott)
     PassBuffers cam, sun;
     size_t bytes;
 };
@@ -195,13 +196,16 @@ RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) 
     w.ray_rec = c.take<float>((size_t)n_rays * RAY_REC);
     w.g_ray = train ? c.take<float>((size_t)n_rays * RAY_REC) : nullptr;
     w.amb_save = train ? c.take<float>((size_t)n_rays * 160) : nullptr;
-    w.m_bott = train ? c.take<float>(2 * 128 * 256) : nullptr;
+    // [bottleneck factors | GEMM work queue] and, right behind them, the pipeline's sync block: everything the backward needs zeroed, so
+    // that the first pipeline launch of a backward call clears all of it with ONE memset
+    w.m_bott = train ? c.take<float>(2 * 128 * 256 + 64) : nullptr;
+    w.queue = train ? reinterpret_cast<int*>(w.m_bott + 2 * 128 * 256) : nullptr;
     memset(&w.pipe, 0, sizeof(w.pipe));
     if (train && ctx->pipe) {
-        w.pipe.dy_in = c.take<uint8_t>((size_t)p_cap * 512);
-        w.pipe.rings = c.take<uint8_t>((size_t)ctx->n_pipes * (PIPE_STAGES - 1) * PIPE_RING * PIPE_UNIT_B);
         w.pipe.sync_bytes = (64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32 + (size_t)ctx->n_pipes * (PIPE_STAGES - 1) * 64) * sizeof(uint32_t);
         w.pipe.sync = c.take<uint32_t>(w.pipe.sync_bytes / sizeof(uint32_t));
+        w.pipe.dy_in = c.take<uint8_t>((size_t)p_cap * 512);
+        w.pipe.rings = c.take<uint8_t>((size_t)ctx->n_pipes * (PIPE_STAGES - 1) * PIPE_RING * PIPE_UNIT_B);
     }
     memset(&w.det, 0, sizeof(w.det));
     if (train && ctx->deterministic) {
@@ -254,7 +258,11 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
 int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, bool clear_error = true) {
     const ParamLayout& pl = ctx->pl;
     // sync block: [0] error word | [32] role counter | [64..] scratch lines, edge flags -- one memset either way
-    if (clear_error) HIP_TRY(hipMemsetAsync(w.pipe.sync, 0, w.pipe.sync_bytes, st));
+    if (clear_error) {      // first pipeline launch of this backward: also the GEMM's accumulator and queue in front of the sync block
+        uint8_t* lo = reinterpret_cast<uint8_t*>(w.m_bott);
+        uint8_t* hi = reinterpret_cast<uint8_t*>(w.pipe.sync) + w.pipe.sync_bytes;
+        HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), st));
+    }
     else HIP_TRY(hipMemsetAsync(w.pipe.sync + 32, 0, w.pipe.sync_bytes - 32 * sizeof(uint32_t), st));
     ProfScope ps(ctx, prof_id, st);
     BwdPipeArgs pa;
@@ -279,7 +287,7 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
 //   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
                          const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false,
-                         bool dens_trunk_done = false, float* det_partials = nullptr) {
+                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false) {
     const ParamLayout& pl = ctx->pl;
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
@@ -321,7 +329,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         const PassBuffers& c = *full;
         trunk_jobs(c, full_trunk_done);
         // bottleneck layer: factor M_a = dA1^T X8 (and M_t = dT1^T X8), finished by eo_launch_bott_wgrad below
-        HIP_TRY(hipMemsetAsync(m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
+        if (!zeroed) HIP_TRY(hipMemsetAsync(m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
         // dY A1 and dY T1 are the two halves of one 256-row block of the gradient slab: with the transient head both factors (and both
         // first-layer gradients against the bottleneck output) are ONE job each -- every operand block is read once, not twice
         if (transient) {
@@ -359,7 +367,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         j.item0 = tab.items;
         tab.items += j.slices;
     }
-    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials)); }
+    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed)); }
     if (full) {   // bottleneck layer: dW = W_A1^T M_a (+ W_T1^T M_t) from the two factors the GEMM above accumulated
         BottWgradArgs bw;
         bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_a1 = dptr(pl.a1_b);
@@ -879,7 +887,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, 5, st, !shadows); if (rcp) return rcp; }
 
     {
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.flags + 2, st, pipe, pipe && shadows, w.det.wgrad_part);
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.queue, st, pipe, pipe && shadows, w.det.wgrad_part, pipe);
         if (rcw) return rcw;
     }
 

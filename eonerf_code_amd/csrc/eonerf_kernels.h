@@ -146,5 +146,6 @@ struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int items; };   // by 
 // partials != nullptr (deterministic mode): every work item stores its tile to partials[item] ([256][256] dW | [256] db) instead of
 // adding it atomically, and a second kernel sums the items of a job in slice order
 constexpr int WGRAD_PART_F = 256 * 256 + 256;
-hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st, float* partials = nullptr);
+hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st, float* partials = nullptr,
+                           bool zero_queue = true);
 hipError_t eo_launch_pipe_reduce(const BwdPipeArgs& a, hipStream_t st);

@@ -280,8 +280,10 @@ template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_
 
 }  // namespace
 
-hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st, float* partials) {
-    hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st);
-    if (e != hipSuccess) return e;
+hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st, float* partials, bool zero_queue) {
+    if (zero_queue) {
+        hipError_t e = hipMemsetAsync(queue, 0, sizeof(int), st);
+        if (e != hipSuccess) return e;
+    }
     return bf16 ? launch<PBf16>(jobs, n_wg, p_pad, queue, st, partials) : launch<PF32>(jobs, n_wg, p_pad, queue, st, partials);
 }
