@@ -761,7 +761,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     if (philox) { sa.seed = ctx->noise_seed; sa.call = ctx->noise_call++; }
     sa.n_rays = n_rays; sa.sun_pass = 0; sa.patch_last = 1;
     sa.cnt_first = w.cnt_first; sa.cnt_retry = w.cnt_retry; sa.counts = w.cam.counts; sa.offsets = w.cam.offsets;
-    sa.flags = w.flags; sa.n_pts = w.cam.n_pts;
+    sa.flags = w.flags; sa.n_pts = w.cam.n_pts; sa.n_pts_copy = n_samples_dev;       // the scan kernel also fills the caller's count
     sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
     HIP_TRY(eo_launch_sampler(sa, st));
     const bool rgb_loss = train && !shadows && (flags & EONERF_F_RGB_LOSS);
@@ -781,7 +781,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
         ss.img_idx = nullptr; ss.u = u_sun; ss.u_retry = nullptr; ss.retry = 0;
         ss.depth = w.ray_rec + RR_DEPTH; ss.depth_stride = RAY_REC; ss.sun_pass = 1; ss.patch_last = 0;
         ss.cnt_first = w.sun.counts; ss.cnt_retry = w.cnt_retry; ss.counts = w.sun.counts; ss.offsets = w.sun.offsets;
-        ss.n_pts = w.sun.n_pts;
+        ss.n_pts = w.sun.n_pts; ss.n_pts_copy = nullptr;
         ss.px = w.sun.px; ss.py = w.sun.py; ss.pz = w.sun.pz; ss.tmid = w.sun.tmid; ss.delta = w.sun.delta; ss.simg = w.sun.simg;
         HIP_TRY(eo_launch_sampler(ss, st));
         rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train ? 1 : 0, st, 3);
@@ -799,8 +799,6 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     sh.pts_first = w.cnt_first; sh.sc_counts = shadows ? w.sun.counts : w.cnt_first;
     sh.n_rays = n_rays; sh.use_shadow = shadows ? 1 : 0; sh.eval = (flags & EONERF_F_EVAL) ? 1 : 0; sh.out = out;
     HIP_TRY(eo_launch_shade_fwd(sh, st));
-    if (n_samples_dev) HIP_TRY(hipMemcpyAsync(n_samples_dev, w.cam.n_pts, sizeof(int), hipMemcpyDeviceToDevice, st));
-
     return EONERF_OK;
 }
 

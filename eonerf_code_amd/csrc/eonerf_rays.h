@@ -25,6 +25,7 @@ struct SampleArgs {
     int *cnt_first, *cnt_retry, *counts, *offsets;   // [R], [R], [R], [R+1]
     int* flags;               // bit0: retry taken
     int* n_pts;
+    int* n_pts_copy;          // optional second destination of the sample count (the caller's device scalar), or nullptr
     float *px, *py, *pz, *tmid, *delta;   // [p_pad] compact outputs
     int* simg;
     // optional flattened outputs of satnerf_sampling (sat_rendering.py:82-84): ray_indices, t_starts, t_ends

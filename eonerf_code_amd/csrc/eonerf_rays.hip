@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_scan(SampleArgs a) {
         if (tid == 1023) carry = c + woff + incl;
         __syncthreads();
     }
-    if (tid == 0) { a.offsets[a.n_rays] = carry; *a.n_pts = carry; }
+    if (tid == 0) { a.offsets[a.n_rays] = carry; *a.n_pts = carry; if (a.n_pts_copy) *a.n_pts_copy = carry; }
 }
 
 // ---- kernel 3: recompute the samples and write them compactly ---------------------------------------------
