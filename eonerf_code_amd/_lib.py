@@ -20,8 +20,9 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_render_workspace_bytes", "eonerf_field_forward", "eonerf_query_density", "eonerf_render_forward",
            "eonerf_render_backward", "eonerf_adam_step", "eonerf_profile_enable", "eonerf_profile_read",
            "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering", "eonerf_generate_rays",
-           "eonerf_adam_step_late", "eonerf_param_is_late", "eonerf_field_train_workspace_bytes", "eonerf_field_forward_train",
-           "eonerf_field_backward", "eonerf_set_noise_seed", "eonerf_render_status"]
+           "eonerf_field_train_workspace_bytes", "eonerf_field_forward_train",
+           "eonerf_field_backward", "eonerf_set_noise_seed", "eonerf_render_status", "eonerf_device_status", "eonerf_grad_floats",
+           "eonerf_grad_seal"]
 
 
 class EonerfRpc(C.Structure):
@@ -78,9 +79,11 @@ def lib():
     L.eonerf_query_density.argtypes = [vp, vp, vp, i, vp, vp, sz, vp]
     L.eonerf_render_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_render_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
-    L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp]
-    L.eonerf_adam_step_late.argtypes = [vp, vp, vp, vp, vp, i, i, fp, fp, fp, fp, fp, vp]
-    L.eonerf_param_is_late.argtypes = [vp, i]
+    L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp, vp]
+    L.eonerf_device_status.argtypes = [vp, vp]
+    L.eonerf_grad_floats.restype = sz
+    L.eonerf_grad_floats.argtypes = [vp]
+    L.eonerf_grad_seal.argtypes = [vp, vp, vp]
     L.eonerf_field_train_workspace_bytes.restype = sz
     L.eonerf_field_train_workspace_bytes.argtypes = [vp, i, i]
     L.eonerf_field_forward_train.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]
@@ -103,12 +106,6 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError(f"libeonerf_hip: {lib().eonerf_strerror(rc).decode()} (code {rc})")
-
-
-def late_param_names(ctx):
-    """Names of the tensors whose Adam step starts counting when the shadow pass switches on (eonerf_adam_step_late)."""
-    L = lib()
-    return {name for k, (name, _, _, _) in enumerate(param_layout(ctx)) if L.eonerf_param_is_late(ctx, k) == 1}
 
 
 def param_layout(ctx):

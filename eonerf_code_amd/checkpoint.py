@@ -23,19 +23,19 @@ def occ_grid_state_dict(resolution=128):
             "binaries": torch.ones(1, r, r, r, dtype=torch.bool)}
 
 
-def adam_state_dict(field, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, step_late=None, late_names=()):
-    """torch.optim.Adam.state_dict() equivalent built from the flat moment buffers of FusedTrainer.  Parameters in
-    `late_names` (transient embedding / head, ambient head: grad None in the reference while epoch_idx < 2) carry their own
-    step count `step_late`, and NO state entry while it is 0 -- exactly what torch.optim.Adam holds for them."""
+def adam_state_dict(field, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.Adam.state_dict() equivalent built from the flat moment buffers of FusedTrainer.  EVERY parameter has a state
+    entry with the global step: in the reference the transient / ambient heads receive defined zero gradients while epoch_idx < 2
+    (torch.cat + slicing keeps them in the graph, sat_rendering.py:294,311-312,322), so torch.optim.Adam creates their state at
+    step 1 like everybody else's."""
     by_name = {name: (off, r, c) for name, off, r, c in field._layout}
     state, ids = {}, []
     for i, (name, p) in enumerate(field.named_parameters()):
         ids.append(i)
-        st = step_late if (step_late is not None and name in late_names) else step
-        if st == 0:
+        if step == 0:
             continue
         off, r, c = by_name[name]
-        state[i] = {"step": torch.tensor(float(st)),
+        state[i] = {"step": torch.tensor(float(step)),
                     "exp_avg": exp_avg[off:off + r * c].view(p.shape).detach().cpu().clone(),
                     "exp_avg_sq": exp_avg_sq[off:off + r * c].view(p.shape).detach().cpu().clone()}
     group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
@@ -48,8 +48,7 @@ def save_checkpoint(path, epoch, field, trainer=None, loss=None, grid_resolution
     ckpt = {"epoch": epoch, "occ_grid_state_dict": occ_grid_state_dict(grid_resolution),
             "model_state_dict": {k: v.detach().cpu() for k, v in field.state_dict().items()},
             "optimizer_state_dict": (adam_state_dict(field, trainer.exp_avg, trainer.exp_avg_sq, trainer.step_count, trainer.lr,
-                                                     trainer.betas, trainer.eps, getattr(trainer, "step_late", None),
-                                                     getattr(trainer, "late_names", ())) if trainer is not None else None),
+                                                     trainer.betas, trainer.eps) if trainer is not None else None),
             "loss": None if loss is None else torch.as_tensor(loss).detach().cpu()}
     torch.save(ckpt, path)
     return path
@@ -62,15 +61,17 @@ def load_checkpoint(path, field, trainer=None, map_location="cpu"):
     if trainer is not None and ckpt.get("optimizer_state_dict"):
         by_name = {name: (off, r, c) for name, off, r, c in field._layout}
         st = ckpt["optimizer_state_dict"]["state"]
-        late_names = getattr(trainer, "late_names", ())
-        steps, steps_late = [0], [0]
+        # parameters without a state entry (a checkpoint of a run that never stepped them) start from zero moments, whatever the
+        # trainer held before
+        trainer.exp_avg.zero_()
+        trainer.exp_avg_sq.zero_()
+        steps = [0]
         for i, (name, p) in enumerate(field.named_parameters()):
             if i in st:
                 off, r, c = by_name[name]
                 trainer.exp_avg[off:off + r * c].copy_(st[i]["exp_avg"].reshape(-1))
                 trainer.exp_avg_sq[off:off + r * c].copy_(st[i]["exp_avg_sq"].reshape(-1))
-                (steps_late if name in late_names else steps).append(int(float(st[i]["step"])))
-        trainer.step_count = max(steps)
-        trainer.step_late = max(steps_late) if late_names else trainer.step_count
+                steps.append(int(float(st[i]["step"])))
+        trainer.step_count = max(steps)      # one count for all (k_adam); a reference checkpoint carries the same value everywhere
         trainer.lr = ckpt["optimizer_state_dict"]["param_groups"][0]["lr"]
     return ckpt["epoch"]

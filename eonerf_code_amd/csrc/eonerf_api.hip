@@ -84,6 +84,8 @@ struct eonerf_ctx {
     uint64_t noise_seed = 0x5eed5eedULL; uint32_t noise_call = 0;   // in-kernel Philox jitter (eonerf_set_noise_seed)
     bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
+    int* dev_status = nullptr;       // STICKY device status word (watchdog bits of the pipelined backward, bit 8: a remote rank's fault);
+                                     // written by the kernels, gates eonerf_adam_step, read and cleared only by eonerf_device_status
     bool weights_set = false;
     bool dens_dirty = false;         // density-only streams are re-packed lazily (only the shadow pass reads them)
     // measurement hooks
@@ -253,23 +255,23 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
 
 // trunk layers 7..1 of one pass: dX chain + weight gradients, layer-pipelined (eonerf_bwd_pipe.hip).  Reads dY_7 from w.pipe.dy_in
 // (written by the heads part of the backward chain), accumulates dW / db of the trunk into d_flat, saves dY_5 / dY_0 in b.grd.
-// The error word ([0] of the sync block) is only cleared by the FIRST launch of a backward call (clear_error) so that a watchdog
-// raised in either pass survives until eonerf_render_status reads it.
-int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, bool clear_error = true) {
+// A watchdog that fires goes to the context's STICKY status word (ctx->dev_status), which no launch clears.
+// first_of_backward: the first pipeline launch of a backward call also zeroes the GEMM's accumulator and work queue, which sit right
+// in front of the sync block (one memset for everything the backward needs zeroed).
+int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, bool first_of_backward = true) {
     const ParamLayout& pl = ctx->pl;
-    // sync block: [0] error word | [32] role counter | [64..] scratch lines, edge flags -- one memset either way
-    if (clear_error) {      // first pipeline launch of this backward: also the GEMM's accumulator and queue in front of the sync block
-        uint8_t* lo = reinterpret_cast<uint8_t*>(w.m_bott);
+    // sync block: [32] role counter | [64..] scratch lines, edge flags
+    {
+        uint8_t* lo = first_of_backward ? reinterpret_cast<uint8_t*>(w.m_bott) : reinterpret_cast<uint8_t*>(w.pipe.sync);
         uint8_t* hi = reinterpret_cast<uint8_t*>(w.pipe.sync) + w.pipe.sync_bytes;
         HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), st));
     }
-    else HIP_TRY(hipMemsetAsync(w.pipe.sync + 32, 0, w.pipe.sync_bytes - 32 * sizeof(uint32_t), st));
     ProfScope ps(ctx, prof_id, st);
     BwdPipeArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.n_pts = b.n_pts; pa.p_pad = p_cap; pa.n_pipes = ctx->n_pipes;
     pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in; pa.act = b.act; pa.masks = b.masks; pa.grd = b.grd;
-    pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(w.pipe.sync) + 32; pa.error = reinterpret_cast<int*>(w.pipe.sync);
+    pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(w.pipe.sync) + 32; pa.error = ctx->dev_status;
     pa.scratch_word = w.pipe.sync + 64; pa.flags = w.pipe.sync + 64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32;
     pa.d_flat = d_flat; pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
     for (int s = 0; s < PIPE_STAGES; ++s) {
@@ -391,7 +393,7 @@ const char* eonerf_strerror(int code) {
         case EONERF_E_WORKSPACE: return "eonerf: workspace too small";
         case EONERF_E_STATE: return "eonerf: call sequence error (set_weights / train forward missing)";
         case EONERF_E_UNSUPPORTED: return "eonerf: unsupported configuration";
-        case EONERF_E_DEVICE: return "eonerf: a device-side hand-off timed out (pipelined backward watchdog); the gradients of that step are invalid";
+        case EONERF_E_DEVICE: return "eonerf: a device-side hand-off timed out (pipelined backward watchdog) on this or another rank; the gradients of that step are invalid and every optimizer update since has been skipped";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "eonerf: unknown error";
     }
 }
@@ -430,6 +432,8 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
         { const char* f = getenv("EONERF_PIPE_STAMPS");
           if (!rc && ctx->pipe && f && atoi(f)) rc = (int)hipMalloc(&ctx->pipe_stamps, (size_t)ctx->n_pipes * PIPE_STAGES * 128 * sizeof(unsigned long long)); }
     }
+    if (!rc) rc = (int)hipMalloc(&ctx->dev_status, 64 * sizeof(int));
+    if (!rc) rc = (int)hipMemset(ctx->dev_status, 0, 64 * sizeof(int));
     if (!rc) {
         int cm[64];
         for (int s = 0; s < 64; ++s) cm[s] = enc_col_of_slot(ctx->bf16, s);
@@ -474,6 +478,7 @@ int eonerf_destroy(eonerf_ctx* ctx) {
     release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads); release(ctx->bwd_dens_heads); release(ctx->ig_tail_wt);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     if (ctx->pipe_stamps) (void)hipFree(ctx->pipe_stamps);
+    if (ctx->dev_status) (void)hipFree(ctx->dev_status);
     delete ctx;
     return EONERF_OK;
 }
@@ -916,15 +921,26 @@ int eonerf_debug_pipe_stamps(eonerf_ctx* ctx, unsigned long long* host_out, int 
     return n;
 }
 
-int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* ws, size_t ws_bytes, void* stream) {
-    if (!ctx || !ws || n_rays < 0) return EONERF_E_ARG;
-    RenderWs w = carve_render(ctx, ws, n_rays, flags);
-    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
-    if (!w.pipe.sync) return EONERF_OK;
+int eonerf_device_status(eonerf_ctx* ctx, void* stream) {
+    if (!ctx) return EONERF_E_ARG;
     int err = 0;
-    HIP_TRY(hipMemcpyAsync(&err, w.pipe.sync, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(&err, ctx->dev_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return err ? EONERF_E_DEVICE : EONERF_OK;
+    if (!err) return EONERF_OK;
+    HIP_TRY(hipMemsetAsync(ctx->dev_status, 0, sizeof(int), (hipStream_t)stream));
+    return EONERF_E_DEVICE;
+}
+
+int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* ws, size_t ws_bytes, void* stream) {
+    (void)n_rays; (void)flags; (void)ws; (void)ws_bytes;
+    return eonerf_device_status(ctx, stream);
+}
+
+size_t eonerf_grad_floats(const eonerf_ctx* ctx) { return ctx ? ctx->pl.total + 4 : 0; }
+
+int eonerf_grad_seal(eonerf_ctx* ctx, float* d_flat, void* stream) {
+    if (!ctx || !d_flat) return EONERF_E_ARG;
+    return (int)eo_launch_grad_seal(d_flat + ctx->pl.total, ctx->dev_status, (hipStream_t)stream);
 }
 
 int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, int n_rays, int kind, float* d_out, float* loss, void* stream) {
@@ -932,31 +948,12 @@ int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, in
     return (int)eo_launch_loss(out, pixels, n_rays, kind, d_out, loss, (hipStream_t)stream);
 }
 
-static int adam_common(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
-                       int step, int step_late, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
-    if (!ctx || !flat || !d_flat || !exp_avg || !exp_avg_sq || step < 1 || step_late < 0 || step_late > step) return EONERF_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const ParamLayout& pl = ctx->pl;
-    // "late" parameters (outside the reference's autograd graph while epoch_idx < 2): the transient embedding, and the
-    // transient head + ambient head, which are contiguous at the end of the flat buffer (ParamLayout::build)
-    const size_t late[4] = {pl.t[pl.emb].offset, pl.t[pl.rad].offset, pl.t[pl.t_w[0]].offset, pl.total};
-    HIP_TRY(eo_launch_adam(flat, d_flat, exp_avg, exp_avg_sq, pl.total, step, step_late, late, lr, beta1, beta2, eps, grad_scale, st));
-    return eonerf_set_weights(ctx, flat, stream);
-}
-
 int eonerf_adam_step(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
-                     int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
-    return adam_common(ctx, flat, d_flat, exp_avg, exp_avg_sq, step, step, lr, beta1, beta2, eps, grad_scale, stream);
-}
-
-int eonerf_adam_step_late(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
-                          int step, int step_late, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
-    return adam_common(ctx, flat, d_flat, exp_avg, exp_avg_sq, step, step_late, lr, beta1, beta2, eps, grad_scale, stream);
-}
-
-int eonerf_param_is_late(const eonerf_ctx* ctx, int index) {
-    if (!ctx || index < 0 || index >= (int)ctx->pl.t.size()) return EONERF_E_ARG;
-    return (index == ctx->pl.emb || index >= ctx->pl.t_w[0]) ? 1 : 0;
+                     int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream) {
+    if (!ctx || !flat || !d_flat || !exp_avg || !exp_avg_sq || step < 1) return EONERF_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(eo_launch_adam(flat, d_flat, exp_avg, exp_avg_sq, ctx->pl.total, step, lr, beta1, beta2, eps, grad_scale, ctx->dev_status, fault_flag, st));
+    return eonerf_set_weights(ctx, flat, stream);
 }
 
 }  // extern "C"

@@ -202,16 +202,24 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     auto poll_sync = [&](gu32* word) -> int {      // slow path: one synchronous agent-scope read
         return (int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    auto wait_for = [&](gu32* word, int need, int& known) {        // bounded spin (watchdog)
-        if (known >= need) return;
+    // bounded spin (watchdog).  Once this workgroup has given up (its own watchdog, or another stage's: the status word is polled in
+    // the slow path), every later wait returns at once: the launch drains in a handful of steps instead of one 0.3 s timeout per
+    // wait and stage.  (The status word is sticky across launches: until the host has read it, every pipelined launch whose
+    // hand-offs ever enter the slow path leaves early too -- its gradients are not used anyway, see k_adam.)
+    bool aborted = false;
+    auto wait_for = [&](gu32* word, int need, int& known) {
+        if (known >= need || aborted) return;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
+        for (unsigned it = 0;; ++it) {
             known = poll_sync(word);
             if (known >= need) return;
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > WATCHDOG_TICKS) {
-                if (lane == 0) { atomicOr(a.error, 1 << (S.st & 7)); ctl[0] = 1; }
+            const bool expired = __builtin_amdgcn_s_memrealtime() - t0 > WATCHDOG_TICKS;
+            const bool other = (it & 63) == 63 && __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (expired || other) {
+                if (lane == 0) { if (expired) atomicOr(a.error, 1 << (S.st & 7)); ctl[0] = 1; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                aborted = true;
                 return;
             }
         }
@@ -530,11 +538,10 @@ hipError_t eo_launch_pipe_reduce(const BwdPipeArgs& a, hipStream_t st) {
 size_t eo_bwd_pipe_lds_bytes() { return SMEM_B; }
 
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+    static EoAttrOnce attr;
+    {
+        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B); });
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(k_bwd_pipe, dim3(a.n_pipes * PIPE_STAGES), dim3(NT), SMEM_B, st, a);
     return hipGetLastError();

@@ -87,11 +87,10 @@ __global__ __launch_bounds__(256) void k_ig_tail(IgTailArgs a) {
 
 hipError_t eo_launch_ig_tail(const IgTailArgs& a, int n_wg, hipStream_t st) {
     constexpr int SMEM = 4 * 2 * IMG;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig_tail), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    static EoAttrOnce attr;
+    {
+        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ig_tail), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(k_ig_tail, dim3(n_wg), dim3(256), SMEM, st, a);
     return hipGetLastError();

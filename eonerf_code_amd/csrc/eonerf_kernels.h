@@ -4,6 +4,20 @@
 #include <stdint.h>
 #include "eonerf_common.h"
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of the kernel ON ONE DEVICE (of the code object loaded there): a process
+// that drives several GPUs has to set it once per device, not once per process.
+struct EoAttrOnce {
+    bool done[64] = {};
+    template <class F> hipError_t ensure(F&& set) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set();
+        if (done[dev]) return hipSuccess;
+        const hipError_t e = set();
+        if (e == hipSuccess) done[dev] = true;
+        return e;
+    }
+};
+
 // ---- rows of the saved-activation slab [ACT_ROWS][p_pad] (feature-major, see eonerf_mlp_fwd.hip) ----
 constexpr int ACT_ROW_ENC = 0;        // 64 encoding slots (slot order, see enc_col_of_hq)
 constexpr int ACT_ROW_X1 = 64;        // X1..X8 : outputs of trunk layers 0..7, 256 rows each

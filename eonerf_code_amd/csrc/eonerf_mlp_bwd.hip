@@ -235,12 +235,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
 template <class P, bool FULL, bool IG, bool TRANS, bool PIPE = false>
 hipError_t launch(const MlpBwdArgs& a, int grid, hipStream_t st) {
     constexpr int SMEM = 2 * FwdSlot<P>::BYTES + SlabWriter<P, GrdMap>::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG, TRANS, PIPE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    static EoAttrOnce attr;
+    {
+        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd<P, FULL, IG, TRANS, PIPE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL((k_mlp_bwd<P, FULL, IG, TRANS, PIPE>), dim3(grid), dim3(P::NT), SMEM, st, a);
     return hipGetLastError();

@@ -204,12 +204,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 template <class P, bool FULL, int MODE>
 hipError_t launch(const MlpFwdArgs& a, int grid, hipStream_t st) {
     constexpr int SMEM = 2 * FwdSlot<P>::BYTES + (MODE ? SlabWriter<P, ActMap>::LDS_BYTES : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    static EoAttrOnce attr;
+    {
+        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL((k_mlp_fwd<P, FULL, MODE>), dim3(grid), dim3(P::NT), SMEM, st, a);
     return hipGetLastError();

@@ -127,9 +127,10 @@ hipError_t eo_launch_ambient_points_bwd(const AmbientW& w, const float* sun, con
                                         float* d_w1, float* d_b1, float* d_w2, float* d_b2, hipStream_t st);
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st);
 hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st);
-// late_ranges = {lo0, hi0, lo1, hi1}: flat-index ranges whose Adam step is step_late (0 = skipped), see k_adam
-hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, int step_late, const size_t late_ranges[4],
-                          float lr, float b1, float b2, float eps, float gscale, hipStream_t st);
+// status: the context's sticky device status word; fault_flag: reduced fault flag of the gradient message or nullptr (see k_adam)
+hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
+                          float gscale, int* status, const float* fault_flag, hipStream_t st);
+hipError_t eo_launch_grad_seal(float* tail, const int* status, hipStream_t st);
 hipError_t eo_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);
 hipError_t eo_launch_shade_fwd(const ShadeArgs& a, hipStream_t st);
 hipError_t eo_launch_points_to_soa(const float* xyz, const int64_t* img, int n, int p_pad, float* px, float* py, float* pz,

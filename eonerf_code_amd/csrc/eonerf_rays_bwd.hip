@@ -427,25 +427,30 @@ __global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt,
 }
 
 // ---- torch.optim.Adam (no weight decay, no amsgrad) on the flat buffers --------------------------------------
-// Parameters inside the two "late" ranges (transient embedding; transient head + ambient head) have grad None in the
-// reference while epoch_idx < 2 (s = 1, MSE on rgb: sat_rendering.py:269-272, train_eonerf.py:139-141), so torch.optim.Adam
-// skips them and their per-parameter step starts counting at epoch 2: they get their own bias corrections (late.active == 0:
-// skipped altogether, as torch does for grad None).
-struct AdamLate { size_t lo0, hi0, lo1, hi1; float bc1, bc2_sqrt; int active; };
+// ONE step count for every parameter: while epoch_idx < 2 the reference's graph still reaches the transient / ambient heads through
+// torch.cat + slicing (sat_rendering.py:294,311-312,322), so they receive defined ZERO gradients, torch.optim.Adam creates their
+// state at step 1 and moves them by 0 -- which is what zero entries of g do here.
+// Fault gate: the update is skipped as a whole (parameters and both moments untouched) when the context's sticky status word is set
+// (a watchdog of the pipelined backward fired on this rank: its gradients are invalid) or when the reduced fault flag of the
+// gradient message is non-zero (some rank's are); the latter also raises the local status word so that this rank's next
+// eonerf_device_status reports it.
 __global__ void k_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                       float bc1, float bc2_sqrt, float gscale, AdamLate late) {
+                       float bc1, float bc2_sqrt, float gscale, int* status, const float* fault_flag) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool remote = fault_flag != nullptr && *fault_flag != 0.f;
+    if (remote && i == 0) atomicOr(status, 0x100);
+    if (remote || (status != nullptr && *status != 0)) return;
     if (i >= n) return;
-    if ((i >= late.lo0 && i < late.hi0) || (i >= late.lo1 && i < late.hi1)) {
-        if (!late.active) return;
-        bc1 = late.bc1; bc2_sqrt = late.bc2_sqrt;
-    }
     const float gi = g[i] * gscale;
     const float mi = m[i] + (1.f - b1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1-beta1)
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= (lr / bc1) * (mi / denom);
+}
+// the fault flag of the gradient message (eonerf_grad_seal): control floats [0..3] behind the gradients
+__global__ void k_grad_seal(float* tail, const int* status) {
+    if (threadIdx.x < 4) tail[threadIdx.x] = (threadIdx.x == 0 && *status != 0) ? 1.f : 0.f;
 }
 
 }  // namespace
@@ -508,11 +513,13 @@ hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, fl
     hipLaunchKernelGGL(k_loss, dim3((n + 255) / 256), dim3(256), 0, st, out, gt, n, kind, d_out, loss);
     return hipGetLastError();
 }
-hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, int step_late, const size_t late_ranges[4],
-                          float lr, float b1, float b2, float eps, float gscale, hipStream_t st) {
+hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
+                          float gscale, int* status, const float* fault_flag, hipStream_t st) {
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
-    AdamLate late{late_ranges[0], late_ranges[1], late_ranges[2], late_ranges[3], 1.f, 1.f, step_late > 0 ? 1 : 0};
-    if (step_late > 0) { late.bc1 = 1.f - powf(b1, (float)step_late); late.bc2_sqrt = sqrtf(1.f - powf(b2, (float)step_late)); }
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, late);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, status, fault_flag);
+    return hipGetLastError();
+}
+hipError_t eo_launch_grad_seal(float* tail, const int* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_grad_seal, dim3(1), dim3(64), 0, st, tail, status);
     return hipGetLastError();
 }

@@ -267,11 +267,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradJobTable tab, c
 
 template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, hipStream_t st, float* partials) {
     constexpr int SMEM = NS * SLOT_B + 16;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<P>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    static EoAttrOnce attr;
+    {
+        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<P>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL((k_wgrad<P>), dim3(n_wg), dim3(WG_NT), SMEM, st, jobs, p_pad, queue, partials);
     if (partials) hipLaunchKernelGGL((k_wgrad_reduce<P>), dim3(256, jobs.n), dim3(256), 0, st, jobs, partials);

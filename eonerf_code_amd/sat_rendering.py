@@ -182,6 +182,10 @@ def render_image(
         counts.append(n)
     out = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
     n_rendering_samples = int(torch.stack(counts).sum().item())     # the only host sync of the call
+    if torch.is_grad_enabled() and any(p.requires_grad for p in radiance_field.parameters()):
+        # training through autograd: the stream is synchronised right here anyway, so this is where a device-side fault of an EARLIER
+        # backward (pipelined kernels' watchdog, include/eonerf_hip.h) surfaces -- before another optimizer step builds on it
+        _lib.check(_lib.lib().eonerf_device_status(radiance_field._ctx, _stream()))
     lead = tuple(rays_shape[:-1])
     if only_depth:
         return {"depth": out[:, 3:4].reshape(*lead, -1)}, n_rendering_samples

@@ -27,14 +27,26 @@ def main():
     ap.add_argument("--logs_dir", default="logs")
     ap.add_argument("--exp_name", default="eonerf_hip")
     ap.add_argument("--synthetic_rays", type=int, default=1 << 20)
+    ap.add_argument("--check_every", type=int, default=1000, help="steps between host syncs (loss print + device status on every rank)")
+    ap.add_argument("--dump_params", default=None, help="write the final flat parameters of every rank to <path>.rank<r>")
     args = ap.parse_args()
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # EONERF_DP_REHEARSAL=1 (tests on a one-GPU box, not a deployment mode): every rank on cuda:0, gloo instead of RCCL; run it with
+    # EONERF_PIPE=0 -- the pipelined backward assumes the card to itself
+    rehearsal = os.environ.get("EONERF_DP_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from .checkpoint import save_checkpoint
     from .radiance_fields.eonerf import EONerfMLP
@@ -57,14 +69,20 @@ def main():
         for i in range(steps_per_epoch):
             r, im, px = table.batch(epoch, i, args.batch_size)
             loss = trainer.step(r, im, px, epoch)
-            if step % 1000 == 0 and rank == 0:                              # the only host sync, every 1000 steps (:173-178)
-                trainer.check_device_status()                                # raises if a device-side hand-off timed out
+            if step % args.check_every == 0:                                # the only host sync, every 1000 steps (:173-178)
+                # on EVERY rank: raises (-> non-zero exit of the job) if a device-side hand-off timed out on ANY rank since the last
+                # check; the fault flag of the gradient message has kept all replicas from applying an update since
+                trainer.check_device_status()
+            if step % args.check_every == 0 and rank == 0:
                 el = time.time() - tic
                 print(f"epoch={epoch} | elapsed_time={el:.2f}s | step={step} | loss={float(loss):.5f} | "
                       f"rays/s={(step + 1) * args.batch_size * world / max(el, 1e-9):.0f}", flush=True)
             if step > 0 and step % (4 * steps_per_epoch) == 0 and rank == 0:  # save_freq, :180-191
                 save_checkpoint(os.path.join(args.logs_dir, args.exp_name, f"ckpts/epoch={epoch}.ckpt"), epoch, field, trainer, loss)
             if step == args.max_train_steps:
+                trainer.check_device_status()
+                if args.dump_params:                                        # replica-equality checks of the tests
+                    torch.save(field.flat_params().detach().cpu(), f"{args.dump_params}.rank{rank}")
                 if world > 1:
                     torch.distributed.destroy_process_group()
                 return

@@ -1,13 +1,19 @@
 """Fused training step over libeonerf_hip.so -- the loop body of train_eonerf.py:104-161 without autograd plumbing:
 
-    jitter noise -> eonerf_render_forward(TRAIN) -> loss gradient on [R,21] -> eonerf_render_backward
-      -> [RCCL all-reduce of the flat gradient] -> eonerf_adam_step (+ weight re-pack)
+    jitter noise -> eonerf_render_forward(TRAIN) -> loss gradient on [R,21] -> eonerf_render_backward -> eonerf_grad_seal
+      -> [RCCL all-reduce of the flat gradient message] -> eonerf_adam_step (+ weight re-pack)
 
 One process per GPU; with torch.distributed initialised (backend "nccl" = RCCL over xGMI) the flat fp32 gradient
 (679,821 floats at 20 images, 2.7 MB) is summed across ranks in ONE collective per step and scaled by 1/world inside
 the Adam kernel.  Rays are independent units, so ranks render disjoint ray batches and nothing else is exchanged.
+
+Fault protocol (device-side watchdog of the pipelined backward, include/eonerf_hip.h): the message carries one control float
+behind the gradients -- "my gradients are invalid" -- written by eonerf_grad_seal from the context's sticky status word.  The
+sum all-reduce hands every rank the OR of all flags, the Adam kernel skips the update on every rank while it (or the local status
+word) is set, and every rank raises at its next check_device_status(): replicas never apply a poisoned gradient and never diverge.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -21,7 +27,9 @@ def reduce_gradients(d_flat):
     the CPU tests).  Returns the factor the optimizer must scale it by (1/world: every rank holds the mean-loss gradient
     of its own equally-sized batch, so the mean over ranks is the gradient of the global-batch mean loss)."""
     dist = torch.distributed
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    if dist.get_world_size() == 1 and os.environ.get("EONERF_FORCE_ALLREDUCE") != "1":     # (test hook: run the collective at world 1 too)
         return 1.0
     dist.all_reduce(d_flat, op=dist.ReduceOp.SUM)
     return 1.0 / dist.get_world_size()
@@ -40,19 +48,19 @@ class FusedTrainer:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat = field._ensure_packed()
         dev = self.flat.device
-        self.d_flat = torch.zeros_like(self.flat)
-        self.exp_avg = torch.zeros_like(self.flat)
-        self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.step_count = 0
-        self.step_late = 0      # steps taken with the transient / ambient heads inside the graph (eonerf_adam_step_late)
-        self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         self.L = _lib.lib()
         self.ctx = field._ctx
-        self.late_names = _lib.late_param_names(self.ctx)
+        self.n_params = self.flat.numel()
+        # the gradient MESSAGE: parameters' gradients + 4 control floats ([n_params] = fault flag), one all-reduce unit
+        self.d_flat = torch.zeros(self.L.eonerf_grad_floats(self.ctx), dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0     # ONE Adam step count for every parameter (zero gradients still step, see k_adam)
+        self.dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world = torch.distributed.get_world_size() if self.dist_on else 1
         self.max_rays = max_rays
         self._ws = {}
         self._comm_stream = None
-        self._last = None
         self.out = torch.empty(max_rays, 21, dtype=torch.float32, device=dev)
         self.d_out = torch.zeros(max_rays, 21, dtype=torch.float32, device=dev)
         self.n_samples = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -85,6 +93,12 @@ class FusedTrainer:
 
     def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False):
         """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar."""
+        loss = self.forward_backward(rays, img_idx, pixels, epoch_idx, noise)
+        self.reduce_and_update()
+        return loss
+
+    def forward_backward(self, rays, img_idx, pixels, epoch_idx, noise=None):
+        """First half of a step: render, loss, backward into the gradient message (sealed with this rank's fault flag)."""
         n = rays.shape[0]
         if n > self.max_rays:
             raise ValueError(f"batch of {n} rays exceeds the trainer's max_rays={self.max_rays}")
@@ -116,21 +130,25 @@ class FusedTrainer:
         self.d_flat.zero_()
         _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
                                                  _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
-        self._last = (n, flags, ws)
+        _lib.check(self.L.eonerf_grad_seal(self.ctx, _ptr(self.d_flat), st))
+        return loss
+
+    def reduce_and_update(self):
+        """Second half of a step: the one exchange (sum all-reduce of the message, side stream) and the fused Adam update, which
+        the device skips on every rank when any rank sealed a fault into the message."""
+        st = _stream()
         gscale = self._reduce(st)
         self.step_count += 1
-        if flags & _lib.F_SHADOWS:
-            self.step_late += 1
-        _lib.check(self.L.eonerf_adam_step_late(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                                self.step_count, self.step_late, self.lr, self.betas[0], self.betas[1], self.eps, gscale, st))
+        flag = C.c_void_p(self.d_flat.data_ptr() + 4 * self.n_params)
+        _lib.check(self.L.eonerf_adam_step(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, gscale, flag, st))
         self.field._packed_version = tuple(p._version for p in self.field.parameters())   # adam_step re-packed the weights
-        return loss
 
     def _reduce(self, st):
         """The gradient all-reduce on a SIDE stream: it starts when the last gradient kernel of the backward has
         finished (event on the compute stream) and the Adam kernel waits for it; host-side launches of the next kernels are not
         held up by the collective.  Single process: no-op."""
-        if self.world == 1:
+        if not self.dist_on or (self.world == 1 and os.environ.get("EONERF_FORCE_ALLREDUCE") != "1"):
             return 1.0
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.flat.device)
@@ -142,11 +160,10 @@ class FusedTrainer:
         return gscale
 
     def check_device_status(self):
-        """Synchronises and raises if a device-side hand-off of the pipelined backward timed out in the last step (see
-        eonerf_render_status); meant for the places where the host reads the loss anyway."""
-        if self._last is not None:
-            n, flags, ws = self._last
-            _lib.check(self.L.eonerf_render_status(self.ctx, n, flags, _ptr(ws), ws.numel(), _stream()))
+        """Synchronises and raises (on THIS rank; call it on every rank) if a device-side hand-off of the pipelined backward timed out
+        on any rank since the last check (eonerf_device_status: the status word is sticky and the Adam kernel has been skipping the
+        update since); meant for the places where the host reads the loss anyway."""
+        _lib.check(self.L.eonerf_device_status(self.ctx, _stream()))
 
     def set_noise_seed(self, seed):
         """Key of the in-kernel jitter stream; data-parallel ranks must use different seeds (train_dp.py: seed + rank)."""
@@ -185,10 +202,13 @@ class RayTable:
     def batch(self, epoch, step, batch_per_rank):
         """Batch `step` of epoch `epoch` for this rank.  The shuffle is ONE on-device gather of the whole table per epoch (three
         index_select launches over the table, microseconds at 16 MB); a step's batch is then a contiguous slice of the shuffled
-        copy -- no per-step gather kernels, no host work beyond slicing."""
+        copy -- no per-step gather kernels, no host work beyond slicing.  The shuffled copy doubles the table's footprint
+        (60 B per ray: 1.2 GB -> 2.4 GB for 20 M rays, of 288 GB)."""
         if self._perm_epoch != epoch:
-            g = torch.Generator(device="cpu").manual_seed(self.seed + epoch)
-            self._perm = torch.randperm(self.n, generator=g).to(self.rays.device)
+            # drawn ON the device (same seed -> same permutation on every rank: one device type, one torch build): no host-side
+            # randperm, no H2D copy, no synchronisation at the epoch boundary
+            g = torch.Generator(device=self.rays.device).manual_seed(self.seed + epoch)
+            self._perm = torch.randperm(self.n, generator=g, device=self.rays.device)
             self._shuffled = (self.rays.index_select(0, self._perm), self.img.index_select(0, self._perm), self.rgbs.index_select(0, self._perm))
             self._perm_epoch = epoch
         lo = (step * self.world + self.rank) * batch_per_rank

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EONERF_VERSION 200
+#define EONERF_VERSION 300
 
 enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4, EONERF_E_DEVICE = -5 };
 
@@ -160,31 +160,39 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat_params, const floa
                            int n_rays, int flags, const float* d_out, float* d_flat_params,
                            void* workspace, size_t workspace_bytes, void* stream);
 
-/* Device-side health of the last eonerf_render_backward on this workspace.  In bf16 mode the trunk backward is a persistent,
- * layer-pipelined kernel whose workgroups hand tiles to each other inside the launch; every wait in it is bounded by a
- * wall-clock watchdog, so a launch always drains, and a wait that expired is recorded in the workspace.  This call
- * SYNCHRONISES `stream` and returns EONERF_E_DEVICE if that happened (0 otherwise): call it where the host synchronises anyway
- * (the reference's loop reads the loss every 1000 steps, train_eonerf.py:173-178). */
+/* Device-side health.  In bf16 mode the trunk / heads backward are persistent, layer-pipelined kernels whose workgroups hand
+ * tiles to each other inside the launch; every wait in them is bounded by a wall-clock watchdog, so a launch always drains, and a
+ * wait that expired is recorded in a STICKY status word owned by the context: no later launch clears it, eonerf_adam_step refuses
+ * to apply gradients while it is set (see there), and only eonerf_device_status reads and clears it.
+ *   eonerf_device_status: SYNCHRONISES `stream`, returns EONERF_E_DEVICE if a fault was recorded since the last call (0 otherwise)
+ *   and clears the word.  Call it where the host synchronises anyway (the reference's loop reads the loss every 1000 steps,
+ *   train_eonerf.py:173-178) -- on EVERY data-parallel rank.
+ *   eonerf_render_status: the same check, kept with the workspace arguments of version 2 of this ABI (they are ignored). */
+int eonerf_device_status(eonerf_ctx* ctx, void* stream);
 int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The data-parallel gradient MESSAGE (one flat fp32 all-reduce per step) is eonerf_grad_floats() long:
+ * the eonerf_param_floats() gradients followed by 4 control floats, [0] = fault flag.  eonerf_grad_seal writes the flag
+ * (1.0 if this context's status word is set, else 0.0) behind the last backward of a step, so that the ONE sum all-reduce also
+ * tells every rank that some rank's gradients are invalid; every rank then skips the update (eonerf_adam_step) and raises at its
+ * next eonerf_device_status.  d_flat_params must hold eonerf_grad_floats() floats for this call. */
+size_t eonerf_grad_floats(const eonerf_ctx* ctx);
+int eonerf_grad_seal(eonerf_ctx* ctx, float* d_flat_params, void* stream);
 
 /* Training loss on the packed outputs and its gradient (train_eonerf.py:139-143): kind 0 = F.mse_loss(rgb, pixels),
  * kind 1 = metrics.uncertainty_aware_loss(pixels, rgb, beta) (metrics.py:17-22; the constant 3/2 of its beta term is
  * NOT included in *loss).  Writes d_out[R,21] (zero except the rgb/beta columns) and the scalar *loss (device). */
 int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, int n_rays, int kind, float* d_out, float* loss, void* stream);
 
-/* torch.optim.Adam step on the flat buffers (train_eonerf.py:63,161): lr, betas (0.9,0.999), eps 1e-8, no weight decay.
- * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+/* torch.optim.Adam step on the flat buffers (train_eonerf.py:63,161): lr, betas (0.9,0.999), eps 1e-8, no weight decay; ONE step
+ * count for every parameter (the reference's cat + slice graph hands the transient / ambient heads defined ZERO gradients while
+ * epoch_idx < 2 -- sat_rendering.py:294,311-312,322 -- so torch.optim.Adam steps them from step 1 with a zero update).
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+ * fault_flag (device pointer, may be NULL): the update is SKIPPED -- parameters and moments untouched -- when *fault_flag != 0
+ * (the reduced flag of eonerf_grad_seal: some rank's gradients are invalid) or when this context's sticky status word is set;
+ * a skip through fault_flag also sets the status word, so the next eonerf_device_status on this rank reports it. */
 int eonerf_adam_step(eonerf_ctx* ctx, float* flat_params, const float* d_flat_params, float* exp_avg, float* exp_avg_sq,
-                     int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
-
-/* The same step with torch.optim.Adam's PER-PARAMETER step counts: the transient embedding, the transient head and the ambient
- * head receive grad None in the reference while epoch_idx < 2 (s = 1 and MSE on rgb, sat_rendering.py:269-272,
- * train_eonerf.py:139-141), so Adam skips them and their bias corrections start counting when the shadow pass switches on.
- * step_late = number of steps taken with those parameters inside the graph (0: they are skipped, as torch does for grad None);
- * eonerf_param_is_late(index) tells which tensors of eonerf_param_info these are (1 / 0). */
-int eonerf_adam_step_late(eonerf_ctx* ctx, float* flat_params, const float* d_flat_params, float* exp_avg, float* exp_avg_sq,
-                          int step, int step_late, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
-int eonerf_param_is_late(const eonerf_ctx* ctx, int index);
+                     int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream);
 
 /* Measurement hooks (no reference counterpart): with profiling enabled every launch of the three MFMA kernels is
  * bracketed by hipEvents on the caller's stream.  kernel: 0 = forward chain (camera), 1 = backward chain (camera),

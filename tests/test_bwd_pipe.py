@@ -74,10 +74,28 @@ def test_pipelined_backward_is_repeatable_over_many_steps():
             assert (tr.d_flat - g_ref).norm().item() <= 2e-6 * g_ref.norm().item(), it
 
 
-def test_watchdog_drains_the_launch_and_reports():
+def test_watchdog_drains_the_launch_quickly_reports_and_gates_the_update():
+    import time
+    from eonerf_code_amd.synthetic import synthetic_batch
+    from eonerf_code_amd.trainer import FusedTrainer
     f = _field(True, fault=3)               # stage 3 (layer 4) never publishes its tiles
+    R = 4096
+    rays, img, rgbs = (t.cuda() for t in synthetic_batch(R, N_IMG, seed=3))
+    tr = FusedTrainer(f, lr=1e-3, max_rays=R)
+    p0, m0 = tr.flat.detach().clone(), tr.exp_avg.clone()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    tr.step(rays, img, rgbs, 0)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    # ONE 0.3 s timeout (the stage behind the stalled edge), then every other waiting stage sees the status word in its slow path and
+    # leaves: the launch drains in well under a second more, not in one timeout per wait and stage
+    assert dt < 2.0, dt
+    # the corrupted step was NOT applied: the Adam kernel saw the status word
+    assert torch.equal(tr.flat.detach(), p0) and torch.equal(tr.exp_avg, m0)
+    assert tr.d_flat[tr.n_params].item() == 1.0          # and the gradient message carries the fault flag for the other ranks
     with pytest.raises(RuntimeError, match="hand-off timed out"):
-        _grads(f, 4096, 0)
+        tr.check_device_status()
     # the context stays usable: a healthy field next to it still trains
     l, g, _ = _grads(_field(True), 512, 0)
     assert torch.isfinite(g).all()

@@ -32,17 +32,17 @@ def _free_port():
     return port
 
 
-def _run_job(out_dir, mode, epoch, timeout=300):
+def _run_job(out_dir, mode, epoch, timeout=300, world=WORLD, kill_on_failure=True):
     """A miniature of what torchrun does: start one process per rank, fail the job when any rank fails."""
     port = str(_free_port())
-    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), str(r), str(WORLD), port, str(out_dir), mode,
-                               str(epoch)], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(WORLD)]
-    t0, codes = time.time(), [None] * WORLD
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), str(r), str(world), port, str(out_dir), mode,
+                               str(epoch)], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    t0, codes = time.time(), [None] * world
     while any(c is None for c in codes):
         for i, p in enumerate(procs):
             if codes[i] is None:
                 codes[i] = p.poll()
-        if any(c not in (None, 0) for c in codes) or time.time() - t0 > timeout:
+        if (kill_on_failure and any(c not in (None, 0) for c in codes)) or time.time() - t0 > timeout:
             for p in procs:                      # exactly the PIDs started above
                 if p.poll() is None:
                     p.kill()
@@ -85,3 +85,109 @@ def test_nonzero_c_abi_return_code_on_one_rank_fails_the_job(tmp_path):
     assert codes[1] not in (0, None) and "libeonerf_hip" in outs[1], outs[1]
     assert not all(c == 0 for c in codes)
     assert not (tmp_path / "rank1.pt").exists()
+
+
+def _single_process_reference(precision, epoch):
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    from eonerf_code_amd.trainer import FusedTrainer
+    sd = orc.random_state_dict(N_IMG, seed=91, bias_scale=0.05)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    f = EONerfMLP(N_IMG, radiometric_normalization=True, precision=precision)
+    f.load_state_dict(sd, strict=True)
+    f = f.cuda()
+    tr = FusedTrainer(f, lr=5e-4, max_rays=R * WORLD)
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R * WORLD, N_IMG, seed=92)
+    loss = tr.step(rays.cuda(), ts.reshape(-1).cuda(), rgbs.cuda(), epoch, noise=(u_cam.cuda(), None, u_sun.cuda()))
+    tr.check_device_status()
+    return f, tr, float(loss)
+
+
+@pytest.mark.parametrize("epoch", [0, 3])
+def test_two_ranks_bf16_pipelined_backward_under_torch_distributed(tmp_path, epoch):
+    """The benchmarked path (bf16, layer-pipelined backward) with torch.distributed initialised and a real gradient exchange: the
+    ranks take turns on the card for the render/backward half, then all-reduce and update together."""
+    codes, outs = _run_job(tmp_path, "pipe", epoch)
+    assert codes == [0, 0], outs
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(WORLD))
+    assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
+    assert torch.equal(r0["d_flat"], r1["d_flat"])
+    assert r0["d_flat"][-4].item() == 0.0                             # the fault flag of the reduced message
+    f, tr, loss = _single_process_reference("bf16", epoch)
+    ref, got = tr.d_flat.cpu(), r0["d_flat"] / WORLD
+    assert abs(loss - 0.5 * (r0["loss"] + r1["loss"])) < 1e-5
+    for (name, p), g_ref, g_got in zip(f.named_parameters(), f.grad_views(ref), f.grad_views(got)):
+        assert (g_ref - g_got).norm().item() <= 2e-4 * g_ref.norm().item() + 1e-9, (epoch, name)
+
+
+def test_device_side_fault_on_one_rank_stops_every_rank_before_the_update(tmp_path):
+    """Rank 1's pipelined backward hits its watchdog.  The fault flag rides on the gradient all-reduce: neither rank's Adam kernel
+    applies the (poisoned) update, the replicas stay identical, and BOTH ranks raise at their next status check."""
+    codes, outs = _run_job(tmp_path, "fault", 0, timeout=180, kill_on_failure=False)
+    assert all(c not in (0, None) for c in codes), (codes, outs)
+    assert all("hand-off timed out" in o for o in outs), outs
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(WORLD))
+    assert r0["d_flat"][-4].item() >= 1.0 and torch.equal(r0["d_flat"][-4:], r1["d_flat"][-4:])
+    assert torch.equal(r0["flat"], r0["flat_before"]) and torch.equal(r1["flat"], r1["flat_before"])
+    assert torch.equal(r0["flat"], r1["flat"])
+
+
+def test_rccl_process_group_world_one_pipelined_step(tmp_path):
+    """backend "nccl" (= RCCL): communicator creation and the gradient all-reduce on the side stream really execute (world size 1 is
+    all a one-GPU box allows), next to the pipelined backward, in one process."""
+    codes, outs = _run_job(tmp_path, "nccl1", 3, world=1)
+    assert codes == [0], outs
+    r0 = torch.load(tmp_path / "rank0.pt")
+    f, tr, loss = _single_process_reference_world1(3)
+    assert abs(loss - r0["loss"]) < 1e-5
+    assert (tr.d_flat.cpu() - r0["d_flat"]).norm().item() <= 2e-4 * tr.d_flat.norm().item()
+
+
+def _single_process_reference_world1(epoch):
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    from eonerf_code_amd.trainer import FusedTrainer
+    sd = orc.random_state_dict(N_IMG, seed=91, bias_scale=0.05)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    f = EONerfMLP(N_IMG, radiometric_normalization=True, precision="bf16")
+    f.load_state_dict(sd, strict=True)
+    f = f.cuda()
+    tr = FusedTrainer(f, lr=5e-4, max_rays=R)
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R, N_IMG, seed=92)
+    loss = tr.step(rays.cuda(), ts.reshape(-1).cuda(), rgbs.cuda(), epoch, noise=(u_cam.cuda(), None, u_sun.cuda()))
+    return f, tr, float(loss)
+
+
+def _torchrun(args, env_extra, timeout=600):
+    port = str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port] + args
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), **env_extra)
+    return subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_n_gt_1_path_rehearsal_two_ranks_on_one_card():
+    """bench.py's N > 1 logic exactly as the driver launches it (torch.distributed.run, rendezvous from the environment, barrier-bracketed
+    timing, MAX over ranks, rank 0's JSON line) -- rehearsed with two ranks on one card over gloo (EONERF_BENCH_REHEARSAL=1, chain + GEMM
+    backward: two pipelined launches must not share a card).  Not a measurement: the checks are the line's shape and bookkeeping."""
+    import json
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-pass"],
+                  {"EONERF_BENCH_REHEARSAL": "1", "EONERF_PIPE": "0"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak" and line["steps"] == 3
+    assert "full EO-NeRF" in line["config"]["workload"]
+    # whole-job rate = both ranks' rays over the slowest rank's time
+    assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert "cpu_baseline" not in line                                  # rank 0 at N = 1 only
+
+
+def test_launcher_two_ranks_keeps_replicas_identical(tmp_path):
+    """train_dp.py under torch.distributed.run with two ranks (one card, gloo rehearsal): broadcast at start, per-rank slices of one
+    shared permutation, per-rank jitter seeds, one all-reduce per step -- the replicas end bit-identical."""
+    r = _torchrun(["-m", "eonerf_code_amd.train_dp", "--synthetic_rays", "8192", "--batch_size", "512", "--n_images", "5",
+                   "--max_train_steps", "20", "--check_every", "10", "--logs_dir", str(tmp_path), "--exp_name", "t",
+                   "--dump_params", str(tmp_path / "params")],
+                  {"EONERF_DP_REHEARSAL": "1", "EONERF_PIPE": "0"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    p0, p1 = torch.load(str(tmp_path / "params") + ".rank0"), torch.load(str(tmp_path / "params") + ".rank1")
+    assert torch.equal(p0, p1) and torch.isfinite(p0).all()
+    assert "rays/s=" in r.stdout

@@ -164,7 +164,7 @@ def test_adam_step_matches_torch():
         ref_p.grad = grad.clone()
         opt.step()
         _lib.check(_lib.lib().eonerf_adam_step(f._context(), _ptr(flat), _ptr(grad.cuda()), _ptr(m), _ptr(v), step,
-                                               5e-4, 0.9, 0.999, 1e-8, 1.0, _stream()))
+                                               5e-4, 0.9, 0.999, 1e-8, 1.0, None, _stream()))
     assert (flat.cpu() - ref_p.detach()).abs().max().item() < 1e-6
 
 

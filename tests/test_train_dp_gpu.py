@@ -1,7 +1,7 @@
 """GPU: the launcher loop (eonerf_code_amd/train_dp.py = train_eonerf.py:96-161,304 on the HIP path) end to end in one process:
 epochs of a small synthetic ray table, the MSE -> uncertainty-loss / shadow-pass switch at epoch 2 (train_eonerf.py:139-143), StepLR
-gamma 0.9 once per epoch (:64,304), the periodic checkpoint (:180-191) in the reference's format with the per-parameter Adam steps
-of the transient head (late parameters, torch.optim.Adam semantics) and the decayed learning rate.
+gamma 0.9 once per epoch (:64,304), the periodic checkpoint (:180-191) in the reference's format with torch.optim.Adam's step count
+(one for every parameter: zero gradients still step) and the decayed learning rate.
 """
 import os
 import subprocess
@@ -29,12 +29,12 @@ def test_launcher_runs_epochs_switches_loss_decays_lr_and_checkpoints(tmp_path):
     opt = ckpt["optimizer_state_dict"]
     # four epoch ends before step 32 -> lr = 5e-4 * 0.9^4
     assert abs(opt["param_groups"][0]["lr"] - 5e-4 * 0.9 ** 4) < 1e-12
-    # the trunk stepped 33 times (steps 0..32); the transient head only since the loss switch at epoch 2 (step 16): 17 times
+    # every parameter stepped 33 times (steps 0..32): the transient head with zero gradients until the loss switch at epoch 2
     from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
     names = [n for n, _ in EONerfMLP(5, radiometric_normalization=True).named_parameters()]
     steps = {names[i]: int(float(s["step"])) for i, s in opt["state"].items()}
     assert steps["base_mlp.hidden_layers.0.weight"] == 33, steps
-    late = [v for k, v in steps.items() if k.startswith("transient_mlp")]
-    assert late and all(v == 17 for v in late), steps
+    head = [v for k, v in steps.items() if k.startswith("transient_mlp")]
+    assert head and all(v == 33 for v in head) and len(steps) == len(names), steps
     for v in ckpt["model_state_dict"].values():
         assert torch.isfinite(v).all()

@@ -1,5 +1,6 @@
 """GPU: FusedTrainer host logic -- argument checks, stale packed weights after in-place parameter changes, checkpoint resume
-(train_eonerf.py:180-191 / eval_eonerf.py:44-75), torch.optim.Adam's per-parameter step counts."""
+(train_eonerf.py:180-191 / eval_eonerf.py:44-75), torch.optim.Adam semantics of the fused update (one step count, zero gradients
+still step), the device-side fault gate of the update."""
 import pytest
 import torch
 
@@ -67,7 +68,7 @@ def test_checkpoint_resume_continues_the_uninterrupted_run(tmp_path):
     # resumed: fresh field (other weights) + trainer, load, same 4th step
     f2, tr2, _ = _make(seed=5)
     assert load_checkpoint(path, f2, tr2) == 2
-    assert tr2.step_count == 3 and tr2.step_late == 1
+    assert tr2.step_count == 3
     loss = float(tr2.step(rays2, img2, pix2, 3, noise=noise2))
     assert abs(loss - loss_ref) < 1e-6
     assert (tr2.d_flat - g_ref).norm().item() <= 1e-4 * g_ref.norm().item()
@@ -75,46 +76,87 @@ def test_checkpoint_resume_continues_the_uninterrupted_run(tmp_path):
     ck = torch.load(path, weights_only=False)
     st = ck["optimizer_state_dict"]["state"]
     names = [n for n, _ in f.named_parameters()]
-    assert all(float(st[i]["step"]) == (1.0 if names[i] in tr.late_names else 3.0) for i in st)
+    assert len(st) == len(names) and all(float(st[i]["step"]) == 3.0 for i in st)      # every parameter, ONE step count
 
 
-def test_adam_late_parameters_follow_torch_adam_with_none_grads():
-    # reference semantics: transient / ambient parameters get grad None for the first steps (torch.optim.Adam skips them), then
-    # start their own bias-correction count
-    import ctypes as C
+def test_adam_kernel_matches_torch_adam_with_zero_gradients_for_the_heads_outside_the_loss():
+    # reference semantics (sat_rendering.py:294,311-312,322 + train_eonerf.py:139-141): for epoch_idx < 2 the transient / ambient
+    # parameters receive defined ZERO gradients (cat + slice), so torch.optim.Adam steps them from step 1 with a zero update and ONE
+    # step count serves every parameter
     from eonerf_code_amd import _lib
     from eonerf_code_amd.radiance_fields.eonerf import _ptr, _stream
     f, tr, _ = _make()
     flat = tr.flat
-    layout = f._layout
-    late = torch.zeros(flat.numel(), dtype=torch.bool)
+    head = torch.zeros(flat.numel(), dtype=torch.bool)
     real = torch.zeros(flat.numel(), dtype=torch.bool)              # tensors sit at 16-byte aligned offsets: skip the padding floats
-    for name, off, r, c in layout:
+    for name, off, r, c in f._layout:
         real[off:off + r * c] = True
-        if name in tr.late_names:
-            late[off:off + r * c] = True
-    assert late.sum().item() > 80000 and "transient_encoder.weight" in tr.late_names and "ambient_mlp.output_layer.bias" in tr.late_names
-    main = real & ~late
-    p_main = flat.detach().cpu()[main].clone().requires_grad_(True)
-    p_late = flat.detach().cpu()[late].clone().requires_grad_(True)
-    opt = torch.optim.Adam([p_main, p_late], lr=5e-4)
+        if name.startswith(("transient_", "ambient_mlp")):
+            head[off:off + r * c] = True
+    assert head.sum().item() > 80000
+    p_ref = flat.detach().cpu()[real].clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=5e-4)
     m, v = torch.zeros_like(flat), torch.zeros_like(flat)
     g = torch.Generator().manual_seed(3)
-    step_late = 0
     for step in range(1, 6):
         grad = torch.randn(flat.numel(), generator=g) * 0.01
-        in_graph = step >= 3
-        if not in_graph:
-            grad[late] = 0.0
-        p_main.grad = grad[main].clone()
-        p_late.grad = grad[late].clone() if in_graph else None
+        if step < 3:
+            grad[head] = 0.0                                         # outside the loss: zeros, not None
+        p_ref.grad = grad[real].clone()
         opt.step()
-        step_late += 1 if in_graph else 0
-        _lib.check(_lib.lib().eonerf_adam_step_late(f._ctx, _ptr(flat), _ptr(grad.cuda()), _ptr(m), _ptr(v), step, step_late,
-                                                    5e-4, 0.9, 0.999, 1e-8, 1.0, _stream()))
+        _lib.check(_lib.lib().eonerf_adam_step(f._ctx, _ptr(flat), _ptr(grad.cuda()), _ptr(m), _ptr(v), step,
+                                               5e-4, 0.9, 0.999, 1e-8, 1.0, None, _stream()))
     got = flat.detach().cpu()
-    assert (got[main] - p_main.detach()).abs().max().item() < 1e-6
-    assert (got[late] - p_late.detach()).abs().max().item() < 1e-6
+    assert (got[real] - p_ref.detach()).abs().max().item() < 1e-6
+
+
+def test_first_real_update_of_the_transient_head_carries_the_global_bias_correction():
+    # two epoch < 2 steps (zero gradients for the transient head) and one step with the shadow pass on, against the oracle under
+    # torch.optim.Adam: the head's first real update is ~0.64 lr sign(g) (bias corrections of step 3), not lr sign(g)
+    f, tr, sd = _make(seed=61)
+    rays, img, pix, noise = _batch(seed=62)
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    opt = torch.optim.Adam([v for v in sdg.values() if v.is_floating_point()], lr=5e-4)
+    r_c, ts_c, px_c = rays.cpu(), img.cpu().reshape(-1, 1), pix.cpu()
+    for epoch in (0, 1, 2):
+        tr.step(rays, img, pix, epoch, noise=noise)
+        orc.train_step(sdg, r_c, ts_c, px_c, noise[0].cpu(), noise[2].cpu(), epoch, 2.0 / 128, opt)
+    name = "transient_mlp.hidden_layers.1.weight"
+    assert int(opt.state[sdg[name]]["step"]) == 3                    # the reference's Adam has stepped it three times
+    before = sd[name]
+    d_ref = (sdg[name].detach() - before)
+    d_hip = (dict(f.named_parameters())[name].detach().cpu() - before)
+    big = sdg[name].grad.abs() > 1e-6                                 # elements whose sign is not noise
+    assert big.sum().item() > 1000
+    assert abs(d_ref[big].abs().median().item() / 5e-4 - 0.639) < 0.01
+    assert abs(d_hip[big].abs().median().item() / 5e-4 - 0.639) < 0.01
+    assert (d_hip[big] - d_ref[big]).abs().max().item() < 2e-5
+
+
+def test_update_is_skipped_while_the_status_word_or_the_reduced_fault_flag_is_set():
+    # the fault gate of k_adam: a non-zero fault flag in the gradient message (what the all-reduce hands every rank when ANY rank
+    # sealed a fault) skips the update, raises the local status word, and the status stays up until it has been read
+    from eonerf_code_amd import _lib
+    from eonerf_code_amd.radiance_fields.eonerf import _ptr, _stream
+    f, tr, _ = _make()
+    rays, img, pix, noise = _batch()
+    tr.forward_backward(rays, img, pix, 3, noise=noise)
+    assert tr.d_flat[tr.n_params].item() == 0.0                       # sealed: no fault on this rank
+    p0, m0 = tr.flat.detach().clone(), tr.exp_avg.clone()
+    tr.d_flat[tr.n_params] = 1.0                                      # "some rank faulted"
+    tr.reduce_and_update()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.flat.detach(), p0) and torch.equal(tr.exp_avg, m0)
+    # sticky: the next, healthy step is skipped too, until the host has looked
+    tr.forward_backward(rays, img, pix, 3, noise=noise)
+    assert tr.d_flat[tr.n_params].item() == 1.0                       # the seal now reports this rank's raised status word
+    tr.reduce_and_update()
+    assert torch.equal(tr.flat.detach(), p0)
+    with pytest.raises(RuntimeError, match="hand-off"):
+        tr.check_device_status()
+    tr.check_device_status()                                          # read-and-clear: healthy again
+    tr.step(rays, img, pix, 3, noise=noise)
+    assert not torch.equal(tr.flat.detach(), p0)
 
 
 def test_without_radiometric_normalization_matches_the_oracle():
