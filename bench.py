@@ -10,15 +10,18 @@ with in-kernel jitter, fused MLP chain, compositing, shading) -> loss -> backwar
 weight-gradient GEMM) -> [RCCL all-reduce of the flat gradient] -> Adam + weight re-pack.
 
 ONE run measures both single-GPU configurations of BASELINE.json, each with W warm-up steps and EXACTLY K timed steps
-bracketed by barrier + synchronize (max over ranks):
-  `value`, `ms_per_step`, ...  configs[1]: JAX_068-like synthetic rays, 4096 rays x 128 samples per GPU,
-                               shadow pass off (epoch_idx < 2, MSE loss), bf16 MFMA   <- the metric's configuration
-  `full`                       configs[2]: the same rays with the shadow-ray pass, sun-visibility head and uncertainty loss
-                               (epoch_idx >= 2) -- what the reference runs for all but its first two epochs
+bracketed by barrier + synchronize (max over ranks; HIP events at the boundaries of three blocks inside the bracket give the run's
+own spread):
+  `value`, `ms_per_step`, `roofline`, `config.workload`
+                               configs[2]: JAX_068-like synthetic rays, 4096 rays x 128 samples per GPU, FULL EO-NeRF:
+                               shadow-ray pass, sun-visibility head, uncertainty loss (epoch_idx >= 2) -- what the reference runs
+                               for all but its first two epochs (sat_rendering.py:269-276), and the N = 1 point of configs[3]
+  `rgb`                        configs[1]: the same rays with the shadow pass off (epoch_idx < 2, MSE loss)
 Weak scaling: per-GPU work is fixed, rays are independent units.
 
-Kernel times come from a SECOND, untimed pass of K steps with the library's HIP-event brackets on (the timed passes run
-without them).  `roofline` prices the dominant kernel against the bound SURVEY.md 8(d) names (bf16 MFMA peak) from its
+Kernel times come from a SECOND, untimed pass of K steps with the library's HIP-event scopes on -- one scope per kernel launch, on
+the stream the kernels run on (the timed passes run without them); every scope is priced with the FLOPs of exactly the layers
+that launch evaluates (kernel_model), so the scopes' FLOPs add up to the step's useful work.  `roofline` prices the dominant kernel against the bound SURVEY.md 8(d) names (bf16 MFMA peak) from its
 ALGORITHMIC FLOPs (8(d): 2 x MACs of the layers it evaluates x live samples) and also carries the HBM view of the same
 launch (the design's stash bytes; PMC-measured bytes in `traffic`).  `cpu_baseline` is the oracle (CPU port of the reference
 algorithm, torch fp32) timed on this box's host cores per BASELINE.md 3: >= 1024 rays, 1 warm-up + median of 3 steps.
@@ -110,13 +113,65 @@ def cpu_baseline(workloads, n_rays=1024, reps=3):
             orc.train_step(params, rays, ts, rgbs, u_cam, u_sun, epoch, STEP_SIZE, opt)
             times.append(time.perf_counter() - t0)
         res[wl] = (n_rays / statistics.median(times), statistics.median(times))
-    head = res["rgb"] if "rgb" in res else next(iter(res.values()))
+    head = res["full"] if "full" in res else next(iter(res.values()))      # the headline workload
     out = {"value": head[0], "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
            "sample": f"oracle (torch CPU fp32) full train steps (render+loss+backward+Adam) of {n_rays} rays x 128 samples, "
                      f"1 warm-up + median of {reps}: " + ", ".join(f"{k} {v[1]:.2f} s/step" for k, v in res.items())}
-    if "full" in res:
-        out["full_value"] = res["full"][0]
+    if "rgb" in res and "full" in res:
+        out["rgb_value"] = res["rgb"][0]
     return out
+
+
+def split_blocks(k, n_blocks=3):
+    """K timed steps as (at most) three consecutive blocks of nearly equal length."""
+    n = max(1, min(n_blocks, k))
+    edges = [round(i * k / n) for i in range(n + 1)]
+    return [(edges[i], edges[i + 1]) for i in range(n)]
+
+
+def kernel_model(wl, piped, n_cam, n_sun, elt):
+    """Per profiled kernel scope: ALGORITHMIC FLOPs per launch (2 x the MACs of the layers that launch really evaluates x live samples;
+    SURVEY.md 8d / 8a H6 layer shapes) and the HBM bytes the design moves there (saved rows x element size).  The FLOPs of all scopes
+    add up to the step's useful work: 3 x forward of the layers inside the autograd graph."""
+    dead = MAC_TRANSIENT if wl == "rgb" else 0          # transient head outside the graph when epoch_idx < 2 (s = 1, MSE on rgb)
+    trunk_dx = trunk_dw = 7 * 65536                     # layers 1..7: 256 x 256 each way
+    enc_dw = 2 * 63 * 256                               # layer 0 and the skip columns of layer 5 against the 63 encoding columns
+    flop, byts = {}, {}
+    flop["fwd_chain_camera"] = 2.0 * MAC_FWD * n_cam
+    rows_w = 2496 if wl == "rgb" else 3012              # enc 64 + X1..X8 2048 + bottleneck 256 + A1 128 (+ T 512 + emb 4)
+    masks = 9 if wl == "rgb" else 13
+    byts["fwd_chain_camera"] = (rows_w * elt + masks * 32) * n_cam
+    if wl == "full":
+        flop["fwd_chain_sun"] = 2.0 * MAC_DENS * n_sun
+        byts["fwd_chain_sun"] = (2112 * elt + 8 * 32) * n_sun
+    if piped:
+        # heads chain: dX of everything behind X8 (bottleneck, albedo, transient, sigma row); hands dY_7 over in unit order
+        flop["bwd_chain_camera"] = 2.0 * (MAC_BWD - dead - trunk_dx) * n_cam
+        byts["bwd_chain_camera"] = ((256 + 192 + (0 if wl == "rgb" else 544)) * elt + masks * 32) * n_cam
+        # pipelined trunk: dX AND dW of layers 1..7; reads dY_7 + X1..X7, writes dY_5 / dY_0 for the jobs the GEMM keeps
+        flop["bwd_pipe_camera"] = 2.0 * (trunk_dx + trunk_dw) * n_cam
+        byts["bwd_pipe_camera"] = (256 + 7 * 256 + 2 * 256) * elt * n_cam
+        cam_rows_rd = 2 * 320 + 257 + 131 + (2 * 384 if wl == "rgb" else 2 * 512 + 132 + 3 * 256 + 130)
+        flop["wgrad_gemm"] = 2.0 * (MAC_WGRAD - dead - trunk_dw) * n_cam
+        byts["wgrad_gemm"] = cam_rows_rd * elt * n_cam
+        if wl == "full":
+            flop["bwd_chain_sun"] = 2.0 * MAC_SIGMA * n_sun                       # dY_7 = W_sigma^T d sigma_pre
+            byts["bwd_chain_sun"] = (256 * elt + 32 + 4) * n_sun
+            flop["bwd_pipe_sun"] = 2.0 * (trunk_dx + trunk_dw) * n_sun
+            byts["bwd_pipe_sun"] = (256 + 7 * 256 + 2 * 256) * elt * n_sun
+            flop["ig_tail_sun"] = 2.0 * enc_dw * n_sun                            # d enc = W_0^T dY_0 + W_5skip^T dY_5
+            byts["ig_tail_sun"] = (2 * 256 * elt + 24) * n_sun
+            flop["wgrad_gemm"] += 2.0 * (MAC_DENS - trunk_dw) * n_sun             # layer 0, skip columns, sigma row of the sun pass
+            byts["wgrad_gemm"] += (2 * 320 + 257) * elt * n_sun
+    else:
+        flop["bwd_chain_camera"] = 2.0 * (MAC_BWD - dead) * n_cam
+        byts["bwd_chain_camera"] = ((2180 if wl == "rgb" else 2694) * elt + masks * 32) * n_cam
+        flop["wgrad_gemm"] = 2.0 * ((MAC_WGRAD - dead) * n_cam + MAC_DENS * n_sun)
+        byts["wgrad_gemm"] = ((2564 + 2816) if wl == "rgb" else (3334 + 3972)) * elt * n_cam + (2305 + 2176) * elt * n_sun
+        if wl == "full":
+            flop["bwd_chain_sun"] = 2.0 * MAC_DENS * n_sun
+            byts["bwd_chain_sun"] = ((2048 + 1) * elt + 8 * 32) * n_sun
+    return flop, byts
 
 
 def main():
@@ -125,7 +180,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=("both", "rgb", "full"), default="both",
-                    help="both: the metric's configuration (rgb) as the headline + the full EO-NeRF configuration under \"full\"")
+                    help="both: the full EO-NeRF configuration (configs[2]) as the headline + the sigma+albedo configuration (configs[1]) under \"rgb\"")
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the untimed per-kernel event pass (rocprof runs)")
@@ -178,21 +233,31 @@ def main():
         epoch_idx = 3 if wl == "full" else 0
         for i in range(args.warmup):
             one_step(first_step + i, epoch_idx)
+        # EXACTLY K timed steps between two barrier + synchronize brackets; events at the block boundaries (no host sync inside the
+        # timed region) give three sub-timings, so that a short driver run carries its own spread
+        blocks = split_blocks(args.steps)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(blocks) + 1)]
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            loss = one_step(first_step + args.warmup + i, epoch_idx)
+        marks[0].record()
+        for b, (lo, hi) in enumerate(blocks):
+            for i in range(lo, hi):
+                loss = one_step(first_step + args.warmup + i, epoch_idx)
+            marks[b + 1].record()
         barrier()
         dt = time.perf_counter() - t0
+        trainer.check_device_status()                           # every rank: a faulted step would have been skipped, not timed as work
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = t.item()
-        rec = {"rays_per_s": world * RAYS * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "final_loss": float(loss)}
+        block_ms = [marks[b].elapsed_time(marks[b + 1]) / (hi - lo) for b, (lo, hi) in enumerate(blocks)]
+        rec = {"rays_per_s": world * RAYS * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "final_loss": float(loss),
+               "blocks_ms_per_step": block_ms, "median_block_ms_per_step": statistics.median(block_ms)}
         n_cam = int(trainer.n_samples.item())
         n_sun = int(trainer.out[:RAYS, 15].sum().item()) if wl == "full" else 0     # sc_pts_per_ray column (sat_rendering.py:311)
         rec["camera_samples_per_step"], rec["sun_samples_per_step"] = n_cam, n_sun
-        # ---- untimed pass: the same steps with per-kernel HIP-event brackets ----
+        # ---- untimed pass: the same steps with the library's per-kernel HIP-event scopes (on the stream the kernels run on) ----
         kernels = {}
         if not args.no_kernel_pass:
             trainer.profile_enable(args.steps)
@@ -201,38 +266,10 @@ def main():
             torch.cuda.synchronize()
             prof = trainer.profile_read()
             trainer.profile_enable(0)
-            dead = MAC_TRANSIENT if wl == "rgb" else 0          # transient head outside the graph when epoch_idx < 2 (s = 1, MSE on rgb)
-            # bf16: the camera pass's trunk backward is layer-pipelined (csrc/eonerf_bwd_pipe.hip): ONE kernel does the dX chain AND the
-            # 256 x 256 weight gradients of layers 1..7; the chain kernel keeps the heads, the GEMM the jobs the pipeline leaves
-            piped = prof["bwd_pipe_camera"][1] > 0
-            mac_trunk_dx, mac_trunk_dw = 7 * 65536, 7 * 65536
-            flop_of = {"fwd_chain_camera": 2.0 * MAC_FWD * n_cam,
-                       "bwd_chain_camera": 2.0 * (MAC_BWD - dead - (mac_trunk_dx if piped else 0)) * n_cam,
-                       "bwd_pipe_camera": 2.0 * (mac_trunk_dx + mac_trunk_dw) * n_cam,
-                       "wgrad_gemm": 2.0 * ((MAC_WGRAD - dead - (mac_trunk_dw if piped else 0)) * n_cam + MAC_DENS * n_sun),
-                       "fwd_chain_sun": 2.0 * MAC_DENS * n_sun, "bwd_chain_sun": 2.0 * MAC_DENS * n_sun}
-            # HBM bytes the design moves per launch (bf16 slabs): saved rows x element size (+ 32 B ReLU masks per slot)
-            rows_w = 2496 if wl == "rgb" else 3012              # forward chain writes: enc 64 + X1..X8 2048 + bottleneck 256 + A1 128 (+ T 512 + emb 4)
-            rows_g = 2180 if wl == "rgb" else 2694              # backward chain writes: dY0..7 2048 + dA1 128 + d sigma 1 + d albedo 3 (+ dT 512 + 2)
-            rows_rd = (2564 + 2816) if wl == "rgb" else (3334 + 3972)     # weight-gradient GEMM reads both operands of every job once
-            masks = 9 if wl == "rgb" else 13
-            rows_pipe = 0
-            if piped:
-                # heads chain: writes dY_7 in unit order (256 rows) + the head gradient rows (A1 128, A2 32, sigma 32 [+ T 512 + 32]);
-                # pipeline: reads dY_7 (256) and X1..X7 (7 x 256), writes dY_5 and dY_0 (2 x 256) for the GEMM jobs it leaves;
-                # GEMM: layer 0 and the skip columns of layer 5 (2 x (256 + 64)), sigma (32 + 256), bottleneck factors and head jobs
-                rows_g = 256 + 192 + (0 if wl == "rgb" else 544)
-                rows_pipe = 256 + 7 * 256 + 2 * 256
-                # (rows actually fetched: layer 0 and skip columns 2 x (256 + 64), sigma 1 + 256, a2 3 + 128; rgb: bottleneck factor and
-                #  albedo layer 1 (128 + 256 each); full: dY A1 | dY T1 share one block, so [M_a; M_t] and the two first head layers are
-                #  one 256 + 256 job each, + embedding columns 128 + 4, T2..T4 3 x 256, the two one-row heads 2 + 128)
-                rows_rd = 2 * 320 + 257 + 131 + (2 * 384 if wl == "rgb" else 2 * 512 + 132 + 3 * 256 + 130)
-            bytes_of = {"fwd_chain_camera": (rows_w * elt + masks * 32) * n_cam, "bwd_chain_camera": (rows_g * elt + masks * 32) * n_cam,
-                        "bwd_pipe_camera": (rows_pipe * elt if piped else 0) * n_cam,
-                        "wgrad_gemm": rows_rd * elt * n_cam + ((2 * 320 + 257) if piped else (2305 + 2176)) * elt * n_sun,
-                        "fwd_chain_sun": (2112 * elt + 8 * 32) * n_sun, "bwd_chain_sun": ((2048 + 1) * elt + 8 * 32) * n_sun}
+            piped = prof.get("bwd_pipe_camera", (0.0, 0))[1] > 0
+            flop_of, bytes_of = kernel_model(wl, piped, n_cam, n_sun, elt)
             for name, flop in flop_of.items():
-                ms, cnt = prof[name]
+                ms, cnt = prof.get(name, (0.0, 0))
                 if cnt:
                     avg = ms / cnt
                     kernels[name] = {"avg_ms": avg, "tflops": flop / (avg * 1e-3) / 1e12, "frac_mfma": flop / (avg * 1e-3) / 1e12 / peak,
@@ -240,15 +277,14 @@ def main():
                                      "hbm_gbps": bytes_of[name] / (avg * 1e-3) / 1e9}
             rec["kernels"] = kernels
             rec["kernel_ms_sum"] = sum(k["avg_ms"] for k in kernels.values())
-        # ---- whole-step MFMA fraction: useful FLOPs per step / step time / peak ----
+            rec["kernel_flop_sum"] = sum(k["algorithmic_flop_per_launch"] for k in kernels.values())
+        # ---- whole-step MFMA fraction: FLOPs per step / step time / peak ----
         dead = MAC_TRANSIENT if wl == "rgb" else 0
         pruned = 2.0 * ((MAC_FWD + MAC_BWD - dead + MAC_WGRAD - dead) * n_cam + 3 * MAC_DENS * n_sun)
-        s8d = 3.0 * (F_CAM * n_cam + F_DEN * n_sun)             # train = 3 x forward FLOPs at the measured sample counts
-        s8d_nominal = 3.0 * 127 * RAYS * (F_CAM + (F_DEN if wl == "full" else 0))
+        s8d = 3.0 * (F_CAM * n_cam + F_DEN * n_sun)             # train = 3 x forward FLOPs at the MEASURED sample counts
         sec = rec["ms_per_step"] * 1e-3                         # per GPU: RAYS rays per step and rank (weak scaling)
         rec["step_mfma_frac"] = {"kernels_useful_flop": pruned / sec / 1e12 / peak,
-                                 "survey_8d_3xF_measured_samples": s8d / sec / 1e12 / peak,
-                                 "survey_8d_3xF_nominal_127": s8d_nominal / sec / 1e12 / peak}
+                                 "survey_8d_3xF_measured_samples": s8d / sec / 1e12 / peak}
         rec["step_tflops_per_gpu"] = s8d / sec / 1e12
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
@@ -263,35 +299,45 @@ def main():
                                        "note": "bytes the design stashes/re-reads, not SURVEY 8(d)'s compulsory 148 B/ray"}}
         return rec
 
-    workloads = ("rgb", "full") if args.workload == "both" else (args.workload,)
+    # headline = configs[2], the full EO-NeRF step (what the reference runs for all but its first two epochs, sat_rendering.py:269-276);
+    # configs[1] (shadow pass off) rides along under "rgb"
+    workloads = ("full", "rgb") if args.workload == "both" else (args.workload,)
     recs, first = {}, 0
     for wl in workloads:
         recs[wl] = measure(wl, first)
         if rank == 0:
-            print(f"[bench] {wl}: {recs[wl]['rays_per_s']:.0f} rays/s, {recs[wl]['ms_per_step']:.3f} ms/step", file=sys.stderr, flush=True)
+            print(f"[bench] {wl}: {recs[wl]['rays_per_s']:.0f} rays/s, {recs[wl]['ms_per_step']:.3f} ms/step "
+                  f"(blocks {', '.join(f'{b:.3f}' for b in recs[wl]['blocks_ms_per_step'])})", file=sys.stderr, flush=True)
         first += args.warmup + 2 * args.steps
     if rank == 0:
         head = recs[workloads[0]]
         names = {"rgb": "JAX_068-like synthetic rays, sigma+albedo path (shadow pass off, epoch<2, MSE), 4096 rays x 128 samples per GPU",
                  "full": "JAX_068-like synthetic rays, full EO-NeRF (shadow-ray pass + sun-visibility head + uncertainty loss), "
                          "4096 rays x 128 samples per GPU"}
+
+        def nested(wl):
+            f = recs[wl]
+            return {"workload": names[wl], "value": f["rays_per_s"], "unit": "rays/s", "ms_per_step": f["ms_per_step"],
+                    "blocks_ms_per_step": f["blocks_ms_per_step"], "median_block_ms_per_step": f["median_block_ms_per_step"],
+                    "camera_samples_per_step": f["camera_samples_per_step"], "sun_samples_per_step": f["sun_samples_per_step"],
+                    "roofline": f.get("roofline"), "kernels": f.get("kernels"), "step_mfma_frac": f["step_mfma_frac"],
+                    "final_loss": f["final_loss"]}
+
         result = {
             "metric": "train rays/sec on JAX_068 (4096 rays x 128 samples)", "value": head["rays_per_s"], "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": names[workloads[0]], "rays_per_gpu": RAYS, "n_samples": 128, "n_images": N_IMG, "parallelism": f"dp{world}",
                        "batching": "GPU-resident ray table, shuffled on the device once per epoch, batches = slices (RayTable.batch); in-kernel Philox jitter",
-                       "camera_samples_per_step": head["camera_samples_per_step"], "final_loss": head["final_loss"]},
+                       "camera_samples_per_step": head["camera_samples_per_step"], "sun_samples_per_step": head["sun_samples_per_step"],
+                       "final_loss": head["final_loss"]},
+            "blocks_ms_per_step": head["blocks_ms_per_step"], "median_block_ms_per_step": head["median_block_ms_per_step"],
             "roofline": head.get("roofline"),
             "kernels": head.get("kernels"),
             "step_mfma_frac": head["step_mfma_frac"],
         }
-        if "full" in recs and workloads[0] != "full":
-            f = recs["full"]
-            result["full"] = {"workload": names["full"], "value": f["rays_per_s"], "unit": "rays/s", "ms_per_step": f["ms_per_step"],
-                              "camera_samples_per_step": f["camera_samples_per_step"], "sun_samples_per_step": f["sun_samples_per_step"],
-                              "roofline": f.get("roofline"), "kernels": f.get("kernels"), "step_mfma_frac": f["step_mfma_frac"],
-                              "final_loss": f["final_loss"]}
+        for wl in workloads[1:]:
+            result[wl] = nested(wl)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(workloads)
         print(json.dumps(result))

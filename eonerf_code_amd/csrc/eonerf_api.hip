@@ -40,14 +40,18 @@ struct PassBuffers {       // one MLP pass (camera or sun) over up to p_cap samp
     int* simg;
     void *act, *grd; uint32_t* masks;
     float *g_sigma, *g_albedo, *g_ts, *g_tb, *g_emb, *g_pos;
+    float* dsig;           // heads pipeline: d sigma_pre per sample (fp32), written by the heads chain
 };
 
-struct PipeWs {            // layer-pipelined trunk backward (eonerf_bwd_pipe.hip)
-    uint8_t* dy_in;        // dY_7 in unit order: p_cap x 512 B
-    uint8_t* rings;        // [n_pipes][6 edges][PIPE_RING][16 KiB]
-    uint32_t* sync;        // ONE block zeroed per launch: [0] role counter, [1] error bits, [64..) one scratch line per workgroup, then the edge flags
-    size_t sync_bytes;
+struct PipeWs {            // layer-pipelined backward (eonerf_bwd_pipe.hip)
+    uint8_t* dy_in;        // dY_7 in unit order: p_cap x 512 B (heads chain or heads pipeline -> trunk pipeline)
+    uint8_t* dy_heads;     // [dY_A1; dY_T1] in unit order: p_cap x 512 B (heads chain -> heads pipeline, and the embedding-column GEMM job)
+    uint8_t* rings;        // [pipelines][edges][PIPE_RING][16 KiB], sized for the larger of the two launch shapes
+    uint32_t* sync;        // PIPE_LAUNCHES consecutive blocks, one per pipelined launch of a backward call (sun trunk, camera heads, camera
+                           // trunk): [32] role counter, [64..) one scratch line per workgroup, then the edge flags -- all zeroed by ONE memset
+    size_t sync_bytes;     // of one block
 };
+constexpr int PIPE_LAUNCHES = 3;
 
 struct DetWs {             // EONERF_DETERMINISTIC: partial sums instead of atomics
     float* pipe_part;      // [n_pipes * 7][256 * 256 + 256]
@@ -78,8 +82,16 @@ struct eonerf_ctx {
     DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig, pipe_wt, bwd_full_heads, bwd_rgb_heads, bwd_dens_heads, ig_tail_wt;
     bool pipe = false;               // layer-pipelined trunk backward (bf16 camera pass; EONERF_PIPE=0 switches back to chain + GEMM)
     int n_pipes = 0;
+    bool heads_pipe = false;         // EONERF_HEADS_PIPE=1: the camera pass's two wide head layers as a second pipelined launch.  OFF by default:
+                                     // measured on the same box (round 3) it moves 0.26 ms out of the heads chain, the GEMM and the
+                                     // bottleneck factor product and spends 0.30 ms in the launch (120 steps per pipeline: fill, drain and the
+                                     // stationary-dW flush are a third of it) -- the step gets no faster
+    int n_pipes_heads = 0;
+    DevStream bwd_full_heads2, bwd_rgb_heads2, heads_pipe_wt;
     int pipe_fault_stage = -1;       // test hook (EONERF_PIPE_FAULT)
     bool deterministic = false;      // EONERF_DETERMINISTIC=1: every atomic flush of the backward is replaced by partials + a fixed-order sum
+    bool pipe_partials = false;      // the pipelined launches flush their stationary dW through partial buffers + a reduction kernel (always
+                                     // in deterministic mode; EONERF_PIPE_PARTIALS=1 alone: A/B switch against the atomic flush)
     unsigned long long* pipe_stamps = nullptr;   // diagnostics (EONERF_PIPE_STAMPS=1): cycle sums per stage, read by eonerf_debug_pipe_stamps
     uint64_t noise_seed = 0x5eed5eedULL; uint32_t noise_call = 0;   // in-kernel Philox jitter (eonerf_set_noise_seed)
     bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
@@ -87,11 +99,14 @@ struct eonerf_ctx {
     int* dev_status = nullptr;       // STICKY device status word (watchdog bits of the pipelined backward, bit 8: a remote rank's fault);
                                      // written by the kernels, gates eonerf_adam_step, read and cleared only by eonerf_device_status
     bool weights_set = false;
-    bool dens_dirty = false;         // density-only streams are re-packed lazily (only the shadow pass reads them)
+    bool dens_dirty = false;         // density-only streams are re-packed lazily (only the shadow pass reads them) ...
+    bool dens_used = false;          // ... until a step has used them: from then on they are re-packed with the others (one launch fewer per step)
+    hipStream_t side = nullptr;      // internal side stream: the per-ray ambient-head backward runs beside the weight-gradient GEMM
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // measurement hooks
     int prof_cap = 0;
-    std::vector<hipEvent_t> prof_ev[6][2];
-    int prof_n[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<hipEvent_t> prof_ev[EONERF_PROF_KERNELS][2];
+    int prof_n[EONERF_PROF_KERNELS] = {};
 };
 
 namespace {
@@ -122,7 +137,7 @@ void release(DevStream& d) {
 
 // (re)packs the fp32 master weights into up to PACK_MAX_JOBS packed streams in ONE launch (blockIdx.y = job): after every
 // optimizer step three streams x {bf16, fp32} entries are rewritten, and six ~5 us launches cost more than the copies
-constexpr int PACK_MAX_JOBS = 10;
+constexpr int PACK_MAX_JOBS = 16;
 struct PackJob { const PackEntry* e; int n; uint8_t* data; int is16; };
 struct PackJobs { PackJob j[PACK_MAX_JOBS]; };
 __global__ void k_pack(const float* flat, PackJobs jobs) {
@@ -134,7 +149,7 @@ __global__ void k_pack(const float* flat, PackJobs jobs) {
         else *reinterpret_cast<float*>(jb.data + pe.dst) = v;
     }
 }
-int pack(std::initializer_list<const DevStream*> streams, const float* flat, hipStream_t st) {
+int pack(const std::vector<const DevStream*>& streams, const float* flat, hipStream_t st) {
     PackJobs jobs;
     int n = 0, most = 1;
     for (const DevStream* d : streams) {
@@ -174,6 +189,7 @@ void carve_pass(Carver& c, PassBuffers& b, int n_rays, int p_cap, bool full, boo
     b.tb = full ? c.take<float>(p_cap) : nullptr;
     b.act = b.grd = nullptr; b.masks = nullptr;
     b.g_sigma = b.g_albedo = b.g_ts = b.g_tb = b.g_emb = b.g_pos = nullptr;
+    b.dsig = nullptr;
     if (train) {
         b.act = c.take<uint8_t>((size_t)(full ? ACT_ROWS_FULL : ACT_ROWS_DENSITY) * p_cap * act_bytes);
         b.grd = c.take<uint8_t>((size_t)(full ? GRD_ROWS_FULL : GRD_ROWS_DENSITY) * p_cap * act_bytes);
@@ -183,6 +199,7 @@ void carve_pass(Carver& c, PassBuffers& b, int n_rays, int p_cap, bool full, boo
             b.g_albedo = c.take<float>(3 * (size_t)p_cap);
             b.g_ts = c.take<float>(p_cap); b.g_tb = c.take<float>(p_cap);
             b.g_emb = c.take<float>(4 * (size_t)p_cap);
+            b.dsig = c.take<float>(p_cap);
         }
         if (input_grad) b.g_pos = c.take<float>(3 * (size_t)p_cap);
     }
@@ -204,14 +221,19 @@ RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) 
     w.queue = train ? reinterpret_cast<int*>(w.m_bott + 2 * 128 * 256) : nullptr;
     memset(&w.pipe, 0, sizeof(w.pipe));
     if (train && ctx->pipe) {
-        w.pipe.sync_bytes = (64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32 + (size_t)ctx->n_pipes * (PIPE_STAGES - 1) * 64) * sizeof(uint32_t);
-        w.pipe.sync = c.take<uint32_t>(w.pipe.sync_bytes / sizeof(uint32_t));
+        // one sync block fits either launch shape: 7 x n_pipes or 2 x n_pipes_heads workgroups, 6 x n_pipes or 1 x n_pipes_heads edges
+        const size_t wgs = std::max((size_t)ctx->n_pipes * PIPE_STAGES, (size_t)ctx->n_pipes_heads * HEADS_STAGES);
+        const size_t edges = std::max((size_t)ctx->n_pipes * (PIPE_STAGES - 1), (size_t)ctx->n_pipes_heads * (HEADS_STAGES - 1));
+        w.pipe.sync_bytes = (64 + wgs * 32 + edges * 64) * sizeof(uint32_t);
+        w.pipe.sync = c.take<uint32_t>(PIPE_LAUNCHES * w.pipe.sync_bytes / sizeof(uint32_t));
         w.pipe.dy_in = c.take<uint8_t>((size_t)p_cap * 512);
-        w.pipe.rings = c.take<uint8_t>((size_t)ctx->n_pipes * (PIPE_STAGES - 1) * PIPE_RING * PIPE_UNIT_B);
+        w.pipe.dy_heads = ctx->heads_pipe ? c.take<uint8_t>((size_t)p_cap * 512) : nullptr;
+        w.pipe.rings = c.take<uint8_t>(edges * PIPE_RING * PIPE_UNIT_B);
     }
     memset(&w.det, 0, sizeof(w.det));
+    if (train && ctx->pipe && ctx->pipe_partials)
+        w.det.pipe_part = c.take<float>(std::max((size_t)ctx->n_pipes * PIPE_STAGES, (size_t)ctx->n_pipes_heads * HEADS_STAGES) * WGRAD_PART_F);
     if (train && ctx->deterministic) {
-        if (ctx->pipe) w.det.pipe_part = c.take<float>((size_t)ctx->n_pipes * PIPE_STAGES * WGRAD_PART_F);
         w.det.wgrad_part = c.take<float>((size_t)WGRAD_MAX_JOBS * 48 * WGRAD_PART_F);
         w.det.rad_rays = c.take<float>((size_t)n_rays * 6);
         w.det.emb_rays = c.take<float>((size_t)n_rays * 4);
@@ -235,7 +257,7 @@ int ensure_density_streams(eonerf_ctx* ctx, const float* flat, hipStream_t st) {
     return rc;
 }
 
-int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_cap, bool full, int mode, hipStream_t st, int prof_id = -1) {
+int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_cap, bool full, int mode, hipStream_t st, int prof_id = -1, bool render_train = false) {
     if (!full) { const int rc = ensure_density_streams(ctx, flat, st); if (rc) return rc; }
     const DevStream& ds = full ? ctx->fwd_full : ctx->fwd_dens;
     MlpFwdArgs a;
@@ -245,6 +267,9 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     a.stream = ds.data; a.chunks = ds.chunks; a.n_chunks = ds.n_chunks;
     a.sigma = b.sigma; a.albedo = b.albedo; a.ts = b.ts; a.tb = b.tb;
     a.act = b.act; a.masks = b.masks;
+    // training passes of the render path with the pipelined backward: the trunk's ReLU' comes from the X images, only the heads chain
+    // reads mask bits (slot 7 = X_8 for its last layer; from slot 8 on with the heads pipeline)
+    a.mask_from = (render_train && ctx->pipe) ? ((full && ctx->heads_pipe) ? 8 : 7) : 0;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
     if (prof_id < 0) return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, mode, grid, st);
@@ -253,33 +278,65 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
 }
 
 
-// trunk layers 7..1 of one pass: dX chain + weight gradients, layer-pipelined (eonerf_bwd_pipe.hip).  Reads dY_7 from w.pipe.dy_in
-// (written by the heads part of the backward chain), accumulates dW / db of the trunk into d_flat, saves dY_5 / dY_0 in b.grd.
-// A watchdog that fires goes to the context's STICKY status word (ctx->dev_status), which no launch clears.
-// first_of_backward: the first pipeline launch of a backward call also zeroes the GEMM's accumulator and work queue, which sit right
-// in front of the sync block (one memset for everything the backward needs zeroed).
-int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, bool first_of_backward = true) {
-    const ParamLayout& pl = ctx->pl;
-    // sync block: [32] role counter | [64..] scratch lines, edge flags
-    {
-        uint8_t* lo = first_of_backward ? reinterpret_cast<uint8_t*>(w.m_bott) : reinterpret_cast<uint8_t*>(w.pipe.sync);
-        uint8_t* hi = reinterpret_cast<uint8_t*>(w.pipe.sync) + w.pipe.sync_bytes;
+// One pipelined launch of a backward call (eonerf_bwd_pipe.hip).  `slot` = which of the PIPE_LAUNCHES sync blocks it uses; the FIRST
+// pipelined launch of the call (first_of_backward) zeroes all of them together with the GEMM's accumulator and work queue, which sit
+// right in front (one memset for everything the backward needs zeroed).  A watchdog that fires goes to the context's STICKY status
+// word (ctx->dev_status), which no launch clears.
+void pipe_common(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int slot, int n_pipes, int n_stages, BwdPipeArgs& pa) {
+    memset(&pa, 0, sizeof(pa));
+    uint32_t* sync = w.pipe.sync + (size_t)slot * (w.pipe.sync_bytes / sizeof(uint32_t));
+    pa.n_pts = b.n_pts; pa.p_pad = p_cap; pa.n_pipes = n_pipes; pa.n_stages = n_stages;
+    pa.act = b.act; pa.grd = b.grd;
+    pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(sync) + 32; pa.error = ctx->dev_status;
+    pa.scratch_word = sync + 64; pa.flags = sync + 64 + (size_t)n_pipes * n_stages * 32;
+    pa.d_flat = d_flat; pa.fault_stage = -1; pa.stamps = nullptr;
+    pa.partials = w.det.pipe_part;
+}
+int pipe_clear(const RenderWs& w, bool first_of_backward, int slot, hipStream_t st) {
+    if (first_of_backward) {
+        uint8_t* lo = reinterpret_cast<uint8_t*>(w.m_bott);
+        uint8_t* hi = reinterpret_cast<uint8_t*>(w.pipe.sync) + PIPE_LAUNCHES * w.pipe.sync_bytes;
         HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), st));
     }
+    (void)slot;
+    return 0;
+}
+
+// trunk layers 7..1 of one pass: dX chain + weight gradients.  Reads dY_7 from w.pipe.dy_in (written by the heads chain or the heads
+// pipeline), accumulates dW / db of the trunk into d_flat, saves dY_5 / dY_0 in b.grd.
+int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, int slot, bool first_of_backward) {
+    const ParamLayout& pl = ctx->pl;
+    { const int rc = pipe_clear(w, first_of_backward, slot, st); if (rc) return rc; }
     ProfScope ps(ctx, prof_id, st);
     BwdPipeArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    pa.n_pts = b.n_pts; pa.p_pad = p_cap; pa.n_pipes = ctx->n_pipes;
-    pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in; pa.act = b.act; pa.masks = b.masks; pa.grd = b.grd;
-    pa.rings = w.pipe.rings; pa.role_counter = reinterpret_cast<int*>(w.pipe.sync) + 32; pa.error = ctx->dev_status;
-    pa.scratch_word = w.pipe.sync + 64; pa.flags = w.pipe.sync + 64 + (size_t)ctx->n_pipes * PIPE_STAGES * 32;
-    pa.d_flat = d_flat; pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
+    pipe_common(ctx, w, b, p_cap, d_flat, slot, ctx->n_pipes, PIPE_STAGES, pa);
+    pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in;
+    pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
     for (int s = 0; s < PIPE_STAGES; ++s) {
         const int l = 7 - s;
         pa.dw_off[s] = pl.t[pl.trunk_w[l]].offset; pa.db_off[s] = pl.t[pl.trunk_b[l]].offset; pa.dw_ld[s] = l == 5 ? 319 : 256;
     }
-    pa.partials = w.det.pipe_part;
     HIP_TRY(eo_launch_bwd_pipe(pa, st));
+    if (pa.partials) HIP_TRY(eo_launch_pipe_reduce(pa, st));
+    return 0;
+}
+
+// the two wide head layers of the camera pass: [dY_A1; dY_T1] (w.pipe.dy_heads, from the heads chain) -> d bottleneck -> dY_7
+// (w.pipe.dy_in), with the weight gradients of both heads' first layers (bottleneck columns) and of the bottleneck layer
+int run_heads_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, bool transient, hipStream_t st, int slot, bool first_of_backward) {
+    const ParamLayout& pl = ctx->pl;
+    { const int rc = pipe_clear(w, first_of_backward, slot, st); if (rc) return rc; }
+    ProfScope ps(ctx, EONERF_PROF_HEADS_PIPE_CAMERA, st);
+    BwdPipeArgs pa;
+    pipe_common(ctx, w, b, p_cap, d_flat, slot, ctx->n_pipes_heads, HEADS_STAGES, pa);
+    pa.wt = ctx->heads_pipe_wt.data; pa.wsig = ctx->heads_pipe_wt.data + HEADS_WSIG_OFF;
+    pa.dy_in = w.pipe.dy_heads; pa.dy_out = w.pipe.dy_in; pa.dsig = b.dsig;
+    // stage 0: rows 0..127 = albedo head's first layer, rows 128..255 = transient head's first layer (bottleneck columns, ld 260)
+    pa.dw_off[0] = pl.t[pl.a1_w].offset; pa.db_off[0] = pl.t[pl.a1_b].offset; pa.dw_ld[0] = 256;
+    pa.dw_off2[0] = pl.t[pl.t_w[0]].offset; pa.db_off2[0] = pl.t[pl.t_b[0]].offset; pa.dw_ld2[0] = 260;
+    pa.split[0] = 1; pa.skip_hi[0] = transient ? 0 : 1;
+    pa.dw_off[1] = pl.t[pl.bot_w].offset; pa.db_off[1] = pl.t[pl.bot_b].offset; pa.dw_ld[1] = 256;
+    HIP_TRY(eo_launch_heads_pipe(pa, st));
     if (pa.partials) HIP_TRY(eo_launch_pipe_reduce(pa, st));
     return 0;
 }
@@ -289,7 +346,9 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
 //   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
                          const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false,
-                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false) {
+                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false, const uint8_t* heads_units = nullptr) {
+    // heads_units != nullptr: the two wide head layers ran in the heads pipeline (run_heads_pipe): their weight gradients are done, the
+    // bottleneck factor product is not needed, and [dY_A1; dY_T1] lies in unit-order tiles there (the embedding-column job reads it)
     const ParamLayout& pl = ctx->pl;
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
@@ -330,6 +389,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     if (full) {
         const PassBuffers& c = *full;
         trunk_jobs(c, full_trunk_done);
+        if (!heads_units) {
         // bottleneck layer: factor M_a = dA1^T X8 (and M_t = dT1^T X8), finished by eo_launch_bott_wgrad below
         if (!zeroed) HIP_TRY(hipMemsetAsync(m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
         // dY A1 and dY T1 are the two halves of one 256-row block of the gradient slab: with the transient head both factors (and both
@@ -342,9 +402,18 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
             add(c, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, nullptr, nullptr, 2, 4, 2, 2);
             add(c, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
         }
+        }
         add(c, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
+        if (transient && heads_units) {
+            // embedding columns of the transient head's first layer: rows 128..255 of the unit-order [dY_A1; dY_T1] tile against the 4
+            // embedding rows; rows < 128 (dY_A1) have no destination
+            add(c, GRD_ROW_A1, 256, ACT_ROW_EMB, 4, nullptr, 260, nullptr, nullptr, 4, 2, 2, 1);
+            WgradJob& j = tab.j[tab.n - 1];
+            j.a = heads_units; j.a_stride = PIPE_UNIT_B; j.a_units = 1;
+            split_at(128, dptr(pl.t_w[0]) + 256, 260, nullptr);
+        }
         if (transient) {
-            add(c, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
+            if (!heads_units) add(c, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
             for (int l = 1; l < 4; ++l)
                 add(c, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
             add(c, GRD_ROW_T5, 2, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);     // row 0: d ts_pre, row 1: d tb_pre
@@ -369,8 +438,8 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         j.item0 = tab.items;
         tab.items += j.slices;
     }
-    { ProfScope ps(ctx, 2, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed)); }
-    if (full) {   // bottleneck layer: dW = W_A1^T M_a (+ W_T1^T M_t) from the two factors the GEMM above accumulated
+    { ProfScope ps(ctx, EONERF_PROF_WGRAD, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed)); }
+    if (full && !heads_units) {   // bottleneck layer: dW = W_A1^T M_a (+ W_T1^T M_t) from the two factors the GEMM above accumulated
         BottWgradArgs bw;
         bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_a1 = dptr(pl.a1_b);
         bw.w_t1 = transient ? flat + pl.t[pl.t_w[0]].offset : nullptr; bw.m_t = m_bott + 128 * 256; bw.db_t1 = transient ? dptr(pl.t_b[0]) : nullptr;
@@ -407,6 +476,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     ctx->cfg = *cfg;
     ctx->bf16 = cfg->precision == EONERF_BF16;
     { const char* e = getenv("EONERF_DETERMINISTIC"); ctx->deterministic = e && atoi(e) != 0; }
+    { const char* e = getenv("EONERF_PIPE_PARTIALS"); ctx->pipe_partials = ctx->deterministic || (e && atoi(e) != 0); }
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete ctx; return (int)hipErrorNoDevice; }
@@ -424,14 +494,25 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
         ctx->n_pipes = ctx->n_cu / PIPE_STAGES;
         ctx->pipe = ctx->bf16 && ctx->n_pipes >= 1 && !(e && atoi(e) == 0);
         if (!rc && ctx->pipe) rc = upload(ctx->pipe_wt, build_pipe_stream(ctx->pl));
-        if (!rc && ctx->pipe) rc = upload(ctx->bwd_full_heads, build_bwd_stream(ctx->pl, true, true, false, true, true));
-        if (!rc && ctx->pipe) rc = upload(ctx->bwd_rgb_heads, build_bwd_stream(ctx->pl, true, true, false, false, true));
-        if (!rc && ctx->pipe) rc = upload(ctx->bwd_dens_heads, build_bwd_stream(ctx->pl, true, false, true, false, true));
+        if (!rc && ctx->pipe) rc = upload(ctx->bwd_full_heads, build_bwd_stream(ctx->pl, true, true, false, true, 1));
+        if (!rc && ctx->pipe) rc = upload(ctx->bwd_rgb_heads, build_bwd_stream(ctx->pl, true, true, false, false, 1));
+        if (!rc && ctx->pipe) rc = upload(ctx->bwd_dens_heads, build_bwd_stream(ctx->pl, true, false, true, false, 1));
         if (!rc && ctx->pipe) rc = upload(ctx->ig_tail_wt, build_ig_tail_stream(ctx->pl));
+        {
+            const char* hp = getenv("EONERF_HEADS_PIPE");
+            ctx->n_pipes_heads = ctx->n_cu / HEADS_STAGES;
+            ctx->heads_pipe = ctx->pipe && ctx->n_pipes_heads >= 1 && hp && atoi(hp) != 0;
+            if (!rc && ctx->heads_pipe) rc = upload(ctx->bwd_full_heads2, build_bwd_stream(ctx->pl, true, true, false, true, 2));
+            if (!rc && ctx->heads_pipe) rc = upload(ctx->bwd_rgb_heads2, build_bwd_stream(ctx->pl, true, true, false, false, 2));
+            if (!rc && ctx->heads_pipe) rc = upload(ctx->heads_pipe_wt, build_heads_pipe_stream(ctx->pl));
+        }
         { const char* f = getenv("EONERF_PIPE_FAULT"); ctx->pipe_fault_stage = f ? atoi(f) : -1; }
         { const char* f = getenv("EONERF_PIPE_STAMPS");
           if (!rc && ctx->pipe && f && atoi(f)) rc = (int)hipMalloc(&ctx->pipe_stamps, (size_t)ctx->n_pipes * PIPE_STAGES * 128 * sizeof(unsigned long long)); }
     }
+    if (!rc) rc = (int)hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+    if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (!rc) rc = (int)hipMalloc(&ctx->dev_status, 64 * sizeof(int));
     if (!rc) rc = (int)hipMemset(ctx->dev_status, 0, 64 * sizeof(int));
     if (!rc) {
@@ -447,7 +528,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
 
 int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches) {
     if (!ctx || max_launches < 0) return EONERF_E_ARG;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < EONERF_PROF_KERNELS; ++k) {
         for (int s = 0; s < 2; ++s) {
             for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
             ctx->prof_ev[k][s].clear();
@@ -459,8 +540,14 @@ int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches) {
     return EONERF_OK;
 }
 
+const char* eonerf_profile_name(int kernel) {
+    static const char* const names[EONERF_PROF_KERNELS] = {"fwd_chain_camera", "bwd_chain_camera", "wgrad_gemm", "fwd_chain_sun", "bwd_chain_sun",
+                                                           "bwd_pipe_camera", "bwd_pipe_sun", "ig_tail_sun", "heads_pipe_camera"};
+    return kernel >= 0 && kernel < EONERF_PROF_KERNELS ? names[kernel] : nullptr;
+}
+
 int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launches) {
-    if (!ctx || kernel < 0 || kernel >= 6 || !total_ms || !launches) return EONERF_E_ARG;
+    if (!ctx || kernel < 0 || kernel >= EONERF_PROF_KERNELS || !total_ms || !launches) return EONERF_E_ARG;
     float sum = 0.f;
     for (int i = 0; i < ctx->prof_n[kernel]; ++i) {
         HIP_TRY(hipEventSynchronize(ctx->prof_ev[kernel][1][i]));
@@ -474,11 +561,14 @@ int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launc
 
 int eonerf_destroy(eonerf_ctx* ctx) {
     if (!ctx) return EONERF_E_ARG;
-    for (int k = 0; k < 6; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
-    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads); release(ctx->bwd_dens_heads); release(ctx->ig_tail_wt);
+    for (int k = 0; k < EONERF_PROF_KERNELS; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
+    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads); release(ctx->bwd_dens_heads); release(ctx->ig_tail_wt); release(ctx->bwd_full_heads2); release(ctx->bwd_rgb_heads2); release(ctx->heads_pipe_wt);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     if (ctx->pipe_stamps) (void)hipFree(ctx->pipe_stamps);
     if (ctx->dev_status) (void)hipFree(ctx->dev_status);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
     return EONERF_OK;
 }
@@ -498,10 +588,21 @@ int eonerf_param_info(const eonerf_ctx* ctx, int index, const char** name, size_
 int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     if (!ctx || !flat) return EONERF_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // pipelined backward: the camera pass reads the heads-only streams + the stage-stationary trunk weights
-    const int rc = ctx->pipe ? pack({&ctx->fwd_full, &ctx->bwd_full_heads, &ctx->bwd_rgb_heads, &ctx->pipe_wt}, flat, st)
-                             : pack({&ctx->fwd_full, &ctx->bwd_full, &ctx->bwd_rgb}, flat, st);
-    if (!rc) { ctx->weights_set = true; ctx->dens_dirty = true; ctx->full_ig_dirty = true; }
+    // pipelined backward: the camera pass reads the heads-only streams + the stage-stationary trunk weights; the density-only streams
+    // ride along once a step has used them (shadow pass on: they would be re-packed a few kernels later anyway)
+    std::vector<const DevStream*> v;
+    v.push_back(&ctx->fwd_full);
+    if (ctx->heads_pipe) { v.push_back(&ctx->bwd_full_heads2); v.push_back(&ctx->bwd_rgb_heads2); v.push_back(&ctx->heads_pipe_wt); }
+    else if (ctx->pipe) { v.push_back(&ctx->bwd_full_heads); v.push_back(&ctx->bwd_rgb_heads); }
+    else { v.push_back(&ctx->bwd_full); v.push_back(&ctx->bwd_rgb); }
+    if (ctx->pipe) v.push_back(&ctx->pipe_wt);
+    const bool with_dens = ctx->dens_used;
+    if (with_dens) {      // the same set ensure_density_streams packs
+        v.push_back(&ctx->fwd_dens); v.push_back(&ctx->bwd_dens);
+        if (ctx->pipe) { v.push_back(&ctx->bwd_dens_heads); v.push_back(&ctx->ig_tail_wt); }
+    }
+    const int rc = pack(v, flat, st);
+    if (!rc) { ctx->weights_set = true; ctx->dens_dirty = !with_dens; ctx->full_ig_dirty = true; }
     return rc;
 }
 
@@ -770,7 +871,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
     HIP_TRY(eo_launch_sampler(sa, st));
     const bool rgb_loss = train && !shadows && (flags & EONERF_F_RGB_LOSS);
-    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !od, train ? (rgb_loss ? 2 : 1) : 0, st, 0);
+    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !od, train ? (rgb_loss ? 2 : 1) : 0, st, EONERF_PROF_FWD_CHAIN_CAMERA, train);
     if (rc) return rc;
     CompositeArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -789,7 +890,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
         ss.n_pts = w.sun.n_pts; ss.n_pts_copy = nullptr;
         ss.px = w.sun.px; ss.py = w.sun.py; ss.pz = w.sun.pz; ss.tmid = w.sun.tmid; ss.delta = w.sun.delta; ss.simg = w.sun.simg;
         HIP_TRY(eo_launch_sampler(ss, st));
-        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train ? 1 : 0, st, 3);
+        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train ? 1 : 0, st, EONERF_PROF_FWD_CHAIN_SUN, train);
         if (rc) return rc;
         CompositeArgs cs = ca;
         cs.offsets = w.sun.offsets; cs.counts = w.sun.counts; cs.sigma = w.sun.sigma; cs.delta = w.sun.delta; cs.tmid = w.sun.tmid;
@@ -855,16 +956,15 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         if (pipe_sun) {      // heads (sigma row) -> pipelined trunk -> input-gradient tail
             ms.stream = ctx->bwd_dens_heads.data; ms.chunks = ctx->bwd_dens_heads.chunks; ms.n_chunks = ctx->bwd_dens_heads.n_chunks;
             ms.dy7_units = w.pipe.dy_in;
-            ProfScope ps(ctx, 4, st);
-            HIP_TRY(eo_launch_mlp_bwd(ms, true, false, true, false, grid, st, true));
-            const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, -1, st);
+            { ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_SUN, st); HIP_TRY(eo_launch_mlp_bwd(ms, true, false, true, false, grid, st, true)); }
+            const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, EONERF_PROF_BWD_PIPE_SUN, st, 0, true);
             if (rcp) return rcp;
             IgTailArgs ta;
             ta.n_pts = w.sun.n_pts; ta.p_pad = p_cap; ta.grd = w.sun.grd; ta.wt = ctx->ig_tail_wt.data;
             ta.px = w.sun.px; ta.py = w.sun.py; ta.pz = w.sun.pz; ta.g_pos = w.sun.g_pos;
-            HIP_TRY(eo_launch_ig_tail(ta, ctx->n_cu, st));
+            { ProfScope ps(ctx, EONERF_PROF_IG_TAIL_SUN, st); HIP_TRY(eo_launch_ig_tail(ta, ctx->n_cu, st)); }
         } else {
-            ProfScope ps(ctx, 4, st);
+            ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_SUN, st);
             HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, false, grid, st));
         }
         HIP_TRY(eo_launch_sun_depth_grad(cs, st));
@@ -880,21 +980,42 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     mc.n_pts = w.cam.n_pts; mc.p_pad = p_cap;
     const bool transient = shadows || !(flags & EONERF_F_RGB_LOSS);
     const bool pipe = ctx->pipe && w.pipe.dy_in;
-    const DevStream& bs = pipe ? (transient ? ctx->bwd_full_heads : ctx->bwd_rgb_heads) : (transient ? ctx->bwd_full : ctx->bwd_rgb);
+    const bool hpipe = pipe && ctx->heads_pipe && w.pipe.dy_heads;
+    const DevStream& bs = hpipe ? (transient ? ctx->bwd_full_heads2 : ctx->bwd_rgb_heads2)
+                        : pipe ? (transient ? ctx->bwd_full_heads : ctx->bwd_rgb_heads) : (transient ? ctx->bwd_full : ctx->bwd_rgb);
     mc.stream = bs.data; mc.chunks = bs.chunks; mc.n_chunks = bs.n_chunks;
     mc.sigma = w.cam.sigma; mc.albedo = w.cam.albedo; mc.ts = w.cam.ts; mc.tb = w.cam.tb;
     mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
     mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
-    mc.dy7_units = pipe ? w.pipe.dy_in : nullptr;
-    { ProfScope ps(ctx, 1, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st, pipe)); }
-    if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, 5, st, !shadows); if (rcp) return rcp; }
+    mc.dy7_units = hpipe ? w.pipe.dy_heads : (pipe ? w.pipe.dy_in : nullptr);
+    mc.dsig_out = hpipe ? w.cam.dsig : nullptr;
+    { ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_CAMERA, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st, hpipe ? 2 : (pipe ? 1 : 0))); }
+    if (hpipe) { const int rch = run_heads_pipe(ctx, w, w.cam, p_cap, d_flat, transient, st, 1, !shadows); if (rch) return rch; }
+    if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 2, !shadows && !hpipe); if (rcp) return rcp; }
 
+    // ---- the per-ray ambient head (27 -> 128 -> 3, fp32; ~35 us on a few dozen workgroups) runs on the context's side stream BESIDE
+    //      the weight-gradient GEMM: it reads the ray records and writes gradients nobody else touches (ambient parameters).  Forked here
+    //      -- behind the pipelined launches, which want every CU to themselves -- and joined before the call returns, so the caller's
+    //      stream order still covers everything.  (s == 1 without the shadow pass: the head is outside the graph, sat_rendering.py:269-276,294)
+    const bool ambient_side = shadows && !ctx->deterministic && ctx->side;
+    AmbientBwdArgs ag;
+    if (shadows) {
+        ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
+        ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
+    }
+    if (ambient_side) {
+        HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        HIP_TRY(eo_launch_ambient_bwd(ag, ctx->side, false));
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+    }
     {
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.queue, st, pipe, pipe && shadows, w.det.wgrad_part, pipe);
-        if (rcw) return rcw;
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.queue, st, pipe, pipe && shadows, w.det.wgrad_part, pipe,
+                                             hpipe ? w.pipe.dy_heads : nullptr);
+        if (rcw) { if (ambient_side) (void)hipStreamWaitEvent(st, ctx->ev_join, 0); return rcw; }
     }
 
-    // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
+    // ---- embeddings -----------------------------------------------------------------------------------------
     if (transient) {
         EmbGradArgs eg;
         eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays; eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0;
@@ -902,11 +1023,9 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         HIP_TRY(eo_launch_emb_grad(eg, st));
         if (eg.d_emb_rays) HIP_TRY(eo_launch_table_reduce(eg.d_emb_rays, img_idx, n_rays, 4, 4, ctx->cfg.n_images, 0, eg.d_emb, st));
     }
-    if (!shadows) return EONERF_OK;      // s == 1: rgb = albedo, the ambient head is outside the graph (sat_rendering.py:269-276,294)
-    AmbientBwdArgs ag;
-    ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
-    ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
-    HIP_TRY(eo_launch_ambient_bwd(ag, st, ctx->deterministic));
+    if (!shadows) return EONERF_OK;
+    if (ambient_side) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    else HIP_TRY(eo_launch_ambient_bwd(ag, st, ctx->deterministic));
     return EONERF_OK;
 }
 

@@ -25,6 +25,14 @@
 // (s_memrealtime): on expiry the stage raises *error, tells its workgroup through LDS and leaves -- the launch always drains.
 // Residency: grid = 7 x pipelines <= CU count, one workgroup per CU (LDS), roles taken from an arrival counter, so every pipeline
 // that processes samples is complete as soon as its last workgroup is scheduled.
+//
+// Round 3: the SAME stage body also runs the two wide layers between the heads and the trunk of the camera pass as a second launch shape
+// (k_heads_pipe, 2 stages x CUs / 2 pipelines, see eonerf_kernels.h): stage "AT1" takes [dY_A1; dY_T1] from the heads chain, multiplies
+// with [W_A1; W_T1]^T (no ReLU' -- the bottleneck has an identity activation) and accumulates both heads' first-layer weight gradients
+// against the bottleneck output; stage "bott" adds the sigma row's rank-1 term as a 17th k-group, applies ReLU'(X_8), accumulates the
+// bottleneck layer's weight gradient and writes dY_7 in unit order where the trunk launch reads it.  This removes the two largest
+// layers from the heads chain, the two largest jobs ([dA1; dT1] against X_8 and against the bottleneck output: 64 KB of operand reads per
+// 32 samples) from the weight-gradient GEMM, and the bottleneck factor product.
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
 
@@ -56,6 +64,9 @@ static_assert(DEPTH >= 2 && DEPTH <= NSLOT - 1, "prefetch distance");
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
 constexpr int CTRL_B = 64;
 constexpr int SMEM_B = NSLOT * SLOT_B + CTRL_B;
+constexpr int WSIG_B = 8 * 1024;                  // heads launch: the sigma row's A units (one 1-KiB unit per wave) behind the control words,
+constexpr int DSIG_B = 256;                       // then per ring slot one LDS-DMA piece of d sigma_pre (32 samples x fp32 used)
+constexpr int SMEM_HEADS_B = SMEM_B + WSIG_B + NSLOT * DSIG_B;
 constexpr int AUX_SC1 = 16, AUX_NT = 2;
 constexpr unsigned long long WATCHDOG_TICKS = 30000000ull;     // 0.3 s of the 100 MHz s_memrealtime clock
 
@@ -65,31 +76,41 @@ EO_DEV int wg_swz16(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16
 
 // ops a wave issues per step, in program order: [CTRL: 2 flag stores, 2 flag polls] .. 2 payload stores .. N_DMA pieces
 // second order (waves 4..7): N_DMA pieces .. 2 payload stores
+// XD: extra LDS-DMA pieces this wave issues per step with the others (the "bott" stage's d sigma_pre line, wave 1)
 constexpr int NST = 2;
-template <bool CTRL, bool ORDB> struct Cnt {
-    static constexpr int C = (CTRL ? 4 : 0) + NST + N_DMA;
+template <bool CTRL, bool ORDB, int XD = 0> struct Cnt {
+    static constexpr int ND = N_DMA + XD;
+    static constexpr int C = (CTRL ? 4 : 0) + NST + ND;
     // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s.
     // First order: the pieces of step s-2 and all of step s-1 are younger than those stores; second order: only step s-1
     // (first order, DMA side: the pieces of step s were issued DEPTH steps ago behind that step's stores, so DEPTH - 1 whole steps are
     //  younger; the stricter of the two conditions counts)
-    static constexpr int TOP = ORDB ? C : ((DEPTH - 1) * C < N_DMA + C ? (DEPTH - 1) * C : N_DMA + C);
+    static constexpr int TOP = ORDB ? C : ((DEPTH - 1) * C < ND + C ? (DEPTH - 1) * C : ND + C);
     // control wave (first order): tighter -- only the payload stores and the pieces of step s-1 stay outstanding, so the flag polls
     // of step s-1 are in (one step of latency instead of two: every stage then runs one step closer behind its producer)
-    static constexpr int TOP_CTRL = NST + N_DMA;
+    static constexpr int TOP_CTRL = NST + ND;
 };
 
 struct Stage {
-    int pipe, st, layer, n_k;
-    bool has_in;
+    int pipe, st, n_k;
+    bool has_in;               // false: stage 0, its input comes from an earlier launch (a.dy_in)
+    int x_row;                 // first row of the 256-row block of the activation slab this stage reads as its X image
+    const uint8_t* in_lin;     // != nullptr: the input tiles lie in a linear buffer [global step][16 KiB] written inside this launch (layer 5: dY_5 in the gradient slab)
+    uint8_t* out_lin;          // MODE 1 / 2 / 3: the linear output buffer [global step][16 KiB]
 };
 
 // MODE 0: the output goes to the next stage's ring; 1 (layer 6): the output goes, write-through like a ring slot, to its tile of the
 // dY_5 block of the gradient slab, which the layer-5 stage reads as its "ring" and the skip-column GEMM job reads later; 2 (layer 1): the
-// output dY_0 goes to its tile of the dY_0 block (streaming stores, nobody in this launch reads it)
-template <bool CTRL, int MODE, bool ORDB = false>
+// output dY_0 goes to its tile of the dY_0 block (streaming stores, nobody in this launch reads it); 3 (heads launch, "bott" stage): as 2
+// into a.dy_out, plus the sigma row's rank-1 term w_sigma x d sigma_pre as a 17th k-group of the dX product.
+// MASK = false (heads launch, "AT1" stage): the stage's output feeds an identity activation -- no ReLU' on dX.
+// XD = 1: this wave also copies the step's d sigma_pre line (MODE 3).
+template <bool CTRL, int MODE, bool ORDB = false, bool MASK = true, int XD = 0>
 EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int tid) {
-    constexpr bool HAS_OUT = MODE != 2;        // a consumer inside this launch (flags)
+    constexpr bool HAS_OUT = MODE == 0 || MODE == 1;   // a consumer inside this launch (flags)
     constexpr bool RING_OUT = MODE == 0;       // ... whose ring slots come back through the tail counter
+    constexpr bool SIGMA = MODE == 3;
+    static_assert(XD == 0 || SIGMA, "only the sigma stage has an extra piece");
     typedef PBf16 P;
     typedef P::U U;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
@@ -122,20 +143,31 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 
     // ---- sources ----
     const size_t n_tiles = (size_t)a.p_pad / TS;                       // sample tiles of the slabs
-    const int x_row = ACT_ROW_X1 + 256 * (S.layer - 1);                // input of layer `layer` = output of layer - 1
-    const uint8_t* x_base = reinterpret_cast<const uint8_t*>(a.act) + (size_t)x_row * n_tiles * SEG_B;     // block start (rows x_row.., tile 0)
-    uint8_t* const ring_in = a.rings + (size_t)(S.pipe * (PIPE_STAGES - 1) + (S.st - 1)) * PIPE_RING * IMG_B;
-    uint8_t* const ring_out = a.rings + (size_t)(S.pipe * (PIPE_STAGES - 1) + S.st) * PIPE_RING * IMG_B;
-    gu32* const f_in = (gu32*)(a.flags + (size_t)(S.pipe * (PIPE_STAGES - 1) + (S.st - 1)) * 64);          // [0] head, [32] tail
-    gu32* const f_out = (gu32*)(a.flags + (size_t)(S.pipe * (PIPE_STAGES - 1) + S.st) * 64);
+    const int n_edges = a.n_stages - 1;
+    const uint8_t* x_base = reinterpret_cast<const uint8_t*>(a.act) + (size_t)S.x_row * n_tiles * SEG_B;     // block start (rows x_row.., tile 0)
+    uint8_t* const ring_in = a.rings + (size_t)(S.pipe * n_edges + (S.st - 1)) * PIPE_RING * IMG_B;
+    uint8_t* const ring_out = a.rings + (size_t)(S.pipe * n_edges + S.st) * PIPE_RING * IMG_B;
+    gu32* const f_in = (gu32*)(a.flags + (size_t)(S.pipe * n_edges + (S.st - 1)) * 64);          // [0] head, [32] tail
+    gu32* const f_out = (gu32*)(a.flags + (size_t)(S.pipe * n_edges + S.st) * 64);
     // dummy flag traffic of the end stages (fixed op counts) goes to a line of the workgroup's own: 36 control waves storing to and
     // polling ONE shared line every step serialise at the memory side and stall the whole CU's vector-memory issue
-    gu32* const my_scratch = (gu32*)(a.scratch_word + (size_t)(S.pipe * PIPE_STAGES + S.st) * 32);
+    gu32* const my_scratch = (gu32*)(a.scratch_word + (size_t)(S.pipe * a.n_stages + S.st) * 32);
 
-    // unit-order tiles inside the gradient slab (one 16-KiB tile of a 256-row block per 32 samples, same footprint as the feature-major
-    // tile the chain + GEMM path keeps there): dY_{layer-1} as this stage's output (MODE 1, 2), dY_layer as its input (layer 5)
-    uint8_t* const grd_blk = reinterpret_cast<uint8_t*>(a.grd) + (size_t)(GRD_ROW_Y0 + (S.layer - 1) * 256) * n_tiles * SEG_B;
-    const uint8_t* const in_blk = reinterpret_cast<const uint8_t*>(a.grd) + (size_t)(GRD_ROW_Y0 + S.layer * 256) * n_tiles * SEG_B;
+    // linear unit-order buffers (one 16-KiB tile per 32 samples): this stage's output (MODE 1, 2: its tile of a 256-row block of the
+    // gradient slab, same footprint as the feature-major tile the chain + GEMM path keeps there; MODE 3: a.dy_out), its input (layer 5)
+    uint8_t* const grd_blk = S.out_lin;
+    const uint8_t* const in_blk = S.in_lin;
+
+    // sigma row (MODE 3): the A unit of the 17th k-group for this wave's m-tile lives in LDS (copied once; read into a free slot of the
+    // operand window late in every dX phase: kept in registers it pushed the stage over the 256-register budget), and d sigma_pre of the
+    // step's 32 samples arrives as a fifth LDS-DMA piece of ONE wave (XD), next to the ring slot it belongs to.
+    uint8_t* const wsig_lds = smem + SMEM_B + wave * 1024 + lane * 16;
+    uint8_t* const dsig_lds = smem + SMEM_B + WSIG_B;
+    if constexpr (SIGMA) {
+        const U wu = *reinterpret_cast<const U*>(a.wsig + ((size_t)wave * 64 + lane) * 16);
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), see wt above
+        *reinterpret_cast<U*>(wsig_lds) = wu;     // wave-private: the wave's own lgkmcnt orders this write and its reads
+    }
 
     // per-lane DMA source offsets of the X image: wave w stages rows 32w..32w+31, 16 rows per piece, chunks XOR-swizzled
     int x_voff[2];
@@ -150,7 +182,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
         // dY image: 16 pieces of 1 KiB, wave w copies pieces 2w, 2w+1
         const uint8_t* dsrc = !S.has_in ? a.dy_in + (size_t)g * IMG_B
-                            : (S.layer == 5 ? in_blk + (size_t)g * IMG_B : ring_in + (size_t)(k & (PIPE_RING - 1)) * IMG_B);
+                            : (in_blk ? in_blk + (size_t)g * IMG_B : ring_in + (size_t)(k & (PIPE_RING - 1)) * IMG_B);
         const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dsrc), 0, IMG_B, 0x00020000);
         if (S.has_in) {      // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
 #pragma unroll
@@ -170,6 +202,11 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(slot + IMG_B + (32 * wave + 16 * j) * SEG_B), 16,
                                                      x_voff[j], 0, 0, AUX_NT);
+        if constexpr (XD) {      // d sigma_pre of the step's samples: 128 B (lanes 32..63 fall outside the descriptor and bring zeros)
+            const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dsig) + (size_t)g * TS, 0, TS * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (__attribute__((address_space(3))) void*)(dsig_lds + (k & (NSLOT - 1)) * DSIG_B), 4,
+                                                     lane * 4, 0, 0, AUX_NT);
+        }
     };
 
     // ---- per-lane LDS read offsets ----
@@ -239,13 +276,13 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     for (int d = 0; d < DEPTH; ++d) issue(d < n_k ? d : n_k - 1);
     // step 0 only: nothing but the other two prologue steps is younger than its pieces (the loop's counted wait assumes the
     // steady state, where two whole steps of stores and pieces are)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * N_DMA) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * (N_DMA + XD)) : "memory");
 
     for (int k = 0; k < n_k; ++k) {
         uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
         // ---- top of the step ----
         const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTRL ? Cnt<CTRL, ORDB>::TOP_CTRL : Cnt<CTRL, ORDB>::TOP) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTRL ? Cnt<CTRL, ORDB, XD>::TOP_CTRL : Cnt<CTRL, ORDB, XD>::TOP) : "memory");
         const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         if (CTRL) {
             // the flag values polled in the previous step have landed behind the counted wait
@@ -293,17 +330,29 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             f32x16 acc = zero_acc();
             {
                 const uint8_t* bp = slot + lane * 16;
-                U fr[3];
+                // operand window: WIN reads ahead of the MFMA that consumes them (the sigma stage affords 2: its working set is at the
+                // 256-register limit, one unit more and the compiler spills a W^T unit to scratch and reloads it behind vmcnt(0))
+                constexpr int WIN = SIGMA ? 2 : 3;
+                U fr[WIN];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) fr[d] = lds_unit<P>(bp + d * 1024);
+                for (int d = 0; d < WIN; ++d) fr[d] = lds_unit<P>(bp + d * 1024);
 #pragma unroll
                 for (int kg = 0; kg < 16; ++kg) {
-                    if (!(EO_PABL & 2)) acc = P::mma(wt[kg], fr[kg % 3], acc);
-                    if (!(EO_PABL & 4) && kg + 3 < 16) fr[kg % 3] = lds_unit<P>(bp + (kg + 3) * 1024);
+                    if (!(EO_PABL & 2)) acc = P::mma(wt[kg], fr[kg % WIN], acc);
+                    if (!(EO_PABL & 4) && kg + WIN < 16) fr[kg % WIN] = lds_unit<P>(bp + (kg + WIN) * 1024);
+                    // 17th k-group (sigma row): its A unit comes out of LDS into the window slot that is no longer refilled
+                    if (SIGMA && kg == 16 - WIN) fr[kg % WIN] = lds_unit<P>(wsig_lds);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (SIGMA) {      // feature 256 = d sigma_pre: element 0 of the h == 0 lanes of the B unit
+                    U du = P::zero();
+                    const float ds = *reinterpret_cast<const float*>(dsig_lds + (k & (NSLOT - 1)) * DSIG_B + c * 4);
+                    du[0] = (__bf16)(h == 0 ? ds : 0.f);
+                    acc = P::mma(fr[(16 - WIN) % WIN], du, acc);
+                }
             }
-            u32x2 xm[4];
+            u32x2 xm[4] = {};
+            if constexpr (MASK)
             asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
                          "ds_read_b64_tr_b16 %1, %5\n\t"
                          "ds_read_b64_tr_b16 %2, %6\n\t"
@@ -316,6 +365,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #pragma unroll
             for (int s = 0; s < 8; ++s) {      // word s = accumulator registers 2s, 2s+1 <-> activation word s of the transposed reads
                 if (EO_PABL & 32) { w8[s] = xm[s >> 1][s & 1]; continue; }
+                if constexpr (!MASK) { w8[s] = cvt_pk_bf16(acc[2 * s], acc[2 * s + 1]); continue; }
                 uint32_t flags, r;
                 const uint32_t xw = xm[s >> 1][s & 1];
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(flags) : "v"(xw), "v"(0x00010001u));        // post-ReLU bf16 >= 0: 1 where > 0
@@ -332,7 +382,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                     if (MODE == 1) {
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
-                    } else {
+                    } else {      // read by a LATER launch (the GEMM's jobs; the trunk launch): streaming
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_NT);
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_NT);
                     }
@@ -424,7 +474,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         }
     }
     if (stamp && lane == 0) {
-        unsigned long long* o = a.stamps + ((size_t)(S.pipe * PIPE_STAGES + S.st) * 8 + wave) * 16;
+        unsigned long long* o = a.stamps + ((size_t)(S.pipe * a.n_stages + S.st) * 8 + wave) * 16;
         o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_slow; o[2] = t_top; o[3] = t_bar; o[4] = t_dx; o[5] = n_slow; o[6] = (unsigned long long)n_k;
         o[7] = 0; o[8] = t_is; o[9] = 0; o[10] = t_dw;
     }
@@ -441,7 +491,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) { db[ms] += __shfl_xor(db[ms], 16, 64); db[ms] += __shfl_xor(db[ms], 32, 64); }
     if (a.partials) {
-        float* pt = a.partials + (size_t)(S.pipe * PIPE_STAGES + S.st) * (256 * 256 + 256);
+        float* pt = a.partials + (size_t)(S.pipe * a.n_stages + S.st) * (256 * 256 + 256);
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -466,7 +516,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #else
     db += __shfl_xor(db, 32, 64);
     if (a.partials) {
-        float* pt = a.partials + (size_t)(S.pipe * PIPE_STAGES + S.st) * (256 * 256 + 256);
+        float* pt = a.partials + (size_t)(S.pipe * a.n_stages + S.st) * (256 * 256 + 256);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -474,42 +524,78 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         if (h == 0) pt[256 * 256 + 32 * wave + c] = db;
         return;
     }
-    float* dwp = a.d_flat + a.dw_off[S.st];
-    const int ld = a.dw_ld[S.st];
+    // rows >= 128 of a split stage (heads launch, "AT1": [albedo head; transient head]) belong to a second tensor; wave-uniform choice
+    const bool hi = a.split[S.st] && wave >= 4;
+    if (hi && a.skip_hi[S.st]) return;             // transient head outside the autograd graph: its rows carried zeros
+    float* dwp = a.d_flat + (hi ? a.dw_off2[S.st] : a.dw_off[S.st]);
+    float* dbp = a.d_flat + (hi ? a.db_off2[S.st] : a.db_off[S.st]);
+    const int ld = hi ? a.dw_ld2[S.st] : a.dw_ld[S.st];
+    const int row0 = hi ? 32 * (wave - 4) : 32 * wave;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) atomicAdd(dwp + (size_t)(32 * wave + acc_row(g, h)) * ld + 32 * j + c, dw[j][g]);
-    if (h == 0) atomicAdd(a.d_flat + a.db_off[S.st] + 32 * wave + c, db);
+        for (int g = 0; g < 16; ++g) atomicAdd(dwp + (size_t)(row0 + acc_row(g, h)) * ld + 32 * j + c, dw[j][g]);
+    if (h == 0) atomicAdd(dbp + row0 + c, db);
 #endif
 }
 
-__global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x;
+// role (pipeline, stage) of this workgroup from the arrival counter, step count of its pipeline; false: nothing to do
+EO_DEV bool take_role(const BwdPipeArgs& a, uint8_t* smem, int tid, Stage& S) {
     int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B);
     if (tid == 0) { ctl[0] = 0; ctl[1] = atomicAdd(a.role_counter, 1); }
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(ctl[1]);
-    Stage S;
-    S.pipe = role / PIPE_STAGES; S.st = role % PIPE_STAGES;
-    if (S.pipe >= a.n_pipes) return;
-    S.layer = 7 - S.st;
+    S.pipe = role / a.n_stages; S.st = role % a.n_stages;
+    if (S.pipe >= a.n_pipes) return false;
     const int n_pts = *a.n_pts;
     // whole 256-sample tiles, as the chain kernels process them (dead samples carry zero gradients): the GEMM jobs that follow read
     // the saved dY_0 / dY_5 rows of every sample tile up to that bound
     const int n_steps = (n_pts + 255) / 256 * (256 / TS);
     S.n_k = S.pipe < n_steps ? (n_steps - S.pipe + a.n_pipes - 1) / a.n_pipes : 0;
     S.has_in = S.st > 0;
-    if (S.n_k == 0) return;
+    S.in_lin = nullptr; S.out_lin = nullptr;
+    return S.n_k > 0;
+}
+
+__global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    Stage S;
+    if (!take_role(a, smem, tid, S)) return;
+    const int layer = 7 - S.st;
+    const size_t n_tiles = (size_t)a.p_pad / TS;
+    S.x_row = ACT_ROW_X1 + 256 * (layer - 1);                          // input of layer `layer` = output of layer - 1
+    uint8_t* const grd = reinterpret_cast<uint8_t*>(a.grd);
+    if (layer == 5) S.in_lin = grd + (size_t)(GRD_ROW_Y0 + 5 * 256) * n_tiles * SEG_B;                         // dY_5 tiles, written by the layer-6 stage
+    if (layer == 6 || layer == 1) S.out_lin = grd + (size_t)(GRD_ROW_Y0 + (layer - 1) * 256) * n_tiles * SEG_B;    // dY_5 / dY_0 tiles
     const int wv = tid >> 6;
     // wave 0: control wave (first order); waves 1..3: first order; waves 4..7 (the second wave of every SIMD): second order
-    if (S.layer == 6) {
+    if (layer == 6) {
         if (wv == 0) run_stage<true, 1>(a, S, smem, tid); else if (wv < 4) run_stage<false, 1>(a, S, smem, tid); else run_stage<false, 1, true>(a, S, smem, tid);
-    } else if (S.layer == 1) {
+    } else if (layer == 1) {
         if (wv == 0) run_stage<true, 2>(a, S, smem, tid); else if (wv < 4) run_stage<false, 2>(a, S, smem, tid); else run_stage<false, 2, true>(a, S, smem, tid);
     } else {
         if (wv == 0) run_stage<true, 0>(a, S, smem, tid); else if (wv < 4) run_stage<false, 0>(a, S, smem, tid); else run_stage<false, 0, true>(a, S, smem, tid);
+    }
+}
+
+// heads launch (camera pass): stage 0 "AT1", stage 1 "bott" (see eonerf_kernels.h)
+__global__ __launch_bounds__(NT) void k_heads_pipe(BwdPipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    Stage S;
+    if (!take_role(a, smem, tid, S)) return;
+    const int wv = tid >> 6;
+    if (S.st == 0) {
+        S.x_row = ACT_ROW_BOTT;                    // the bottleneck output: input of both heads' first layers
+        if (wv == 0) run_stage<true, 0, false, false>(a, S, smem, tid); else if (wv < 4) run_stage<false, 0, false, false>(a, S, smem, tid); else run_stage<false, 0, true, false>(a, S, smem, tid);
+    } else {
+        S.x_row = ACT_ROW_X1 + 256 * 7;            // X_8: input of the bottleneck and sigma layers
+        S.out_lin = a.dy_out;
+        if (wv == 0) run_stage<true, 3>(a, S, smem, tid);
+        else if (wv == 1) run_stage<false, 3, false, true, 1>(a, S, smem, tid);      // also copies d sigma_pre
+        else if (wv < 4) run_stage<false, 3>(a, S, smem, tid);
+        else run_stage<false, 3, true>(a, S, smem, tid);
     }
 }
 
@@ -520,29 +606,44 @@ __global__ __launch_bounds__(256) void k_pipe_reduce(BwdPipeArgs a) {
     const int live = n_steps < a.n_pipes ? n_steps : a.n_pipes;
     float acc = 0.f, accb = 0.f;
     for (int p = 0; p < live; ++p) {
-        const float* pt = a.partials + (size_t)(p * PIPE_STAGES + st) * (256 * 256 + 256);
+        const float* pt = a.partials + (size_t)(p * a.n_stages + st) * (256 * 256 + 256);
         acc += pt[row * 256 + col];
         if (col == 0) accb += pt[256 * 256 + row];
     }
-    a.d_flat[a.dw_off[st] + (size_t)row * a.dw_ld[st] + col] += acc;
-    if (col == 0) a.d_flat[a.db_off[st] + row] += accb;
+    const bool hi = a.split[st] && row >= 128;
+    if (hi && a.skip_hi[st]) return;
+    const int r = hi ? row - 128 : row;
+    a.d_flat[(hi ? a.dw_off2[st] : a.dw_off[st]) + (size_t)r * (hi ? a.dw_ld2[st] : a.dw_ld[st]) + col] += acc;
+    if (col == 0) a.d_flat[(hi ? a.db_off2[st] : a.db_off[st]) + r] += accb;
 }
 
 }  // namespace
 
 hipError_t eo_launch_pipe_reduce(const BwdPipeArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_pipe_reduce, dim3(256, PIPE_STAGES), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pipe_reduce, dim3(256, a.n_stages), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
 size_t eo_bwd_pipe_lds_bytes() { return SMEM_B; }
 
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st) {
+    if (a.n_stages != PIPE_STAGES) return hipErrorInvalidValue;
     static EoAttrOnce attr;
     {
         const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B); });
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_bwd_pipe, dim3(a.n_pipes * PIPE_STAGES), dim3(NT), SMEM_B, st, a);
+    return hipGetLastError();
+}
+
+hipError_t eo_launch_heads_pipe(const BwdPipeArgs& a, hipStream_t st) {
+    if (a.n_stages != HEADS_STAGES || !a.dy_out || !a.dsig || !a.wsig) return hipErrorInvalidValue;
+    static EoAttrOnce attr;
+    {
+        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_heads_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_HEADS_B); });
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_heads_pipe, dim3(a.n_pipes * HEADS_STAGES), dim3(NT), SMEM_HEADS_B, st, a);
     return hipGetLastError();
 }

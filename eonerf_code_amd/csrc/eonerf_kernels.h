@@ -78,6 +78,8 @@ struct MlpFwdArgs {
     float *sigma, *albedo, *ts, *tb;   // outputs: sigma[p_pad], albedo[3][p_pad], ts[p_pad], tb[p_pad]
     void* act;                     // TRAIN: [ACT_ROWS][p_pad] of P::act_t
     uint32_t* masks;               // TRAIN: [MASK_SLOTS][p_pad][2][4] ReLU masks
+    int mask_from;                 // TRAIN: first mask slot the backward will read (the pipelined trunk backward derives ReLU' from the saved
+                                   // activations themselves: slots below are not written)
 };
 
 struct MlpBwdArgs {
@@ -93,7 +95,9 @@ struct MlpBwdArgs {
     float* g_emb;                  // FULL: [p_pad][4] grad wrt the per-sample transient embedding
     const float *px, *py, *pz;     // INPUT_GRAD: positions (encoder derivative)
     float* g_pos;                  // INPUT_GRAD: [3][p_pad]
-    uint8_t* dy7_units;            // PIPE: dY_7 in B-operand unit order [step of 32 samples][16 KiB]; the trunk is left to eonerf_bwd_pipe.hip
+    uint8_t* dy7_units;            // PIPE 1: dY_7, PIPE 2: [dY_A1; dY_T1], in B-operand unit order [step of 32 samples][16 KiB]; the rest of the
+                                   // dX chain is left to eonerf_bwd_pipe.hip
+    float* dsig_out;               // PIPE 2: [p_pad] d sigma_pre per sample for the heads pipeline's "bott" stage
 };
 
 // One weight-gradient GEMM job:  dW[m][col_map[n]] += sum_p  dY^T[m][p] * X^T[n][p]
@@ -115,32 +119,47 @@ struct WgradJob {
     int a_units;          // bf16: a's tiles are in B-operand unit order (written by eonerf_bwd_pipe.hip), not feature-major rows
 };
 
-// ---- layer-pipelined trunk backward (eonerf_bwd_pipe.hip) ----
+// ---- layer-pipelined backward (eonerf_bwd_pipe.hip): two launch shapes built from one stage body ----
+//   trunk : 7 stages = trunk layers 7..1 (input dY_7, X images X_7..X_1), floor(CUs / 7) pipelines
+//   heads : 2 stages = the two wide layers between the heads and the trunk (camera pass only), CUs / 2 pipelines:
+//             stage 0 "AT1"  [dY_A1; dY_T1] (256) -> d bottleneck   X image = the bottleneck output (identity activation: no mask),
+//                            dW = the first layers of the albedo head (rows 0..127) and of the transient head (rows 128..255, bottleneck
+//                            columns; its 4 embedding columns stay with the GEMM)
+//             stage 1 "bott" d bottleneck (+ the sigma row's rank-1 term) -> dY_7 = (W_bott^T d_bott + w_sigma d sigma_pre) .* (X_8 > 0),
+//                            written in unit order to the buffer the trunk launch reads; dW = the bottleneck layer
 constexpr int PIPE_STAGES = 7;        // trunk layers 7..1, one workgroup each
+constexpr int HEADS_STAGES = 2;
+constexpr int PIPE_MAX_STAGES = 7;
 constexpr int PIPE_TS = 32;           // samples per step = one sample tile of the bf16 slabs
 constexpr int PIPE_RING = 16;         // slots (steps) of an inter-stage ring
 constexpr int PIPE_UNIT_B = 16 * 1024;   // one step of a 256-feature tensor in B-operand unit order [k-group 16][lane 64][16 B]
 struct BwdPipeArgs {
     const int* n_pts; int p_pad;
     int n_pipes;
-    const uint8_t* wt;        // stage-stationary W_l^T: [stage 7][m-tile 8][k-group 16][lane 64][16 B] bf16 (eonerf_pack.cpp)
-    const uint8_t* dy_in;     // dY_7 of every step in unit order [step][16 KiB] (written by the heads part of the backward chain)
+    int n_stages;             // PIPE_STAGES (trunk launch) or HEADS_STAGES (heads launch)
+    const uint8_t* wt;        // stage-stationary W^T: [stage][m-tile 8][k-group 16][lane 64][16 B] bf16 (eonerf_pack.cpp)
+    const uint8_t* dy_in;     // input of stage 0 of every step in unit order [step][16 KiB] (written by an earlier launch)
     const void* act;          // activation slab (block-major feature-major tiles, eonerf_common.h)
-    const uint32_t* masks;
-    void* grd;                // gradient slab: the stages of layers 6 and 1 also save dY_5 / dY_0 for the remaining GEMM jobs
-    uint8_t* rings;           // [pipeline][edge 6][PIPE_RING][16 KiB]
-    uint32_t* flags;          // [pipeline][edge 6][64]: head counter at [0], tail counter at [32] (own 128-B lines); zeroed per launch
+    void* grd;                // gradient slab (trunk launch): the stages of layers 6 and 1 save dY_5 / dY_0 for the remaining GEMM jobs
+    uint8_t* rings;           // [pipeline][edge n_stages - 1][PIPE_RING][16 KiB]
+    uint32_t* flags;          // [pipeline][edge][64]: head counter at [0], tail counter at [32] (own 128-B lines); zeroed per launch
     uint32_t* scratch_word;   // [workgroup][32]: sink / source of the end stages' fixed-count dummy flag traffic (a line per workgroup)
     int* role_counter;        // zeroed per launch
-    int* error;               // watchdog bits, zeroed per launch
+    int* error;               // the context's STICKY status word: watchdog bits are OR-ed in, never cleared by a launch
     float* d_flat;
-    size_t dw_off[PIPE_STAGES], db_off[PIPE_STAGES];
-    int dw_ld[PIPE_STAGES];
+    // weight / bias gradient destinations per stage; rows >= 128 of a stage with split != 0 go to the second destination (row - 128)
+    size_t dw_off[PIPE_MAX_STAGES], db_off[PIPE_MAX_STAGES], dw_off2[PIPE_MAX_STAGES], db_off2[PIPE_MAX_STAGES];
+    int dw_ld[PIPE_MAX_STAGES], dw_ld2[PIPE_MAX_STAGES], split[PIPE_MAX_STAGES], skip_hi[PIPE_MAX_STAGES];   // skip_hi: rows >= 128 carry no gradient (transient head outside the graph)
     unsigned long long* stamps;   // diagnostics (EONERF_PIPE_STAMPS): [workgroup role][2 waves][8] cycle sums, or nullptr
     float* partials;          // deterministic mode: [pipeline][stage][256 x 256 dW | 256 db] instead of the atomic flush (reduced in pipeline order)
     int fault_stage;          // test hook (EONERF_PIPE_FAULT): this stage never publishes its tiles -> every watchdog downstream must fire; -1 = off
+    // heads launch only
+    uint8_t* dy_out;          // dY_7 of every step in unit order [step][16 KiB]: the trunk launch's dy_in
+    const float* dsig;        // [p_pad] d sigma_pre per sample (written by the heads chain)
+    const uint8_t* wsig;      // [m-tile 8][lane 64][16 B]: the sigma row as the A units of a 17th k-group (k = 0: w_sigma[32 mt + r])
 };
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st);
+hipError_t eo_launch_heads_pipe(const BwdPipeArgs& a, hipStream_t st);
 // input-gradient tail of a pipelined density pass (eonerf_ig_tail.hip)
 struct IgTailArgs {
     const int* n_pts; int p_pad;
@@ -153,7 +172,8 @@ hipError_t eo_launch_ig_tail(const IgTailArgs& a, int n_wg, hipStream_t st);
 size_t eo_bwd_pipe_lds_bytes();
 
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);
-hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, bool pipe = false);
+// pipe: 0 = the whole dX chain; 1 = stop at dY_7 (the trunk is pipelined); 2 (camera pass) = stop at [dY_A1; dY_T1] (heads + trunk pipelined)
+hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, int pipe = 0);
 constexpr int WGRAD_MAX_JOBS = 32;     // <= 31 used (fp32 chain + GEMM path, full model); the table must fit the 4-KiB kernel-argument segment
 static_assert(sizeof(WgradJob) * WGRAD_MAX_JOBS + 8 <= 4096, "job table exceeds the kernel-argument segment");
 struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int items; };   // by value in the kernel-argument segment; jobs sorted heaviest first

@@ -25,9 +25,13 @@ template <class P> EO_DEV typename P::U small_unit(const float (&v)[4], int h) {
 }
 
 // TRANS = false: the transient head is outside the autograd graph (see k_mlp_fwd MODE 2): its layers are skipped.
-// PIPE (camera pass, bf16): the kernel stops at dY_7 and hands it, in B-operand unit order, to the layer-pipelined trunk
-// backward (eonerf_bwd_pipe.hip), which computes dY_6..dY_0 AND the trunk weight gradients without parking dY in HBM.
-template <class P, bool FULL, bool IG, bool TRANS, bool PIPE = false>
+// PIPE 1 (bf16): the kernel stops at dY_7 and hands it, in B-operand unit order, to the layer-pipelined trunk backward
+// (eonerf_bwd_pipe.hip), which computes dY_6..dY_0 AND the trunk weight gradients without parking dY in HBM.
+// PIPE 2 (bf16, camera pass): the kernel stops one layer pair earlier, at [dY_A1; dY_T1] -- the two wide layers behind it (both heads'
+// first layers -> d bottleneck, [d bottleneck; d sigma_pre] -> dX_8) run as the heads launch of the pipelined backward, which also
+// accumulates their weight gradients.  What stays here: the narrow head layers (transient tail, albedo output layer), the four
+// embedding columns of the transient head's first layer (d embedding), and d sigma_pre per sample for the pipeline's sigma term.
+template <class P, bool FULL, bool IG, bool TRANS, int PIPE = 0>
 __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     constexpr int SLOT = FwdSlot<P>::BYTES;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -72,11 +76,16 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             put_slice(P(), dst, mt, s, v);
             sw.stage(grd_row + 32 * mt, s, v);
         };
+        // PIPE 2: dY_A1 / dY_T1 are handed on in unit order only (their weight-gradient products run in the heads pipeline)
+        auto grad_epi_units = [&](U* dst, int mt, const f32x16& accv, int s) {
+            put_slice(P(), dst, mt, s, mask_slice(P(), accv, s, mt, mb[mt >> 1]));
+        };
 
         // ---------------- output heads: activation derivatives from the saved forward outputs ----------------
         const float sg = live ? a.sigma[p] : 0.f;
         float dsig[4] = {live ? a.g_sigma[p] * (1.f - expf(-sg)) : 0.f, 0.f, 0.f, 0.f};    // softplus' = 1 - exp(-softplus)
         sw.elem(GRD_ROW_SIG, h == 0 ? dsig[0] : 0.f);
+        if constexpr (PIPE == 2) { if (h == 0) a.dsig_out[p] = dsig[0]; }      // (p < p_pad: tiles are whole; dead samples carry 0)
 
         U D[HKG], N[HKG];
         if constexpr (FULL) {
@@ -113,14 +122,42 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v, s); });
                 load_mask(9, 2);
+                if constexpr (PIPE == 2)
+                    run_layer<P, SLOT, QKG, 4, false>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
+                        [&](int mt, const f32x16& v, int s) { grad_epi_units(TB, mt, v, s); });                    // TB = dY_T1
+                else
                 run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TB, GRD_ROW_T1, true, mt, v, s); });        // TB = dY_T1
             }
             // ---- albedo head backwards: albedo_pre -> A1 ----
             const U u_al = small_unit<P>(dalb, h);
             load_mask(8, 2);
+            if constexpr (PIPE == 2)
+                run_layer<P, SLOT, 1, 4, false>(ws, mid, lane, h, [&](int) { return u_al; },
+                    [&](int mt, const f32x16& v, int s) { grad_epi_units(DA1, mt, v, s); });
+            else
             run_layer<P, SLOT, 1, 4, false, NST>(ws, mid, lane, h, [&](int) { return u_al; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(DA1, GRD_ROW_A1, true, mt, v, s); });
+            if constexpr (PIPE == 2) {
+                if constexpr (TRANS) {
+                    // ---- dY_T1 -> d embedding: the four embedding columns of the transient head's first layer (one m-tile, rows 0..3) ----
+                    run_layer<P, SLOT, QKG, 1, false>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
+                        [&](int, const f32x16& v, int s) {
+                            if (s == 0 && h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
+                        });
+                }
+                // this wave's 32 samples = step (tile * 8 + wave) of the heads pipeline: units 0..7 = dY_A1, 8..15 = dY_T1 (zeros when the
+                // transient head is outside the graph)
+                uint8_t* dst = a.dy7_units + ((size_t)tile * (P::TILE / 32) + wave) * 16 * 1024 + lane * 16;
+#pragma unroll
+                for (int kg = 0; kg < QKG; ++kg) {
+                    *reinterpret_cast<U*>(dst + kg * 1024) = DA1[kg];
+                    if constexpr (TRANS) *reinterpret_cast<U*>(dst + (QKG + kg) * 1024) = TB[kg];
+                    else *reinterpret_cast<U*>(dst + (QKG + kg) * 1024) = P::zero();
+                }
+                sw.drain();
+                continue;
+            }
             if constexpr (TRANS) {
                 // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
                 run_layer<P, SLOT, 2 * QKG, 9, false>(ws, mid, lane, h,
@@ -137,7 +174,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
-            if constexpr (PIPE) {
+            if constexpr (PIPE == 1) {
                 run_layer<P, SLOT, HKG + 1, 8, false>(ws, mid, lane, h,
                     [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
                     [&](int mt, const f32x16& v, int s) { put_slice(P(), D, mt, s, mask_slice(P(), v, s, mt, mb[mt >> 1])); });
@@ -154,7 +191,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         } else {
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
-            if constexpr (PIPE) {      // density pass: dY_7 = W_sigma^T d sigma_pre .* relu'; trunk and input gradient follow elsewhere
+            if constexpr (PIPE == 1) {      // density pass: dY_7 = W_sigma^T d sigma_pre .* relu'; trunk and input gradient follow elsewhere
                 run_layer<P, SLOT, 1, 8, false>(ws, mid, lane, h, [&](int) { return u_sg; },
                     [&](int mt, const f32x16& v, int s) { put_slice(P(), D, mt, s, mask_slice(P(), v, s, mt, mb[mt >> 1])); });
                 uint8_t* dst = a.dy7_units + ((size_t)tile * (P::TILE / 32) + wave) * 16 * 1024 + lane * 16;
@@ -232,7 +269,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
 #endif
 }
 
-template <class P, bool FULL, bool IG, bool TRANS, bool PIPE = false>
+template <class P, bool FULL, bool IG, bool TRANS, int PIPE = 0>
 hipError_t launch(const MlpBwdArgs& a, int grid, hipStream_t st) {
     constexpr int SMEM = 2 * FwdSlot<P>::BYTES + SlabWriter<P, GrdMap>::LDS_BYTES;
     static EoAttrOnce attr;
@@ -255,13 +292,17 @@ template <class P> hipError_t dispatch(const MlpBwdArgs& a, bool full, bool inpu
 
 // the variants the callers need: camera pass (all heads, with / without the transient head in the graph, no input grad),
 // shadow pass / query_density (density only, with input grad) and the differentiable EONerfMLP.forward (all heads + input grad)
-hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, bool pipe) {
+hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, int pipe) {
     if (!full && !input_grad) return hipErrorInvalidValue;
     if (full && input_grad && !transient) return hipErrorInvalidValue;
+    if (pipe == 2) {      // camera pass, narrow head layers only; the wide layers and the trunk run in eonerf_bwd_pipe.hip
+        if (!bf16 || !a.dy7_units || !a.dsig_out || !full || input_grad) return hipErrorInvalidValue;
+        return transient ? launch<PBf16, true, false, true, 2>(a, grid, st) : launch<PBf16, true, false, false, 2>(a, grid, st);
+    }
     if (pipe) {      // heads only; the trunk runs in eonerf_bwd_pipe.hip (bf16), the input gradient in eonerf_ig_tail.hip
         if (!bf16 || !a.dy7_units || (full && input_grad)) return hipErrorInvalidValue;
-        if (!full) return launch<PBf16, false, true, false, true>(a, grid, st);
-        return transient ? launch<PBf16, true, false, true, true>(a, grid, st) : launch<PBf16, true, false, false, true>(a, grid, st);
+        if (!full) return launch<PBf16, false, true, false, 1>(a, grid, st);
+        return transient ? launch<PBf16, true, false, true, 1>(a, grid, st) : launch<PBf16, true, false, false, 1>(a, grid, st);
     }
     return bf16 ? dispatch<PBf16>(a, full, input_grad, transient, grid, st) : dispatch<PF32>(a, full, input_grad, transient, grid, st);
 }

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         };
         auto save_mask = [&](int mask_slot, int nwords) {
             if constexpr (TRAIN) {
+                if (mask_slot < a.mask_from) return;      // wave-uniform
                 uint32_t* mp = a.masks + ((size_t)mask_slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4;
                 if (nwords == 4) *reinterpret_cast<u32x4*>(mp) = u32x4{mbits[0], mbits[1], mbits[2], mbits[3]};
                 else *reinterpret_cast<u32x2*>(mp) = u32x2{mbits[0], mbits[1]};

@@ -129,7 +129,7 @@ PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full) {
 }
 
 // Backward chain: dX^T = W^T dY^T.  "row" = INPUT feature of the forward layer, "slot" = OUTPUT feature.
-PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient, bool heads_only) {
+PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient, int heads) {
     PackedStream s;
     const int KF = bf16 ? 16 : 8;
     const int HKG = 256 / KF, QKG = 128 / KF;
@@ -146,6 +146,13 @@ PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool 
         }
         // d albedo_pre (slots 0..2) -> A1 (128)
         transposed(pl.a2_w, 3, 128, 1, 4);
+        if (heads == 2) {
+            // dY_T1 (slots 0..127) -> d embedding: rows 0..3 = the embedding columns 256..259 of the transient head's first layer
+            if (transient)
+                append_layer(s, bf16, PackLayer{QKG, 1, false,
+                    [&](int row, int slot) { return (row < 4 && slot < 128) ? pl.at(pl.t_w[0], slot, 256 + row) : -1; }, nullptr});
+            return s;
+        }
         if (transient) {
             // [dY_A1 (slots 0..127), dY_T1 (slots 128..255)] -> bottleneck rows 0..255, embedding rows 256..259
             append_layer(s, bf16, PackLayer{2 * QKG, 9, false,
@@ -163,7 +170,7 @@ PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool 
         append_layer(s, bf16, PackLayer{1, 8, false,
             [&](int row, int slot) { return slot == 0 ? pl.at(pl.sig_w, 0, row) : -1; }, nullptr});
     }
-    if (heads_only) return s;
+    if (heads == 1) return s;
     for (int l = 7; l >= 1; --l) {
         if (l == 5) {
             append_layer(s, bf16, PackLayer{HKG, input_grad ? 10 : 8, false,
@@ -199,6 +206,35 @@ PackedStream build_pipe_stream(const ParamLayout& pl) {
                 }
         s.bytes += 8 * 16 * 1024;
     }
+    s.chunks.push_back(ChunkDesc{0, (uint32_t)s.bytes});
+    return s;
+}
+
+// Heads launch of the pipelined backward (see eonerf_pack.h): A units of dX = W^T dY, lane (r,h) of m-tile mt: input feature 32 mt + r,
+// k elements = output features PBf16::feat(kg, h, e)
+PackedStream build_heads_pipe_stream(const ParamLayout& pl) {
+    PackedStream s;
+    for (int st = 0; st < 2; ++st) {
+        for (int mt = 0; mt < 8; ++mt)
+            for (int kg = 0; kg < 16; ++kg)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 31, h = lane >> 5;
+                    for (int e = 0; e < 8; ++e) {
+                        const int o = PBf16::feat(kg, h, e), i = 32 * mt + r;
+                        const int idx = st == 1 ? pl.at(pl.bot_w, o, i) : (o < 128 ? pl.at(pl.a1_w, o, i) : pl.at(pl.t_w[0], o - 128, i));
+                        s.e16.push_back(PackEntry{(uint32_t)(s.bytes + (size_t)(mt * 16 + kg) * 1024 + lane * 16 + e * 2), idx});
+                    }
+                }
+        s.bytes += 8 * 16 * 1024;
+    }
+    // 17th k-group of the "bott" stage: feature 256 = d sigma_pre -> only k element (h = 0, e = 0) carries a weight
+    for (int mt = 0; mt < 8; ++mt)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int r = lane & 31, h = lane >> 5;
+            for (int e = 0; e < 8; ++e)
+                s.e16.push_back(PackEntry{(uint32_t)(s.bytes + (size_t)mt * 1024 + lane * 16 + e * 2), (h == 0 && e == 0) ? pl.at(pl.sig_w, 0, 32 * mt + r) : -1});
+        }
+    s.bytes += 8 * 1024;
     s.chunks.push_back(ChunkDesc{0, (uint32_t)s.bytes});
     return s;
 }

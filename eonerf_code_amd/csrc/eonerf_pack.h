@@ -42,9 +42,14 @@ struct PackLayer {
 
 void append_layer(PackedStream& s, bool bf16, const PackLayer& L);
 PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full);
-// heads_only: the stream ends behind the [d bottleneck, d sigma_pre] -> dX8 layer (the chain kernel's PIPE variant leaves the trunk
-// to eonerf_bwd_pipe.hip; the stream is consumed cyclically, so it must hold exactly the layers one tile walks)
-PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient = true, bool heads_only = false);
+// heads: 0 = the whole chain; 1 = the stream ends behind the [d bottleneck, d sigma_pre] -> dX8 layer (the chain kernel's PIPE 1 variant
+// leaves the trunk to eonerf_bwd_pipe.hip); 2 = only the narrow head layers and the embedding columns (PIPE 2: the two wide layers run in
+// the heads launch of the pipelined backward).  The stream is consumed cyclically, so it must hold exactly the layers one tile walks.
+PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient = true, int heads = 0);
 PackedStream build_pipe_stream(const ParamLayout& pl);      // stage-stationary W_l^T of trunk layers 7..1 (eonerf_bwd_pipe.hip), bf16
+// heads launch of the pipelined backward: stage 0 [W_A1; W_T1 (bottleneck columns)]^T, stage 1 W_bott^T, then the sigma row as the A
+// units of a 17th k-group ([m-tile 8][lane][16 B], offset HEADS_WSIG_OFF)
+PackedStream build_heads_pipe_stream(const ParamLayout& pl);
+constexpr size_t HEADS_WSIG_OFF = (size_t)2 * 8 * 16 * 1024;
 PackedStream build_ig_tail_stream(const ParamLayout& pl);   // W_0^T and the skip columns of W_5^T as A units (eonerf_ig_tail.hip), bf16
 int enc_col_of_slot(bool bf16, int slot);      // reference encoding column (mlp.py:190-208) of an encoding slot, -1 = pad

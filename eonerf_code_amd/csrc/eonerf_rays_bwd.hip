@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt,
         }
     }
     part = wave_sum(part);
+    if (kind == 1 && blockIdx.x == 0 && threadIdx.x == 0) part += 1.5f;      // the constant 3/2 of the beta term (metrics.py:20)
     if ((threadIdx.x & 63) == 0) atomicAdd(loss, part);
 }
 

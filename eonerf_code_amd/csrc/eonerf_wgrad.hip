@@ -186,8 +186,11 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
     };
     typedef std::integral_constant<bool, false> Rows;
     typedef std::integral_constant<bool, P::IS_BF16> Units;
-    if (job.a_units) {      // A = a whole 256-row tile (two pieces per wave), B = the 64 encoding rows (two pieces on waves 0 and 1)
-        if (n_dma == 4) k_loop(std::integral_constant<int, 4>(), Units()); else k_loop(std::integral_constant<int, 2>(), Units());
+    if (job.a_units) {      // A = a whole 256-row tile (two pieces per wave), B = the 64 encoding rows (two pieces on waves 0 and 1) or the
+                            // 4 embedding rows (one piece on wave 0)
+        if (n_dma == 4) k_loop(std::integral_constant<int, 4>(), Units());
+        else if (n_dma == 3) k_loop(std::integral_constant<int, 3>(), Units());
+        else k_loop(std::integral_constant<int, 2>(), Units());
     } else switch (n_dma) {
         case 0: k_loop(std::integral_constant<int, 0>(), Rows()); break;
         case 1: k_loop(std::integral_constant<int, 1>(), Rows()); break;
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
 #pragma unroll
                         for (int g = 0; g < 16; ++g) {
                             const int row = (wm_idx * wm + i) * 32 + acc_row(g, h);
-                            if (row < job.split) atomicAdd(job.dw + (size_t)row * job.dw_ld + cm, acc[i][j][g]);
+                            if (row < job.split) { if (job.dw) atomicAdd(job.dw + (size_t)row * job.dw_ld + cm, acc[i][j][g]); }      // (dw == nullptr: these rows have no destination)
                             else if (row < job.m_rows) atomicAdd(job.dw2 + (size_t)(row - job.split) * job.dw2_ld + cm, acc[i][j][g]);
                         }
                     }
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradJobTable tab, c
     const bool second = row >= job.split;
     if (col < job.n_rows) {
         const int cm = job.col_map ? job.col_map[col] : col;
-        if (cm >= 0) (second ? job.dw2 + (size_t)(row - job.split) * job.dw2_ld : job.dw + (size_t)row * job.dw_ld)[cm] += acc;      // the only writer of this element in this launch
+        if (cm >= 0 && (second || job.dw)) (second ? job.dw2 + (size_t)(row - job.split) * job.dw2_ld : job.dw + (size_t)row * job.dw_ld)[cm] += acc;      // the only writer of this element in this launch
     }
     if (col == 0 && job.db) (second ? job.db2 + (row - job.split) : job.db + row)[0] += accb;
 }

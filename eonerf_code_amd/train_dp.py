@@ -32,15 +32,13 @@ def main():
     args = ap.parse_args()
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     # EONERF_DP_REHEARSAL=1 (tests on a one-GPU box, not a deployment mode): every rank on cuda:0, gloo instead of RCCL; run it with
     # EONERF_PIPE=0 -- the pipelined backward assumes the card to itself
     rehearsal = os.environ.get("EONERF_DP_REHEARSAL") == "1"
     if rehearsal:
         local = 0
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:

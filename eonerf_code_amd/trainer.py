@@ -89,7 +89,7 @@ class FusedTrainer:
         n = out.shape[0]
         kind = 0 if epoch_idx < 2 else 1
         _lib.check(self.L.eonerf_train_loss(self.ctx, _ptr(out), _ptr(pixels), n, kind, _ptr(d_out), _ptr(self.loss), _stream()))
-        return self.loss if kind == 0 else self.loss + 1.5      # the beta term's constant 3/2
+        return self.loss
 
     def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False):
         """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar."""
@@ -174,13 +174,16 @@ class FusedTrainer:
         _lib.check(self.L.eonerf_profile_enable(self.ctx, max_launches))
 
     def profile_read(self):
-        names = ("fwd_chain_camera", "bwd_chain_camera", "wgrad_gemm", "fwd_chain_sun", "bwd_chain_sun", "bwd_pipe_camera")
-        res = {}
-        for k, name in enumerate(names):
+        """{scope name: (summed ms, launches)} of the library's per-kernel event scopes (include/eonerf_hip.h)."""
+        res, k = {}, 0
+        while True:
+            name = self.L.eonerf_profile_name(k)
+            if name is None:
+                return res
             ms, cnt = C.c_float(), C.c_int()
             _lib.check(self.L.eonerf_profile_read(self.ctx, k, C.byref(ms), C.byref(cnt)))
-            res[name] = (ms.value, cnt.value)
-        return res
+            res[name.decode()] = (ms.value, cnt.value)
+            k += 1
 
 
 class RayTable:

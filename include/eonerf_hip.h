@@ -180,8 +180,8 @@ size_t eonerf_grad_floats(const eonerf_ctx* ctx);
 int eonerf_grad_seal(eonerf_ctx* ctx, float* d_flat_params, void* stream);
 
 /* Training loss on the packed outputs and its gradient (train_eonerf.py:139-143): kind 0 = F.mse_loss(rgb, pixels),
- * kind 1 = metrics.uncertainty_aware_loss(pixels, rgb, beta) (metrics.py:17-22; the constant 3/2 of its beta term is
- * NOT included in *loss).  Writes d_out[R,21] (zero except the rgb/beta columns) and the scalar *loss (device). */
+ * kind 1 = metrics.uncertainty_aware_loss(pixels, rgb, beta) (metrics.py:17-22, including the constant 3/2 of its beta term).
+ * Writes d_out[R,21] (zero except the rgb/beta columns) and the scalar *loss (device). */
 int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, int n_rays, int kind, float* d_out, float* loss, void* stream);
 
 /* torch.optim.Adam step on the flat buffers (train_eonerf.py:63,161): lr, betas (0.9,0.999), eps 1e-8, no weight decay; ONE step
@@ -194,13 +194,18 @@ int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, in
 int eonerf_adam_step(eonerf_ctx* ctx, float* flat_params, const float* d_flat_params, float* exp_avg, float* exp_avg_sq,
                      int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream);
 
-/* Measurement hooks (no reference counterpart): with profiling enabled every launch of the three MFMA kernels is
- * bracketed by hipEvents on the caller's stream.  kernel: 0 = forward chain (camera), 1 = backward chain (camera),
- * 2 = weight-gradient GEMM, 3 = forward chain (shadow pass), 4 = backward chain (shadow pass), 5 = layer-pipelined trunk
- * backward of the camera pass (bf16: kernel 1 is then the heads part only, kernel 2 the GEMM jobs the pipeline leaves).
- * eonerf_profile_read synchronises on the recorded events and returns the summed duration and launch count. */
+/* Measurement hooks (no reference counterpart): with profiling enabled every launch of the MFMA kernels is bracketed by hipEvents on
+ * the caller's stream, ONE scope per kernel launch (so a scope's time is that kernel's time).  In bf16 mode the backward of a pass is
+ * heads chain -> [heads pipeline] -> trunk pipeline -> [input-gradient tail], then one weight-gradient GEMM for the jobs the pipelines
+ * leave; in fp32 mode (or EONERF_PIPE=0) the two chain scopes cover the whole dX chain and the GEMM every weight gradient.
+ * eonerf_profile_read synchronises on the recorded events and returns the summed duration and launch count;
+ * eonerf_profile_name gives the scope's name (NULL beyond the last). */
+enum { EONERF_PROF_FWD_CHAIN_CAMERA = 0, EONERF_PROF_BWD_CHAIN_CAMERA = 1, EONERF_PROF_WGRAD = 2, EONERF_PROF_FWD_CHAIN_SUN = 3,
+       EONERF_PROF_BWD_CHAIN_SUN = 4, EONERF_PROF_BWD_PIPE_CAMERA = 5, EONERF_PROF_BWD_PIPE_SUN = 6, EONERF_PROF_IG_TAIL_SUN = 7,
+       EONERF_PROF_HEADS_PIPE_CAMERA = 8, EONERF_PROF_KERNELS = 9 };
 int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches_per_kernel);
 int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launches);
+const char* eonerf_profile_name(int kernel);
 
 const char* eonerf_strerror(int code);
 int eonerf_version(void);

@@ -76,6 +76,7 @@ def test_two_ranks_on_one_gpu_identical_replicas_and_global_batch_gradient(tmp_p
     for (name, p), g_ref, g_got in zip(f.named_parameters(), f.grad_views(ref), f.grad_views(got)):
         assert (g_ref - g_got).norm().item() <= 2e-4 * g_ref.norm().item() + 1e-9, (epoch, name)
     # and the parameter update agrees (Adam's first step is lr * sign-like: compare where the gradient is not tiny)
+    ref = ref[:tr.n_params]                                            # (the message's 4 control floats are not parameters)
     big = ref.abs() > 1e-4 * ref.abs().max()
     assert (tr.flat.detach().cpu() - r0["flat"])[big].abs().max().item() <= 2e-5
 
