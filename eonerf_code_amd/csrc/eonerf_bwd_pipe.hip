@@ -59,6 +59,9 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 #ifndef EO_PIPE_DEPTH
 #define EO_PIPE_DEPTH 3
 #endif
+#ifndef EO_PIPE_ORDB
+#define EO_PIPE_ORDB 0
+#endif
 constexpr int NSLOT = 4, DEPTH = EO_PIPE_DEPTH;      // LDS ring slots; steps of DMA in flight ahead of the one being multiplied (<= NSLOT - 1)
 static_assert(DEPTH >= 2 && DEPTH <= NSLOT - 1, "prefetch distance");
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
@@ -465,12 +468,21 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             phase_dw();
             if (stamp) { t_dx += tt3 - tt2; t_is += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
         } else {
+#if EO_PIPE_ORDB == 1      // DMA issue -> dX -> dW: the step ends in matrix work (no epilogue tail behind the last MFMA of the SIMD)
+            issue(k_next);
+            const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            phase_dx();
+            const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            phase_dw();
+            if (stamp) { t_is += tt3 - tt2; t_dx += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
+#else
             issue(k_next);
             const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             phase_dw();
             const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             phase_dx();
             if (stamp) { t_is += tt3 - tt2; t_dw += tt4 - tt3; t_dx += __builtin_amdgcn_s_memtime() - tt4; }
+#endif
         }
     }
     if (stamp && lane == 0) {

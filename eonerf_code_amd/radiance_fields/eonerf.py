@@ -68,7 +68,7 @@ class _FieldFn(torch.autograd.Function):
 
 class EONerfMLP(nn.Module):
     def __init__(self, n_input_images: int, net_depth: int = 8, net_width: int = 256, skip_layer: int = 4,
-                 radiometric_normalization: bool = False, precision: str = None):
+                 radiometric_normalization: bool = False, precision: str = None, eval_precision: str = None):
         super().__init__()
         if (net_depth, net_width, skip_layer) != (8, 256, 4):
             raise ValueError("the HIP path implements the shipped EO-NeRF geometry only: depth 8, width 256, skip 4")
@@ -94,7 +94,16 @@ class EONerfMLP(nn.Module):
         self.precision = (precision or os.environ.get("EONERF_PRECISION", "bf16")).lower()
         if self.precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
+        # EXPORT renders (render_image(eval=True), or a module in .eval() mode under no_grad: eval_eonerf.py:311-324, the validation
+        # of train_eonerf.py:197-226 -- where DSMs and their MAE come from) run in fp32 whatever the training precision: on identical
+        # weights the fp32 kernels match the reference arithmetic to 1e-4 (altitude well inside 1 cm), while the bf16 kernels move
+        # the rendered surface of a trained field by ~1 cm per ray (weight rounding of the trunk).  "same": no switch.
+        self.eval_precision = (eval_precision or os.environ.get("EONERF_EVAL_PRECISION", "fp32")).lower()
+        if self.eval_precision not in ("fp32", "same"):
+            raise ValueError("eval_precision must be 'fp32' or 'same'")
         self._ctx = None          # eonerf_ctx*
+        self._ctx_eval = None     # second native context (fp32) for export renders of a bf16 field, created on first use
+        self._packed_version_eval = None
         self._flat = None         # flat fp32 parameter buffer (device)
         self._layout = None
         self._packed_version = None
@@ -117,8 +126,28 @@ class EONerfMLP(nn.Module):
         try:
             if self._ctx is not None:
                 _lib.lib().eonerf_destroy(self._ctx)
+            if getattr(self, "_ctx_eval", None) is not None:
+                _lib.lib().eonerf_destroy(self._ctx_eval)
         except Exception:
             pass
+
+    def _native(self, export=False):
+        """(context, flat parameters) to run a call on, packed weights up to date.  export=True on a bf16 module with
+        eval_precision="fp32": the module's second, fp32 context over the SAME flat parameter buffer."""
+        if not (export and self.precision == "bf16" and self.eval_precision == "fp32"):
+            return self._context(), self._ensure_packed()
+        flat = self.flat_params()
+        L = _lib.lib()
+        if self._ctx_eval is None:
+            cfg = _lib.EonerfConfig(self.n_input_images, _lib.EONERF_FP32, 128, 1 if self.radiometric_normalization else 0)
+            ctx = C.c_void_p()
+            _lib.check(L.eonerf_create(C.byref(ctx), C.byref(cfg)))
+            self._ctx_eval = ctx
+        ver = (flat.data_ptr(),) + tuple(p._version for p in self.parameters())
+        if ver != self._packed_version_eval:
+            _lib.check(L.eonerf_set_weights(self._ctx_eval, _ptr(flat), _stream()))
+            self._packed_version_eval = ver
+        return self._ctx_eval, flat
 
     def _named(self):
         return dict(self.named_parameters())

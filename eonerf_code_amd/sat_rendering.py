@@ -82,17 +82,17 @@ class _RenderChunk(torch.autograd.Function):
     """One chunk of render_image as a differentiable op; the parameters are inputs so autograd routes their grads."""
 
     @staticmethod
-    def forward(ctx, field, table, img, flags, u_cam, u_retry, u_sun, *params):
+    def forward(ctx, field, table, img, flags, export, u_cam, u_retry, u_sun, *params):
         L = _lib.lib()
-        flat = field._ensure_packed()
-        n = table.shape[0]
         train = bool(flags & _lib.F_TRAIN)
-        nb = L.eonerf_render_workspace_bytes(field._ctx, n, flags)
+        native, flat = field._native(export and not train)      # export renders of a bf16 field: its fp32 context (EONerfMLP.eval_precision)
+        n = table.shape[0]
+        nb = L.eonerf_render_workspace_bytes(native, n, flags)
         # a training chunk keeps its own workspace alive until its backward; inference chunks share one
         ws = torch.empty(nb, dtype=torch.uint8, device=table.device) if train else field._workspace("render", nb)
         out = torch.empty(n, 21, dtype=torch.float32, device=table.device)
         n_samples = torch.zeros(1, dtype=torch.int32, device=table.device)
-        _lib.check(L.eonerf_render_forward(field._ctx, _ptr(flat), _ptr(table), _ptr(img), _ptr(_zsteps(table.device)),
+        _lib.check(L.eonerf_render_forward(native, _ptr(flat), _ptr(table), _ptr(img), _ptr(_zsteps(table.device)),
                                            _ptr(u_cam), _ptr(u_retry), _ptr(u_sun), n, flags, _ptr(out), _ptr(n_samples),
                                            _ptr(ws), ws.numel(), _stream()))
         if train:
@@ -114,11 +114,13 @@ class _RenderChunk(torch.autograd.Function):
         _lib.check(L.eonerf_render_backward(field._ctx, _ptr(flat), _ptr(table), _ptr(img), table.shape[0], flags,
                                             _ptr(d_out), _ptr(d_flat), _ptr(ws), ws.numel(), _stream()))
         ctx.ws = None
-        return (None,) * 7 + tuple(field.grad_views(d_flat))
+        return (None,) * 8 + tuple(field.grad_views(d_flat))
 
 
 def render_rays_chunk(radiance_field, table, img, epoch_idx, eval=False, only_depth=False, noise=None):
     """table [n,11] fp32, img [n] int64 -> (out [n,21], n_samples int32[1]) for one chunk."""
+    # an EXPORT render: eval=True (eval_eonerf.py:311-324) or a module in .eval() mode outside autograd (train_eonerf.py:197-226)
+    export = bool(eval) or (not radiance_field.training and not torch.is_grad_enabled())
     n, dev = table.shape[0], table.device
     flags = 0
     if epoch_idx is not None and epoch_idx >= 2:
@@ -134,7 +136,7 @@ def render_rays_chunk(radiance_field, table, img, epoch_idx, eval=False, only_de
         u_cam = u_retry = u_sun = None
     else:
         u_cam, u_retry, u_sun = (None if t is None else t.to(dev, torch.float32).contiguous() for t in noise)
-    return _RenderChunk.apply(radiance_field, table, img, flags, u_cam, u_retry, u_sun, *params)
+    return _RenderChunk.apply(radiance_field, table, img, flags, export, u_cam, u_retry, u_sun, *params)
 
 
 def render_image(

@@ -145,7 +145,7 @@ int eonerf_rendering(eonerf_ctx* ctx, const float* flat_params, const float* ray
  *   reference's torch.rand_like is the same generator family, :52), and the resample branch is always armed.
  *   out[R,21] = rgb3 depth1 albedo3 ambient3 geo1 ts1 beta1 entropy1 pts1 sc_pts1 opacity2 shadowless3 (:311-312)
  *   n_samples_dev: device int, number of camera samples (render_image's second return value).
- *   Size limit with EONERF_F_TRAIN: 66,051 rays per call in bf16 mode, 33,025 in fp32 mode (a 256-row block of the saved-activation
+ *   Size limit with EONERF_F_TRAIN: 66,050 rays per call in bf16 mode, 33,024 in fp32 mode (a 256-row block of the saved-activation
  *   slabs is addressed with 32-bit byte offsets); EONERF_E_UNSUPPORTED beyond -- chunk the batch, as render_image's `chunk` does. */
 int eonerf_render_forward(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
                           const float* zsteps, const float* u_cam, const float* u_retry, const float* u_sun,

@@ -296,5 +296,57 @@ def g8():
     save("g8_render", **out)
 
 
+# ------------------------------------------------------------------ G9 vanilla NeRF field (BASELINE.json configs[0])
+def vanilla_fill(name, shape):
+    """Closed-form weights of the G9 field: only this formula is committed, both sides regenerate the tensors from it."""
+    c = sum(ord(ch) for ch in name) % 17
+    n = 1
+    for d in shape:
+        n *= d
+    idx = torch.arange(n, dtype=torch.float64).reshape(shape)
+    fan = shape[-1] + shape[0] if len(shape) == 2 else 1
+    scale = (6.0 / fan) ** 0.5 if len(shape) == 2 else 0.01
+    return (scale * torch.sin(0.37 * idx + c)).float()
+
+
+def vanilla_inputs(n_rays=256, n_samples=64):
+    """configs[0]: 256 rays x 64 samples.  Positions [R,S,3] inside the unit cube, one view direction per ray [R,3]."""
+    r = torch.arange(n_rays, dtype=torch.float64)[:, None]
+    k = torch.arange(n_samples, dtype=torch.float64)[None, :]
+    x = torch.stack([torch.sin(0.11 * r + 0.07 * k), torch.cos(0.05 * r - 0.13 * k), torch.sin(0.017 * r * k + 0.3)], dim=-1).float() * 0.95
+    d = torch.stack([torch.sin(0.3 * r[:, 0]), torch.cos(0.2 * r[:, 0]), -torch.ones(n_rays, dtype=torch.float64)], dim=-1)
+    d = (d / d.norm(dim=-1, keepdim=True)).float()
+    return x, d
+
+
+def g9():
+    from radiance_fields.mlp import VanillaNeRFRadianceField
+    f = VanillaNeRFRadianceField()                                  # the shipped geometry: 8 x 256, skip 4, condition head 1 x 128
+    with torch.no_grad():
+        for name, p in f.named_parameters():
+            p.copy_(vanilla_fill(name, tuple(p.shape)))
+    x, d = vanilla_inputs()
+    R, S = x.shape[:2]
+    # flattened samples, as the reference's renderers hand them to a field (SinusoidalEncoder.forward tiles its mask for 2-D input
+    # only, mlp.py:207); the view direction of a ray is repeated for its samples
+    x = x.reshape(R * S, 3)
+    d = d[:, None, :].expand(R, S, 3).reshape(R * S, 3)
+    xg = x.clone().requires_grad_(True)
+    rgb, sigma = f(xg, d)
+    dens = f.query_density(x)
+    opac = f.query_opacity(x, 2.0 / 64)
+    # a plumbing train step's loss and gradients (train_mlp_nerf.py renders rgb/opacity from these and back-propagates an L1-type loss)
+    cw = torch.linspace(0.5, 1.5, 3)[None, :]
+    loss = (rgb * cw).sum() / rgb.numel() + 0.1 * sigma.sum() / sigma.numel()
+    loss.backward()
+    grads = {f"grad.{n}": compact_grad(p.grad) for n, p in f.named_parameters()}
+    manifest = np.array([f"{k}:{tuple(v.shape)}:{str(v.dtype).replace('torch.', '')}" for k, v in f.state_dict().items()])
+    save("g9_vanilla", rgb=rgb[::4], sigma=sigma[::4], density=dens[::4], opacity=opac[::4], loss=loss, dx=xg.grad[::8],
+         n_rays=R, n_samples=S, manifest=manifest, **grads)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3_g7(); g4(); g5(); g6(); g8()
+    only = sys.argv[1:]
+    for name, fn in (("g1", g1), ("g2", g2), ("g3_g7", g3_g7), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8), ("g9", g9)):
+        if not only or name in only:
+            fn()

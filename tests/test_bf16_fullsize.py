@@ -63,3 +63,52 @@ def test_bf16_vs_fp32_trained_field_dsm_mae_within_1cm_full_size(monkeypatch):
     st = compare_precisions(f16, f32, seed=1)
     assert st["depth_err_vs_terrain_mean"] < 0.1                    # the field did learn the terrain (from 0.19 at init)
     _check(st, rgb_max=5e-2, rgb_mean=1e-3, depth_mean=6e-4, alt_mae=0.030, alt_p99=0.10, cos_min=0.98, rel_max=2.5e-1)
+
+
+def test_export_render_of_a_bf16_trained_field_runs_in_fp32_and_matches_the_oracle(monkeypatch):
+    """The fence around the bf16 altitude shift: EXPORT renders -- render_image(eval=True), eval_eonerf.py:311-324, or a
+    module in .eval() mode under no_grad, train_eonerf.py:197-226 -- of a field TRAINED in bf16 run on the module's fp32 context
+    (EONerfMLP.eval_precision, default "fp32") and therefore match the reference arithmetic on the same checkpoint: every output
+    within 1e-4 of the oracle at 4096 x 128, altitude within 1 cm (Z_scale 50 m)."""
+    from oracle import eonerf_oracle as orc
+    from bf16_common import R, N_IMG, STEP, Z_SCALE, terrain_batch
+    from eonerf_code_amd.sat_rendering import render_image
+    from eonerf_code_amd.datasets.satellite import define_satrays_from_tensors
+    monkeypatch.setenv("EONERF_DETERMINISTIC", "1")
+    f16, _ = make_fields(seed=42)
+    train_on_terrain(f16, 400)
+    sd = {k: v.detach().cpu() for k, v in f16.state_dict().items()}
+    rays, _, _, _ = terrain_batch(R, seed=903)
+    img = torch.zeros(R, dtype=torch.int64, device="cuda")            # eval_eonerf.py:300-304: ts all zeros
+    g = torch.Generator(device="cuda").manual_seed(5)
+    noise = tuple(torch.rand(R, 128, device="cuda", generator=g) for _ in range(3))
+    sr = define_satrays_from_tensors(rays, img[:, None])
+    with torch.no_grad():
+        exp, n_exp = render_image(f16, None, sr, None, None, epoch_idx=3, chunk=R, render_step_size=STEP, noise=[noise], eval=True)
+        f16.eval()                                                     # the validation loop's way into the same path
+        val, n_val = render_image(f16, None, sr, None, None, epoch_idx=3, chunk=R, render_step_size=STEP, noise=[noise])
+        f16.train()
+        raw, _ = render_image(f16, None, sr, None, None, epoch_idx=3, chunk=R, render_step_size=STEP, noise=[noise])   # training-mode render: bf16
+        outs = []
+        for i in range(0, R, 512):                                     # the oracle, ray chunk by ray chunk (memory)
+            sl = slice(i, i + 512)
+            o, _ = orc.render_rays(orc.Field(sd), orc.define_satrays_from_tensors(rays[sl].cpu(), img[sl, None].cpu()),
+                                   noise[0][sl].cpu(), noise[2][sl].cpu(), 3, STEP, eval=True)
+            outs.append(o)
+    ref = torch.cat(outs)
+    assert f16._ctx_eval is not None                                   # the fp32 export context exists and was used
+    for name, (a, b) in orc.RESULT_SLICES.items():
+        got, want = exp[name].cpu(), ref[:, a:b]
+        if name in ("pts_per_ray", "sc_pts_per_ray", "entropy", "opacity_after_surface"):
+            assert torch.equal(got, want), name
+        else:
+            assert (got - want).abs().max().item() < 1e-4, (name, (got - want).abs().max().item())
+        if name not in ("rgb", "shadowless_rgb"):                      # .eval() mode without eval=True: per-ray radiometric rows (all row 0 here)
+            assert torch.equal(val[name], exp[name]), name
+    alt = orc.altitude_from_depth(rays.cpu(), exp["depth"].cpu(), Z_SCALE, 20.0)
+    alt_ref = orc.altitude_from_depth(rays.cpu(), ref[:, 3:4], Z_SCALE, 20.0)
+    assert (alt - alt_ref).abs().max().item() < 0.01                   # 1 cm, every ray
+    d_bf16 = (orc.altitude_from_depth(rays.cpu(), raw["depth"].cpu(), Z_SCALE, 20.0) - alt_ref).abs()
+    print(f"export (fp32 context) max altitude error {(alt - alt_ref).abs().max().item() * 100:.4f} cm; bf16 render of the same weights: "
+          f"mean {d_bf16.mean().item() * 100:.2f} cm, p99 {d_bf16.quantile(0.99).item() * 100:.2f} cm")
+    assert d_bf16.mean().item() > 1e-4                                 # (the two paths really are different kernels)

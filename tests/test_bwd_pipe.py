@@ -145,7 +145,7 @@ def test_pipelined_path_with_empty_rays_and_an_all_empty_batch(epoch):
 
 def test_four_times_the_bench_batch_and_the_size_guard():
     """16384 rays x 128 samples (2.1 M samples: the training slabs pass 12 GB, byte offsets inside them pass 2^32; every 256-row block is
-    addressed through its own descriptor): pipelined path against chain + GEMM.  Beyond 66,051 rays a 256-row block would outgrow the
+    addressed through its own descriptor): pipelined path against chain + GEMM.  Beyond 66,050 rays a 256-row block would outgrow the
     32-bit offsets of its descriptor: the C ABI refuses (EONERF_E_UNSUPPORTED) instead of wrapping around."""
     import ctypes as C
     from eonerf_code_amd import _lib

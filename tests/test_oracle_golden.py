@@ -214,3 +214,39 @@ def test_compositing_properties():
     assert out[60, 3] == 0 and out[60, 10] == 1 and abs(out[60, 12] - 0.05) < 1e-7 and out[60, 14] == 0
     assert (out[:, 10] <= 1).all() and (out[:, 10] >= 0).all()
     assert np.isfinite(out.numpy()).all()
+
+
+def test_vanilla_field_configs0_matches_reference_golden_g9():
+    """BASELINE.json configs[0] (plumbing, CPU fp32): the vanilla 8 x 256 NeRF field of radiance_fields/mlp.py:211-250 on 256 rays x 64
+    samples -- forward, query_density / query_opacity and the autograd of a train-step-like loss -- restated in oracle/vanilla_oracle.py
+    against golden G9 from the reference's own class."""
+    from oracle import vanilla_oracle as vo
+    g = load_golden("g9_vanilla")
+    R, S = int(g["n_rays"]), int(g["n_samples"])
+    assert (R, S) == (256, 64)
+    sd = vo.state_dict_from_manifest(g["manifest"])
+    assert len(sd) == 26 and sd["mlp.base.hidden_layers.5.weight"].shape == (256, 319)       # skip-concat: 256 + 63 inputs
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    f = vo.VanillaField(sdg)
+    x, d = vo.inputs(R, S)
+    x = x.reshape(R * S, 3)
+    d = d[:, None, :].expand(R, S, 3).reshape(R * S, 3)
+    xg = x.clone().requires_grad_(True)
+    rgb, sigma = f.forward(xg, d)
+    assert (rgb[::4] - T(g["rgb"])).abs().max().item() < 1e-5
+    assert (sigma[::4] - T(g["sigma"])).abs().max().item() < 1e-4 * max(1.0, float(T(g["sigma"]).abs().max()))
+    with torch.no_grad():
+        assert (f.query_density(x)[::4] - T(g["density"])).abs().max().item() < 1e-4 * max(1.0, float(T(g["density"]).abs().max()))
+        assert torch.allclose(f.query_opacity(x, 2.0 / 64)[::4], T(g["opacity"]), rtol=1e-4, atol=1e-6)
+    cw = torch.linspace(0.5, 1.5, 3)[None, :]
+    loss = (rgb * cw).sum() / rgb.numel() + 0.1 * sigma.sum() / sigma.numel()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    assert (xg.grad[::8] - T(g["dx"])).norm().item() <= 2e-3 * T(g["dx"]).norm().item() + 1e-9
+    n_checked = 0
+    for k, v in g.items():
+        if k.startswith("grad."):
+            got, ref = compact_grad(sdg[k[5:]].grad), T(v)
+            assert (got - ref).norm().item() <= 2e-3 * ref.norm().item() + 1e-9, k
+            n_checked += 1
+    assert n_checked == 24
