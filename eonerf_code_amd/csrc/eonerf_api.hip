@@ -159,6 +159,7 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     // training passes of the render path with the pipelined backward: the trunk's ReLU' comes from the X images, only the heads chain
     // reads mask bits (slot 7 = X_8 for its last layer; from slot 8 on with the heads pipeline)
     a.mask_from = (render_train && ctx->pipe) ? ((full && ctx->heads_pipe) ? 8 : 7) : 0;
+    a.save_bott = (render_train && full && ctx->heads_pipe) ? 1 : 0;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
     if (prof_id < 0) return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, mode, grid, st);
@@ -279,17 +280,16 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         const PassBuffers& c = *full;
         trunk_jobs(c, full_trunk_done);
         if (!heads_units) {
-        // bottleneck layer: factor M_a = dA1^T X8 (and M_t = dT1^T X8), finished by eo_launch_bott_wgrad below
-        if (!zeroed) HIP_TRY(hipMemsetAsync(m_bott, 0, 2 * 128 * 256 * sizeof(float), st));
-        // dY A1 and dY T1 are the two halves of one 256-row block of the gradient slab: with the transient head both factors (and both
-        // first-layer gradients against the bottleneck output) are ONE job each -- every operand block is read once, not twice
+        // bottleneck factors M_a = dA1^T X8 (and M_t = dT1^T X8) + the bias gradients db_A1 (db_T1), finished by eo_launch_bott_wgrad
+        // below into THREE weight gradients: the bottleneck layer's and the two head layers' that read the bottleneck output (which is
+        // therefore never saved by the forward, nor read back here: see BottWgradArgs)
+        if (!zeroed) HIP_TRY(hipMemsetAsync(m_bott, 0, BOTT_SCRATCH_F * sizeof(float), st));
+        float* db_at = m_bott + 2 * 128 * 256;
+        // dY A1 and dY T1 are the two halves of one 256-row block of the gradient slab: with the transient head both factors are ONE job
         if (transient) {
-            add(c, GRD_ROW_A1, 256, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, nullptr, nullptr, 2, 4, 4, 2);          // [M_a; M_t]
-            add(c, GRD_ROW_A1, 256, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 4, 2);
-            split_at(128, dptr(pl.t_w[0]), 260, dptr(pl.t_b[0]));
+            add(c, GRD_ROW_A1, 256, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, db_at, nullptr, 2, 4, 4, 2);          // [M_a; M_t], [db_A1; db_T1]
         } else {
-            add(c, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, nullptr, nullptr, 2, 4, 2, 2);
-            add(c, GRD_ROW_A1, 128, ACT_ROW_BOTT, 256, dptr(pl.a1_w), 256, dptr(pl.a1_b), nullptr, 2, 4, 2, 2);
+            add(c, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, db_at, nullptr, 2, 4, 2, 2);
         }
         }
         add(c, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
@@ -328,11 +328,14 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         tab.items += j.slices;
     }
     { ProfScope ps(ctx, EONERF_PROF_WGRAD, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed)); }
-    if (full && !heads_units) {   // bottleneck layer: dW = W_A1^T M_a (+ W_T1^T M_t) from the two factors the GEMM above accumulated
+    if (full && !heads_units) {   // the three weight gradients that follow from the bottleneck factors the GEMM above accumulated
         BottWgradArgs bw;
-        bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_a1 = dptr(pl.a1_b);
-        bw.w_t1 = transient ? flat + pl.t[pl.t_w[0]].offset : nullptr; bw.m_t = m_bott + 128 * 256; bw.db_t1 = transient ? dptr(pl.t_b[0]) : nullptr;
+        bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_at = m_bott + 2 * 128 * 256;
+        bw.w_t1 = transient ? flat + pl.t[pl.t_w[0]].offset : nullptr; bw.m_t = m_bott + 128 * 256;
+        bw.w_bott = flat + pl.t[pl.bot_w].offset; bw.b_bott = flat + pl.t[pl.bot_b].offset;
         bw.d_w = dptr(pl.bot_w); bw.d_b = dptr(pl.bot_b);
+        bw.d_w_a1 = dptr(pl.a1_w); bw.d_b_a1 = dptr(pl.a1_b);
+        bw.d_w_t1 = transient ? dptr(pl.t_w[0]) : nullptr; bw.d_b_t1 = transient ? dptr(pl.t_b[0]) : nullptr;
         HIP_TRY(eo_launch_bott_wgrad(bw, st));
     }
     return 0;
@@ -554,7 +557,7 @@ FieldTrainWs carve_field_train(const eonerf_ctx* ctx, void* base, int p_cap, boo
     Carver c(base);
     FieldTrainWs w;
     carve_pass(c, w.b, 1, p_cap, full, true, true, ctx->bf16 ? 2 : 4);
-    w.m_bott = c.take<float>(2 * 128 * 256);
+    w.m_bott = c.take<float>(BOTT_SCRATCH_F);
     w.queue = c.take<int>(4);
     w.bytes = c.off + 256;
     return w;

@@ -9,6 +9,8 @@
 #include "eonerf_kernels.h"
 #include "eonerf_rays.h"
 
+constexpr int BOTT_SCRATCH_F = 2 * 128 * 256 + 256;       // bottleneck factors M_a | M_t, then db_A1 | db_T1
+
 struct CarveCfg {          // what the layout depends on besides (n_rays, flags): see eonerf_ctx
     bool bf16 = true, pipe = false, heads_pipe = false, deterministic = false, pipe_partials = false;
     int n_pipes = 0, n_pipes_heads = 0;
@@ -57,8 +59,8 @@ struct RenderWs {
     DetWs det;
     int *cnt_first, *cnt_retry, *flags;
     float* ray_rec; float* g_ray; float* amb_save;
-    float* m_bott;        // [2][128][256] fp32: dA1^T X8 and dT1^T X8 (factors of the bottleneck weight gradient)
-    int* queue;           // work-item counter of the weight-gradient GEMM (behind m_bott)
+    float* m_bott;        // [2][128][256] fp32: dA1^T X8 and dT1^T X8 (the bottleneck factors), then [256] db_A1 | db_T1 of this call
+    int* queue;           // work-item counter of the weight-gradient GEMM (behind them)
     PassBuffers cam, sun;
     size_t bytes;
 };
@@ -112,8 +114,8 @@ inline RenderWs carve_render(const CarveCfg& cfg, void* base, int n_rays, int fl
     w.amb_save = train ? c.take<float>((size_t)n_rays * 160) : nullptr;
     // [bottleneck factors | GEMM work queue] and, right behind them, the pipeline's sync block: everything the backward needs zeroed, so
     // that the first pipeline launch of a backward call clears all of it with ONE memset
-    w.m_bott = train ? c.take<float>(2 * 128 * 256 + 64) : nullptr;
-    w.queue = w.m_bott ? reinterpret_cast<int*>(w.m_bott + 2 * 128 * 256) : nullptr;      // (measuring pass: no arithmetic on a null base)
+    w.m_bott = train ? c.take<float>(BOTT_SCRATCH_F + 64) : nullptr;
+    w.queue = w.m_bott ? reinterpret_cast<int*>(w.m_bott + BOTT_SCRATCH_F) : nullptr;      // (measuring pass: no arithmetic on a null base)
     memset(&w.pipe, 0, sizeof(w.pipe));
     if (train && ctx->pipe) {
         // one sync block fits either launch shape: 7 x n_pipes or 2 x n_pipes_heads workgroups, 6 x n_pipes or 1 x n_pipes_heads edges

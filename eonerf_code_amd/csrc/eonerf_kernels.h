@@ -78,6 +78,8 @@ struct MlpFwdArgs {
     float *sigma, *albedo, *ts, *tb;   // outputs: sigma[p_pad], albedo[3][p_pad], ts[p_pad], tb[p_pad]
     void* act;                     // TRAIN: [ACT_ROWS][p_pad] of P::act_t
     uint32_t* masks;               // TRAIN: [MASK_SLOTS][p_pad][2][4] ReLU masks
+    int save_bott;                 // TRAIN: also save the bottleneck OUTPUT rows (only the heads pipeline reads them: the chain + GEMM path gets
+                                   // the heads' first-layer weight gradients from the bottleneck factors, see BottWgradArgs)
     int mask_from;                 // TRAIN: first mask slot the backward will read (the pipelined trunk backward derives ReLU' from the saved
                                    // activations themselves: slots below are not written)
 };

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                     if (mt == 0) { if (s == 0) sigma_raw = v[0]; return; }
                     const Sl<P> x = pack_slice(P(), v, s);
                     put_slice(P(), H, mt - 1, s, x);
-                    if constexpr (TRAIN) sw.stage(ACT_ROW_BOTT + 32 * (mt - 1), s, x);
+                    if constexpr (TRAIN) { if (a.save_bott) sw.stage(ACT_ROW_BOTT + 32 * (mt - 1), s, x); }      // wave-uniform
                 });
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
 

@@ -81,11 +81,20 @@ struct AmbientBwdArgs {
     float *d_w1, *d_b1, *d_w2, *d_b2;
 };
 
-// dW_bott += W_A1^T M_a (+ W_T1^T M_t),  db_bott += W_A1^T db_A1 (+ W_T1^T db_T1)   (see k_mlp_bwd, bott_epi)
+// The bottleneck layer has an identity activation: bott = W_bott X8 + b_bott feeds the first layers of the albedo and transient heads.
+// With the factors  M_a = dA1^T X8  (and M_t = dT1^T X8) and the bias gradients db_A1 = sum_p dA1 (db_T1) -- ONE weight-gradient job
+// against X8 -- three weight gradients follow without the d bottleneck tensor and without the bottleneck OUTPUT ever being saved:
+//     dW_bott += W_A1^T M_a (+ W_T1^T M_t)             db_bott += W_A1^T db_A1 (+ W_T1^T db_T1)          (see k_mlp_bwd, bott_epi)
+//     dW_A1   += M_a W_bott^T + db_A1 (x) b_bott       (since sum_p dA1 bott^T = sum_p dA1 (W_bott X8 + b_bott)^T)     db_A1 -> d_flat
+//     dW_T1[:, :256] += M_t W_bott^T + db_T1 (x) b_bott                                                               db_T1 -> d_flat
 struct BottWgradArgs {
-    const float *w_a1, *m_a, *db_a1;     // [128][256] weights, [128][256] dA1^T X8, [128]
-    const float *w_t1, *m_t, *db_t1;     // transient head's first layer ([128][260] weights) or nullptr
-    float *d_w, *d_b;                    // [256][256], [256] inside the flat gradient buffer
+    const float *w_a1, *m_a;             // [128][256] weights, [128][256] dA1^T X8
+    const float *w_t1, *m_t;             // transient head's first layer ([128][260] weights) or nullptr, [128][256] dT1^T X8
+    const float* db_at;                  // [256] scratch: db_A1 | db_T1 of THIS backward call (not yet in the flat gradient buffer)
+    const float *w_bott, *b_bott;        // [256][256], [256]
+    float *d_w, *d_b;                    // bottleneck layer: [256][256], [256] inside the flat gradient buffer
+    float *d_w_a1, *d_b_a1;              // [128][256], [128]
+    float *d_w_t1, *d_b_t1;              // [128][260] (columns 0..255 written), [128]; nullptr without the transient head
 };
 
 struct EmbGradArgs {

@@ -325,32 +325,57 @@ __global__ void k_table_reduce(const float* contrib, const int64_t* idx, int n_r
     out[(size_t)row * stride + w] += acc;
 }
 
-// ---- bottleneck layer weight gradient from the two factors (fp32): block = input feature i of the heads' first layers =
-//      output feature (row) of the bottleneck layer, thread = column j ----
+// ---- weight gradients that follow from the bottleneck factors (fp32, see BottWgradArgs).
+//      blocks 0..255: bottleneck layer, block = input feature i of the heads' first layers = output feature (row) of the bottleneck
+//      layer, thread = column j;  blocks 256..: one row m of [W_A1; W_T1] each, thread = bottleneck feature i ----
 __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
     __shared__ float s_w[256];
-    const int i = blockIdx.x, j = threadIdx.x;
-    float acc = 0.f, accb = 0.f;
-    if (j < 128) s_w[j] = a.w_a1[j * 256 + i];
-    else s_w[j] = a.w_t1 ? a.w_t1[(j - 128) * 260 + i] : 0.f;
-    __syncthreads();
-    // (unrolled: the 128 loads of a column are independent, 32 of them in flight instead of the few the compiler keeps by itself;
-    //  four partial sums keep the adds off one dependency chain)
-    float p4[4] = {0.f, 0.f, 0.f, 0.f};
+    __shared__ float s_t[256][17];
+    const int j = threadIdx.x;
+    if (blockIdx.x < 256) {
+        const int i = blockIdx.x;
+        float acc = 0.f, accb = 0.f;
+        if (j < 128) s_w[j] = a.w_a1[j * 256 + i];
+        else s_w[j] = a.w_t1 ? a.w_t1[(j - 128) * 260 + i] : 0.f;
+        __syncthreads();
+        // (unrolled: the 128 loads of a column are independent, 32 of them in flight instead of the few the compiler keeps by itself;
+        //  four partial sums keep the adds off one dependency chain)
+        float p4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 32
-    for (int k = 0; k < 128; ++k) p4[k & 3] += s_w[k] * a.m_a[k * 256 + j];
-    if (a.w_t1) {
+        for (int k = 0; k < 128; ++k) p4[k & 3] += s_w[k] * a.m_a[k * 256 + j];
+        if (a.w_t1) {
 #pragma unroll 32
-        for (int k = 0; k < 128; ++k) p4[k & 3] += s_w[128 + k] * a.m_t[k * 256 + j];
+            for (int k = 0; k < 128; ++k) p4[k & 3] += s_w[128 + k] * a.m_t[k * 256 + j];
+        }
+        acc = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        a.d_w[i * 256 + j] += acc;                      // the only writer of this block of the gradient buffer
+        if (j == 0) {
+            for (int k = 0; k < 128; ++k) accb += s_w[k] * a.db_at[k];
+            if (a.w_t1)
+                for (int k = 0; k < 128; ++k) accb += s_w[128 + k] * a.db_at[128 + k];
+            a.d_b[i] += accb;
+        }
+        return;
     }
-    acc = (p4[0] + p4[1]) + (p4[2] + p4[3]);
-    a.d_w[i * 256 + j] += acc;                      // the only writer of this block of the gradient buffer
-    if (j == 0) {
-        for (int k = 0; k < 128; ++k) accb += s_w[k] * a.db_a1[k];
-        if (a.w_t1)
-            for (int k = 0; k < 128; ++k) accb += s_w[128 + k] * a.db_t1[k];
-        a.d_b[i] += accb;
+    // first layer of a head, row m:  dW[m][i] += sum_j M[m][j] W_bott[i][j] + db[m] b_bott[i]
+    const int mm = blockIdx.x - 256, m = mm & 127;
+    const bool tr = mm >= 128;
+    const float* M = (tr ? a.m_t : a.m_a) + m * 256;
+    s_w[j] = M[j];
+    const float dbm = a.db_at[mm];
+    float acc = 0.f;
+    for (int j0 = 0; j0 < 256; j0 += 16) {             // W_bott tile [256 rows][16 columns]: 16 threads read one 64-B row segment
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_t[(j >> 4) + 16 * r][j & 15] = a.w_bott[((j >> 4) + 16 * r) * 256 + j0 + (j & 15)];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc += s_w[j0 + c] * s_t[j][c];
     }
+    acc += dbm * a.b_bott[j];
+    float* dw = tr ? a.d_w_t1 + m * 260 : a.d_w_a1 + m * 256;
+    dw[j] += acc;                                       // the only writer of this row in this launch
+    if (j == 0) (tr ? a.d_b_t1 : a.d_b_a1)[m] += dbm;
 }
 
 // ---- transient embedding gradient: per-sample d emb (from the backward chain) summed per ray, added per image ---
@@ -488,7 +513,7 @@ hipError_t eo_launch_ambient_points_bwd(const AmbientW& w, const float* sun, con
     return hipGetLastError();
 }
 hipError_t eo_launch_bott_wgrad(const BottWgradArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_bott_wgrad, dim3(256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_bott_wgrad, dim3(256 + 128 + (a.w_t1 ? 128 : 0)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st, bool deterministic) {

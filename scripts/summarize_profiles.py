@@ -10,12 +10,13 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, "gpurun_out", "prof_r02")
+RT = os.environ.get("RT", "r03")
+SRC = os.path.join(REPO, "gpurun_out", "prof_" + RT)
 DST = os.path.join(REPO, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02_a"
+TAG = sys.argv[1] if len(sys.argv) > 1 else RT + "_a"
 SHORT = {"k_mlp_fwd<PBf16, true, 2>": "fwd_chain_camera", "k_mlp_fwd<PBf16, true, 1>": "fwd_chain_camera", "k_mlp_fwd<PBf16, false, 1>": "fwd_chain_sun",
          "k_mlp_bwd<PBf16, true, false, false, true>": "bwd_chain_camera", "k_mlp_bwd<PBf16, true, false, true, true>": "bwd_chain_camera",
-         "k_mlp_bwd<PBf16, false, true, false, true>": "bwd_chain_sun", "k_bwd_pipe": "bwd_pipe", "k_wgrad<PBf16>": "wgrad_gemm", "k_ig_tail": "ig_tail"}
+         "k_mlp_bwd<PBf16, false, true, false, true>": "bwd_chain_sun", "k_bwd_pipe": "bwd_pipe", "k_heads_pipe": "heads_pipe_camera", "k_wgrad<PBf16>": "wgrad_gemm", "k_ig_tail": "ig_tail_sun"}
 
 
 def short(name):
@@ -44,10 +45,10 @@ def durations(path):
 
 traffic = {}
 for wl in ("rgb", "full"):
-    shutil.copy(os.path.join(SRC, f"stats_{wl}", "r02_kernel_stats.csv"), os.path.join(DST, f"{TAG}_bench_{wl}_kernel_stats.csv"))
+    shutil.copy(os.path.join(SRC, f"stats_{wl}", "prof_kernel_stats.csv"), os.path.join(DST, f"{TAG}_bench_{wl}_kernel_stats.csv"))
     shutil.copy(os.path.join(SRC, f"bench_under_rocprof_{wl}.json"), os.path.join(DST, f"{TAG}_bench_{wl}_under_rocprof.json"))
-    f = counters(os.path.join(SRC, f"pmc_fetch_{wl}", "r02_counter_collection.csv"), {"FETCH_SIZE"})
-    w = counters(os.path.join(SRC, f"pmc_write_{wl}", "r02_counter_collection.csv"), {"WRITE_SIZE"})
+    f = counters(os.path.join(SRC, f"pmc_fetch_{wl}", "prof_counter_collection.csv"), {"FETCH_SIZE"})
+    w = counters(os.path.join(SRC, f"pmc_write_{wl}", "prof_counter_collection.csv"), {"WRITE_SIZE"})
     out = [["kernel", "launches_used", "fetch_bytes_per_launch(2xFETCH_SIZE)", "write_bytes_per_launch", "total_bytes_per_launch"]]
     tot = collections.defaultdict(float)
     step_total = 0.0
@@ -69,11 +70,22 @@ for wl in ("rgb", "full"):
     with open(os.path.join(DST, f"{TAG}_pmc_hbm_traffic_{wl}.csv"), "w", newline="") as fh:
         csv.writer(fh).writerows(out)
     traffic[f"{wl}_bf16"] = {k: v for k, v in tot.items()}
-    traffic[f"{wl}_bf16"]["bwd_pipe_camera"] = tot.get("bwd_pipe", 0.0)
+    # k_bwd_pipe runs twice per step in the full workload (sun pass first, then the camera pass): split its dispatches by order
+    pipe = [n for n in (set(f) | set(w)) if "k_bwd_pipe" in n]
+    if pipe:
+        fv = [v for _, v in sorted(f.get(pipe[0], {}).get("FETCH_SIZE", []))]
+        wv = [v for _, v in sorted(w.get(pipe[0], {}).get("WRITE_SIZE", []))]
+        if wl == "full":
+            fs, fc, ws_, wc = fv[0::2][2:], fv[1::2][2:], wv[0::2][2:], wv[1::2][2:]
+            avg = lambda x: sum(x) / max(1, len(x))
+            traffic[f"{wl}_bf16"]["bwd_pipe_sun"] = avg(fs) * 2 * 1024 + avg(ws_) * 1024
+            traffic[f"{wl}_bf16"]["bwd_pipe_camera"] = avg(fc) * 2 * 1024 + avg(wc) * 1024
+        else:
+            traffic[f"{wl}_bf16"]["bwd_pipe_camera"] = tot.get("bwd_pipe", 0.0)
     traffic[f"{wl}_bf16"]["step_total"] = step_total
     # MFMA busy
-    m = counters(os.path.join(SRC, f"pmc_mfma_{wl}", "r02_counter_collection.csv"), {"SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"})
-    dur = durations(os.path.join(SRC, f"pmc_mfma_{wl}", "r02_kernel_trace.csv"))
+    m = counters(os.path.join(SRC, f"pmc_mfma_{wl}", "prof_counter_collection.csv"), {"SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"})
+    dur = durations(os.path.join(SRC, f"pmc_mfma_{wl}", "prof_kernel_trace.csv"))
     out = [["kernel", "avg_ms", "mfma_busy_frac_of_simd_cycles", "effective_clock_GHz"]]
     for name in sorted(m):
         if not short(name):
@@ -87,7 +99,7 @@ for wl in ("rgb", "full"):
         out.append([name, f"{t:.4f}", f"{b / (a_ / 8 * 1024):.4f}", f"{a_ / 8 / (t * 1e-3) / 1e9:.3f}"])
     with open(os.path.join(DST, f"{TAG}_pmc_mfma_busy_{wl}.csv"), "w", newline="") as fh:
         csv.writer(fh).writerows(out)
-for name in ("bench.json", "bench_chain_gemm_path.json", "bench_fp32.json"):
+for name in ("bench.json", "bench_chain_gemm_path.json", "bench_fp32.json", "bench_heads_pipe.json"):
     shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_{name}"))
 traffic["_note"] = ("bytes per launch (per step for kernels launched twice a step) = (2*FETCH_SIZE + WRITE_SIZE)*1024: the L2's fabric-side "
                     "request counters (gfx950: FETCH_SIZE reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section; Infinity-Cache "

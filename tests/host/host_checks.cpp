@@ -111,15 +111,15 @@ static void check_carve(const CarveCfg& cfg, int n_rays, int flags) {
     add(v, "cnt_first", w.cnt_first, 4 * (size_t)n_rays, base); add(v, "cnt_retry", w.cnt_retry, 4 * (size_t)n_rays, base); add(v, "flags", w.flags, 16, base);
     add(v, "ray_rec", w.ray_rec, 4 * (size_t)n_rays * RAY_REC, base); add(v, "g_ray", w.g_ray, 4 * (size_t)n_rays * RAY_REC, base);
     add(v, "amb_save", w.amb_save, 4 * (size_t)n_rays * 160, base);
-    add(v, "m_bott+queue", w.m_bott, 4 * (2 * 128 * 256 + 64), base);
+    add(v, "m_bott+queue", w.m_bott, 4 * (BOTT_SCRATCH_F + 64), base);
     if (w.pipe.sync) {
         add(v, "sync", w.pipe.sync, PIPE_LAUNCHES * w.pipe.sync_bytes, base);
         add(v, "dy_in", w.pipe.dy_in, p_cap * 512, base); add(v, "dy_heads", w.pipe.dy_heads, p_cap * 512, base);
         const size_t edges = std::max((size_t)cfg.n_pipes * (PIPE_STAGES - 1), (size_t)cfg.n_pipes_heads * (HEADS_STAGES - 1));
         add(v, "rings", w.pipe.rings, edges * PIPE_RING * PIPE_UNIT_B, base);
         // the ONE memset of a backward call runs from m_bott to the end of the sync blocks: they must be adjacent
-        CHECK(reinterpret_cast<uint8_t*>(w.pipe.sync) >= reinterpret_cast<uint8_t*>(w.m_bott) + 4 * (2 * 128 * 256 + 64) &&
-              reinterpret_cast<uint8_t*>(w.pipe.sync) - (reinterpret_cast<uint8_t*>(w.m_bott) + 4 * (2 * 128 * 256 + 64)) < 256, "sync block not behind the GEMM queue");
+        CHECK(reinterpret_cast<uint8_t*>(w.pipe.sync) >= reinterpret_cast<uint8_t*>(w.m_bott) + 4 * (BOTT_SCRATCH_F + 64) &&
+              reinterpret_cast<uint8_t*>(w.pipe.sync) - (reinterpret_cast<uint8_t*>(w.m_bott) + 4 * (BOTT_SCRATCH_F + 64)) < 256, "sync block not behind the GEMM queue");
         const size_t wgs = std::max((size_t)cfg.n_pipes * PIPE_STAGES, (size_t)cfg.n_pipes_heads * HEADS_STAGES);
         CHECK(w.pipe.sync_bytes >= (64 + wgs * 32 + edges * 64) * 4, "sync block too small");
     }

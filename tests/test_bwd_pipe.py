@@ -62,10 +62,13 @@ def test_pipelined_backward_matches_chain_plus_gemm(R, epoch, heads_pipe):
     assert abs(l0 - l1) <= 1e-6 * abs(l0)             # the loss itself is an atomic sum over rays
     assert torch.isfinite(g1).all()
     for (name, p), a, b in zip(f_old.named_parameters(), f_old.grad_views(g0), f_new.grad_views(g1)):
-        # the bottleneck layer's weight gradient is the one product whose OPERANDS differ: the chain + GEMM path factors it as
-        # W_A1^T (dA1^T X8) with fp32 master weights and an un-rounded d bottleneck, the heads pipeline multiplies the bf16 d bottleneck
-        # tile it hands on with X8 directly (the plain bf16 model: every dY rounded where it is handed on) -- bf16 rounding, 2^-9 per element
-        tol = 1e-2 if (heads_pipe and name.startswith("bottleneck_layer")) else 1e-4
+        # three products have different OPERANDS in the two paths: the chain + GEMM path gets the weight gradients of the bottleneck layer
+        # and of the two head layers that read its output from the bottleneck FACTORS (dA1^T X8 etc. times fp32 master weights,
+        # BottWgradArgs: neither d bottleneck nor the bottleneck output is rounded or even stored), the heads pipeline multiplies the bf16
+        # tiles it hands on / finds saved (the plain bf16 model: every tensor rounded where it crosses a layer) -- bf16 rounding, 2^-9
+        # per element
+        factored = ("bottleneck_layer", "albedo_mlp.hidden_layers.0.weight", "transient_mlp.hidden_layers.0.weight")
+        tol = 1e-2 if (heads_pipe and name.startswith(factored)) else 1e-4
         assert (a - b).norm().item() <= tol * a.norm().item() + 1e-10, (name, (a - b).norm().item(), a.norm().item())
 
 
