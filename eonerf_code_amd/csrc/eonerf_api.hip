@@ -53,8 +53,6 @@ struct eonerf_ctx {
     bool weights_set = false;
     bool dens_dirty = false;         // density-only streams are re-packed lazily (only the shadow pass reads them) ...
     bool dens_used = false;          // ... until a step has used them: from then on they are re-packed with the others (one launch fewer per step)
-    hipStream_t side = nullptr;      // internal side stream: the per-ray ambient-head backward runs beside the weight-gradient GEMM
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // measurement hooks
     int prof_cap = 0;
     std::vector<hipEvent_t> prof_ev[EONERF_PROF_KERNELS][2];
@@ -402,9 +400,6 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
         { const char* f = getenv("EONERF_PIPE_STAMPS");
           if (!rc && ctx->pipe && f && atoi(f)) rc = (int)hipMalloc(&ctx->pipe_stamps, (size_t)ctx->n_pipes * PIPE_STAGES * 128 * sizeof(unsigned long long)); }
     }
-    if (!rc) rc = (int)hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
-    if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-    if (!rc) rc = (int)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (!rc) rc = (int)hipMalloc(&ctx->dev_status, 64 * sizeof(int));
     if (!rc) rc = (int)hipMemset(ctx->dev_status, 0, 64 * sizeof(int));
     if (!rc) {
@@ -458,9 +453,6 @@ int eonerf_destroy(eonerf_ctx* ctx) {
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     if (ctx->pipe_stamps) (void)hipFree(ctx->pipe_stamps);
     if (ctx->dev_status) (void)hipFree(ctx->dev_status);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
     return EONERF_OK;
 }
@@ -885,29 +877,13 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     if (hpipe) { const int rch = run_heads_pipe(ctx, w, w.cam, p_cap, d_flat, transient, st, 1, !shadows); if (rch) return rch; }
     if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 2, !shadows && !hpipe); if (rcp) return rcp; }
 
-    // ---- the per-ray ambient head (27 -> 128 -> 3, fp32; ~35 us on a few dozen workgroups) runs on the context's side stream BESIDE
-    //      the weight-gradient GEMM: it reads the ray records and writes gradients nobody else touches (ambient parameters).  Forked here
-    //      -- behind the pipelined launches, which want every CU to themselves -- and joined before the call returns, so the caller's
-    //      stream order still covers everything.  (s == 1 without the shadow pass: the head is outside the graph, sat_rendering.py:269-276,294)
-    const bool ambient_side = shadows && !ctx->deterministic && ctx->side;
-    AmbientBwdArgs ag;
-    if (shadows) {
-        ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
-        ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
-    }
-    if (ambient_side) {
-        HIP_TRY(hipEventRecord(ctx->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-        HIP_TRY(eo_launch_ambient_bwd(ag, ctx->side, false));
-        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
-    }
     {
         const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.queue, st, pipe, pipe && shadows, w.det.wgrad_part, pipe,
                                              hpipe ? w.pipe.dy_heads : nullptr);
-        if (rcw) { if (ambient_side) (void)hipStreamWaitEvent(st, ctx->ev_join, 0); return rcw; }
+        if (rcw) return rcw;
     }
 
-    // ---- embeddings -----------------------------------------------------------------------------------------
+    // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
     if (transient) {
         EmbGradArgs eg;
         eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays; eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0;
@@ -915,9 +891,14 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         HIP_TRY(eo_launch_emb_grad(eg, st));
         if (eg.d_emb_rays) HIP_TRY(eo_launch_table_reduce(eg.d_emb_rays, img_idx, n_rays, 4, 4, ctx->cfg.n_images, 0, eg.d_emb, st));
     }
-    if (!shadows) return EONERF_OK;
-    if (ambient_side) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
-    else HIP_TRY(eo_launch_ambient_bwd(ag, st, ctx->deterministic));
+    if (!shadows) return EONERF_OK;      // s == 1: rgb = albedo, the ambient head is outside the graph (sat_rendering.py:269-276,294)
+    // (27 -> 128 -> 3, fp32, ~35 us on a few dozen workgroups.  Running it on a side stream beside the weight-gradient GEMM was tried
+    //  and bought nothing: every large kernel of the step holds the whole register file of its CUs -- 8 waves x 256 registers -- so
+    //  the small kernel's workgroups only start when the large one's leave)
+    AmbientBwdArgs ag;
+    ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
+    ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
+    HIP_TRY(eo_launch_ambient_bwd(ag, st, ctx->deterministic));
     return EONERF_OK;
 }
 
