@@ -62,6 +62,9 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 #ifndef EO_PIPE_ORDB
 #define EO_PIPE_ORDB 0
 #endif
+#ifndef EO_PIPE_SPREAD
+#define EO_PIPE_SPREAD 0
+#endif
 constexpr int NSLOT = 4, DEPTH = EO_PIPE_DEPTH;      // LDS ring slots; steps of DMA in flight ahead of the one being multiplied (<= NSLOT - 1)
 static_assert(DEPTH >= 2 && DEPTH <= NSLOT - 1, "prefetch distance");
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
@@ -179,37 +182,49 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         const int row = 32 * wave + 16 * j + (lane >> 2);
         x_voff[j] = row * SEG_B + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
     }
-    auto issue = [&](int k) {      // DMA of this pipeline's k-th step (clamped by the caller) into LDS slot k & 3
-        if ((EO_PABL & 8) && k >= DEPTH) return;
+    // DMA of this pipeline's k-th step (clamped by the caller) into LDS slot k & 3: N_DMA (+ XD) pieces of 1 KiB per wave, issued in a
+    // block of their own between the phases.  In-kernel stamps (round 3) put that block at 320 cycles per step on waves 0..3 and 530 on
+    // waves 4..7 -- the critical path of a step -- so the pieces were also issued ONE AT A TIME between the MFMAs of the dW phase
+    // (build switch EO_PIPE_SPREAD=1, same vmcnt order, parity green): 1 % SLOWER on the same box (3.82 vs 3.79 ms full, 2.104 vs 2.090
+    // rgb).  Left off: the block form is what the partner wave's matrix phase overlaps best.
+    struct Dma { __amdgpu_buffer_rsrc_t rs_d, rs_x, rs_s; uint8_t* slot; uint8_t* dsg; bool on; };
+    auto dma_prep = [&](int k) {
+        Dma d;
+        d.on = !((EO_PABL & 8) && k >= DEPTH);
         const int g = S.pipe + k * a.n_pipes;                          // global step = sample tile
-        uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
+        d.slot = smem + (k & (NSLOT - 1)) * SLOT_B;
+        d.dsg = dsig_lds + (k & (NSLOT - 1)) * DSIG_B;
         // dY image: 16 pieces of 1 KiB, wave w copies pieces 2w, 2w+1
         const uint8_t* dsrc = !S.has_in ? a.dy_in + (size_t)g * IMG_B
                             : (in_blk ? in_blk + (size_t)g * IMG_B : ring_in + (size_t)(k & (PIPE_RING - 1)) * IMG_B);
-        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dsrc), 0, IMG_B, 0x00020000);
-        if (S.has_in) {      // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(slot + (2 * wave + j) * 1024), 16,
-                                                         lane * 16, (2 * wave + j) * 1024, 0, AUX_SC1);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(slot + (2 * wave + j) * 1024), 16,
-                                                         lane * 16, (2 * wave + j) * 1024, 0, AUX_NT);
-        }
+        d.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dsrc), 0, IMG_B, 0x00020000);
         // X image: rows of the activation slab, written by the forward kernel of an earlier launch (streaming: nt)
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(x_base) + (size_t)g * 256 * SEG_B, 0,
-                                                                             256 * SEG_B, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(slot + IMG_B + (32 * wave + 16 * j) * SEG_B), 16,
-                                                     x_voff[j], 0, 0, AUX_NT);
-        if constexpr (XD) {      // d sigma_pre of the step's samples: 128 B (lanes 32..63 fall outside the descriptor and bring zeros)
-            const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dsig) + (size_t)g * TS, 0, TS * 4, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (__attribute__((address_space(3))) void*)(dsig_lds + (k & (NSLOT - 1)) * DSIG_B), 4,
-                                                     lane * 4, 0, 0, AUX_NT);
+        d.rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(x_base) + (size_t)g * 256 * SEG_B, 0, 256 * SEG_B, 0x00020000);
+        // d sigma_pre of the step's samples (XD): 128 B (lanes 32..63 fall outside the descriptor and bring zeros)
+        d.rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(XD ? a.dsig : nullptr) + (XD ? (size_t)g * TS : 0), 0, TS * 4, 0x00020000);
+        return d;
+    };
+    auto dma_piece = [&](const Dma& d, int i) {      // i: compile-time constant at every call site
+        if (!d.on) return;
+        if (i < 2) {
+            // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
+            if (S.has_in)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
+                                                         lane * 16, (2 * wave + i) * 1024, 0, AUX_SC1);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
+                                                         lane * 16, (2 * wave + i) * 1024, 0, AUX_NT);
+        } else if (i < 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_x, (__attribute__((address_space(3))) void*)(d.slot + IMG_B + (32 * wave + 16 * (i - 2)) * SEG_B), 16,
+                                                     x_voff[i - 2], 0, 0, AUX_NT);
+        } else if constexpr (XD) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_s, (__attribute__((address_space(3))) void*)d.dsg, 4, lane * 4, 0, 0, AUX_NT);
         }
+    };
+    auto issue = [&](int k) {      // all pieces in one block (prologue)
+        const Dma d = dma_prep(k);
+#pragma unroll
+        for (int i = 0; i < N_DMA + XD; ++i) dma_piece(d, i);
     };
 
     // ---- per-lane LDS read offsets ----
@@ -392,7 +407,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 }
             }
         };
-        auto phase_dw = [&]() {        // dW += dY X^T over the 32 samples of the step, db += row sums
+        auto phase_dw = [&](const Dma& dma) {        // dW += dY X^T over the 32 samples of the step, db += row sums; the next DMA pieces in between
 #if EO_PIPE_DW16
             // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
             // LDS-DMA in flight and drains it)
@@ -450,6 +465,9 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 for (int j = 0; j < 8; ++j) {
                     if (!(EO_PABL & 1)) dw[j] = P::mma(af, bf[j & 1], dw[j]);
                     if (!(EO_PABL & 4) && j + 2 < 8) bf[j & 1] = lds_unit<P>(xb + (j + 2) * 2048);
+#if EO_PIPE_SPREAD
+                    if ((j & 1) && 4 * ks + (j >> 1) < N_DMA + XD) dma_piece(dma, 4 * ks + (j >> 1));      // pieces 0..3 behind MFMAs 1, 3, 5, 7 of the first K step, piece 4 (XD) behind MFMA 1 of the second
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // bias gradient: this lane's 8 samples of feature 32 wave + (lane & 31)
@@ -460,25 +478,32 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #endif
         };
         const int k_next = k + DEPTH < n_k ? k + DEPTH : n_k - 1;       // refill: into the slot step k-1 used (free behind this step's barrier)
+        const Dma dma = dma_prep(k_next);
+        auto issue_block = [&]() {
+#if !EO_PIPE_SPREAD
+#pragma unroll
+            for (int i = 0; i < N_DMA + XD; ++i) dma_piece(dma, i);
+#endif
+        };
         if (!ORDB) {
             phase_dx();
             const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            issue(k_next);
+            issue_block();
             const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            phase_dw();
+            phase_dw(dma);
             if (stamp) { t_dx += tt3 - tt2; t_is += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
         } else {
-#if EO_PIPE_ORDB == 1      // DMA issue -> dX -> dW: the step ends in matrix work (no epilogue tail behind the last MFMA of the SIMD)
-            issue(k_next);
+#if EO_PIPE_ORDB == 1      // DMA issue -> dX -> dW (measured 0.8 % slower, round 3)
+            issue_block();
             const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             phase_dx();
             const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            phase_dw();
+            phase_dw(dma);
             if (stamp) { t_is += tt3 - tt2; t_dx += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
 #else
-            issue(k_next);
+            issue_block();
             const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            phase_dw();
+            phase_dw(dma);
             const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             phase_dx();
             if (stamp) { t_is += tt3 - tt2; t_dw += tt4 - tt3; t_dx += __builtin_amdgcn_s_memtime() - tt4; }
