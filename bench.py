@@ -282,6 +282,8 @@ def main():
         dead = MAC_TRANSIENT if wl == "rgb" else 0
         pruned = 2.0 * ((MAC_FWD + MAC_BWD - dead + MAC_WGRAD - dead) * n_cam + 3 * MAC_DENS * n_sun)
         s8d = 3.0 * (F_CAM * n_cam + F_DEN * n_sun)             # train = 3 x forward FLOPs at the MEASURED sample counts
+        if kernels and len(kernels) == len(flop_of):            # every scope measured: their FLOPs are the step's useful work, no more, no less
+            assert abs(rec["kernel_flop_sum"] - pruned) <= 1e-9 * pruned, (rec["kernel_flop_sum"], pruned)
         sec = rec["ms_per_step"] * 1e-3                         # per GPU: RAYS rays per step and rank (weak scaling)
         rec["step_mfma_frac"] = {"kernels_useful_flop": pruned / sec / 1e12 / peak,
                                  "survey_8d_3xF_measured_samples": s8d / sec / 1e12 / peak}

@@ -317,9 +317,11 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         // 6-9 jobs are left, and 48 slices each would leave most CUs with one item and a few with two
         // Few jobs (the rgb state: 6): exactly two rounds -- just UNDER 2 items per CU, so that no workgroup starts a third item
         // (scripts/wgrad_items_sweep.sh: 0.33-0.35 ms at 504-512 items against 0.39 at ~1,024 and 0.36-0.37 at 448 / 640)
-        int fill = (4 * ctx->n_cu + tab.n - 1) / tab.n;
+        // Many jobs (the full state with the pipelined trunk: 13): ~2.5 items per CU -- round 3 sweep on one box, twice: 0.583 ms at 650
+        // items against 0.606 at 600, 0.590 at 700, 0.608 at 780-1,040 and 0.617 at the former ~4 per CU (1,027)
+        int fill = (int)(2.54 * ctx->n_cu / tab.n + 0.5);
         if (tab.n <= 8) fill = 2 * ctx->n_cu / tab.n;
-        int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : (fill > 48 ? (fill > 256 ? 256 : fill) : 48);
+        int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : (tab.n > 16 ? std::max(fill, 48) : std::min(std::max(fill, 1), 256));
         if (det_partials && sl > 48) sl = 48;       // the partial buffer holds WGRAD_MAX_JOBS x 48 items
         j.slices = sl < 1 ? 1 : sl;
         j.item0 = tab.items;
