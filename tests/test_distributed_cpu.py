@@ -83,3 +83,37 @@ def test_fault_flag_of_the_gradient_message_reaches_every_rank(tmp_path):
     (m0, s0), (m1, s1) = torch.load(tmp_path / "m0.pt"), torch.load(tmp_path / "m1.pt")
     assert torch.equal(m0, m1) and s0 == s1 == 0.5
     assert m0[8].item() == 1.0 and float(m0[:8].mean()) == 3.0 and float(m0[9:].abs().max()) == 0.0
+
+
+def _w8(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from eonerf_code_amd.trainer import reduce_gradients, rank_slice, RayTable
+    # configs[3] / configs[4] in miniature: 8 ranks, each its slice of ONE shared permutation of the ray table, one all-reduce per step
+    n = 8 * 16
+    rays = torch.arange(n, dtype=torch.float32)[:, None].repeat(1, 11)
+    table = RayTable(rays, torch.arange(n), torch.zeros(n, 3), "cpu", seed=42, rank=rank, world=world)
+    idx = table.batch(0, 1, 4)[1]                       # step 1 of epoch 0, 4 rays per rank
+    msg = torch.zeros(12)
+    msg[:8] = float(rank + 1)
+    scale = reduce_gradients(msg)
+    torch.save((idx, msg * scale), os.path.join(out_dir, f"w{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_ranks_share_one_permutation_and_average_their_gradients(tmp_path):
+    """BASELINE.json configs[3] / configs[4] (8 x MI355X, 32,768 rays per step) rehearsed on the CPU with gloo: every rank walks its own
+    slice of one shared per-epoch permutation (disjoint, together one contiguous run of the shuffled table) and the exchange step turns the
+    per-rank gradients into their mean."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_w8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    res = [torch.load(tmp_path / f"w{r}.pt") for r in range(8)]
+    seen = torch.cat([r[0] for r in res])
+    assert seen.numel() == 32 and seen.unique().numel() == 32
+    assert all(torch.equal(r[1], res[0][1]) for r in res)
+    assert float(res[0][1][0]) == 4.5                   # mean of 1..8

@@ -220,3 +220,27 @@ def test_zz_report_exactness_ratios():
     worst = sorted(RATIOS, reverse=True)[:5]
     print("worst exactness ratios (err / (ref_err + 2e-3 |fp64|)):", [(round(r, 3), t, n) for r, t, n in worst])
     assert worst[0][0] <= EXACT_FACTOR
+
+
+def test_iarpa_like_configuration_twenty_images_radiometric_fp32():
+    """BASELINE.json configs[4] (IARPA, 20 dates, learned radiometric correction) at a size the oracle evaluates in seconds: n_img = 20,
+    radiometric table away from its identity init, shadow pass on -- outputs and every gradient incl. the 20 x 9 radiometric table and the
+    20 x 4 transient embedding against torch autograd on the oracle.  ("RPC bundle-adjust params" do not exist in the shipped reference,
+    SURVEY.md 0.)"""
+    n_img, R = 20, 512
+    sd = orc.random_state_dict(n_img, seed=77, bias_scale=0.05, radiometric_jitter=0.1)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R, n_img, seed=78)
+    f = make_field(sd, n_img, "fp32")
+    loss, res = hip_step(f, rays, ts, rgbs, (u_cam, None, u_sun), 3)
+    ref_loss, ref = oracle_step(sd, rays, ts, rgbs, u_cam, u_sun, 3)
+    with torch.no_grad():
+        out, _ = orc.render_rays(orc.Field(sd), orc.define_satrays_from_tensors(rays, ts), u_cam, u_sun, 3, STEP)
+    assert (res["rgb"].detach().cpu() - out[:, 0:3]).abs().max().item() < 1e-4
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    check_as_exact_as_reference(f, ref, oracle_step64(sd, rays, ts, rgbs, u_cam, u_sun, 3), "iarpa20")
+    params = dict(f.named_parameters())
+    for name in ("radiometricT_enc.weight", "transient_encoder.weight"):
+        g, r = params[name].grad.cpu(), ref[name]
+        assert tuple(g.shape) == (n_img, 9 if "radio" in name else 4)
+        assert (g - r).norm().item() <= 2e-3 * r.norm().item() + 1e-9, name
