@@ -37,8 +37,8 @@
 #include "eonerf_kernels.h"
 
 // Diagnostic builds only (scripts/pipe_ablate.sh): EO_PABL bit 0 drops the dW MFMAs, bit 1 the dX MFMAs, bit 2 the B-fragment LDS reads of
-// both products, bit 3 the LDS-DMA refill, bit 4 the ring / slab stores, bit 5 the epilogue's VALU work and the bias sums.  Results are
-// WRONG with any bit set; the shipped library is built with EO_PABL == 0.
+// both products, bit 3 the LDS-DMA refill, bit 4 the ring / slab stores, bit 5 the epilogue's VALU work and the bias sums, bit 6 the final
+// flush of the stationary gradients.  Results are WRONG with any bit set; the shipped library is built with EO_PABL == 0.
 #ifndef EO_PABL
 #define EO_PABL 0
 #endif
@@ -561,6 +561,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         if (h == 0) pt[256 * 256 + 32 * wave + c] = db;
         return;
     }
+    if (EO_PABL & 64) return;      // diagnostic: no flush at all (what the 64 K atomics per workgroup cost)
     // rows >= 128 of a split stage (heads launch, "AT1": [albedo head; transient head]) belong to a second tensor; wave-uniform choice
     const bool hi = a.split[S.st] && wave >= 4;
     if (hi && a.skip_hi[S.st]) return;             // transient head outside the autograd graph: its rows carried zeros
