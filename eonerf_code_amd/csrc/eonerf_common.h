@@ -190,6 +190,44 @@ template <class P, int SLOT_BYTES> struct WStream {
         par ^= 1;
     }
     EO_DEV const uint8_t* cur() const { return lds + par * SLOT_BYTES; }
+    // a wave WITHOUT samples in the current tile (balanced tail, TileSched): it still owns 1 KiB of every copy round and a seat at
+    // every chunk barrier -- one pass over the chunk table, nothing else.  It has no younger stores to count: vmcnt(0).
+    EO_DEV void idle_tile() {
+        for (int i = 0; i < n_chunks; ++i) {
+            prefetch_next();
+            pump_rest();
+            if (EO_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            q = q + 1; if (q == n_chunks) q = 0;
+            par ^= 1;
+        }
+    }
+};
+
+// Tile schedule of the chain kernels.  The padded sample range is W = ceil(n_pts / TILE) * WAVES wave tiles of 32 samples.  Rounds in
+// which every workgroup has a whole tile run tile = round * grid + block, as ever.  What is left (R < WAVES * grid wave tiles) used
+// to be whole tiles for the first R / WAVES workgroups while the others idled through the last round: 7.49 rounds of work cost 8,
+// 5.19 (the shadow pass) 6.  Now the R wave tiles are dealt out evenly, a contiguous run of floor / ceil (R / grid) per workgroup:
+// every workgroup ends with ONE tile in which only its first `n` waves carry samples; the others step the weight stream
+// (WStream::idle_tile).  A tile with half the waves costs well under a whole one (one wave per SIMD has the matrix pipe to itself).
+template <class P> struct TileSched {
+    int full, grid, block, rem_start, rem_cnt;
+    EO_DEV TileSched(int n_pts, int grid_, int block_) : grid(grid_), block(block_) {
+        const int W = (n_pts + P::TILE - 1) / P::TILE * P::WAVES;
+        full = W / (P::WAVES * grid);
+        const int R = W - full * P::WAVES * grid, q = R / grid, r = R % grid;
+        rem_cnt = (EO_ABL & 32) ? 0 : q + (block < r ? 1 : 0);
+        rem_start = full * P::WAVES * grid + block * q + (block < r ? block : r);
+        if (EO_ABL & 32) {      // diagnostic: the former schedule (whole tiles only)
+            const int tiles = R / P::WAVES;
+            rem_cnt = block < tiles ? P::WAVES : 0;
+            rem_start = (full * grid + block) * P::WAVES;
+        }
+    }
+    EO_DEV int iters() const { return full + (rem_cnt > 0 ? 1 : 0); }
+    // first wave tile and number of waves with samples in iteration `it`
+    EO_DEV int first(int it) const { return it < full ? (it * grid + block) * P::WAVES : rem_start; }
+    EO_DEV int waves(int it) const { return it < full ? P::WAVES : rem_cnt; }
 };
 
 template <class P> EO_DEV typename P::U lds_unit(const uint8_t* p) {

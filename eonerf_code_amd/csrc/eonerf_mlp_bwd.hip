@@ -45,17 +45,20 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     WStream<P, SLOT> ws;
     ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks;
     ws.wave_b = __builtin_amdgcn_readfirstlane(wave) * 1024; ws.lane_b = lane * 16;
-    if ((int)blockIdx.x * P::TILE >= n_pts) return;
+    const TileSched<P> sched(n_pts, gridDim.x, blockIdx.x);
+    if (sched.iters() == 0) return;
     ws.start();
 #ifdef EO_STAMP
     const unsigned long long t_begin = EO_T();
 #endif
 
-    for (int tile = blockIdx.x; tile * P::TILE < n_pts; tile += gridDim.x) {
-        const int p = tile * P::TILE + wave * 32 + c;
+    for (int it = 0; it < sched.iters(); ++it) {
+        const int wt = sched.first(it) + __builtin_amdgcn_readfirstlane(wave);      // this wave's 32 samples (balanced tail: TileSched)
+        if (__builtin_amdgcn_readfirstlane(wave) >= sched.waves(it)) { ws.idle_tile(); continue; }
+        const int p = wt * 32 + c;
         const bool live = p < n_pts;
         SlabWriter<P, GrdMap> sw;                                                   // this wave's sample tile(s) of the gradient slab
-        sw.init(a.grd, a.p_pad / Slab<P>::TSAMP, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
+        sw.init(a.grd, a.p_pad / Slab<P>::TSAMP, wt * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
         uint32_t mb[4];
         auto& mid = sw;          // run_layer's slab-flush hooks
 
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                             if (s == 0 && h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
                         });
                 }
-                // this wave's 32 samples = step (tile * 8 + wave) of the heads pipeline: units 0..7 = dY_A1, 8..15 = dY_T1 (zeros when the
+                // this wave's 32 samples = step wt of the heads pipeline: units 0..7 = dY_A1, 8..15 = dY_T1 (zeros when the
                 // transient head is outside the graph)
-                uint8_t* dst = a.dy7_units + ((size_t)tile * (P::TILE / 32) + wave) * 16 * 1024 + lane * 16;
+                uint8_t* dst = a.dy7_units + (size_t)wt * 16 * 1024 + lane * 16;
 #pragma unroll
                 for (int kg = 0; kg < QKG; ++kg) {
                     *reinterpret_cast<U*>(dst + kg * 1024) = DA1[kg];
@@ -178,8 +181,8 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 run_layer<P, SLOT, HKG + 1, 8, false>(ws, mid, lane, h,
                     [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
                     [&](int mt, const f32x16& v, int s) { put_slice(P(), D, mt, s, mask_slice(P(), v, s, mt, mb[mt >> 1])); });
-                // this wave's 32 samples = step (tile * 8 + wave) of the pipeline: 16 units of 1 KiB
-                uint8_t* dst = a.dy7_units + ((size_t)tile * (P::TILE / 32) + wave) * 16 * 1024 + lane * 16;
+                // this wave's 32 samples = step wt of the pipeline: 16 units of 1 KiB
+                uint8_t* dst = a.dy7_units + (size_t)wt * 16 * 1024 + lane * 16;
 #pragma unroll
                 for (int kg = 0; kg < HKG; ++kg) *reinterpret_cast<U*>(dst + kg * 1024) = D[kg];
                 sw.drain();
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             if constexpr (PIPE == 1) {      // density pass: dY_7 = W_sigma^T d sigma_pre .* relu'; trunk and input gradient follow elsewhere
                 run_layer<P, SLOT, 1, 8, false>(ws, mid, lane, h, [&](int) { return u_sg; },
                     [&](int mt, const f32x16& v, int s) { put_slice(P(), D, mt, s, mask_slice(P(), v, s, mt, mb[mt >> 1])); });
-                uint8_t* dst = a.dy7_units + ((size_t)tile * (P::TILE / 32) + wave) * 16 * 1024 + lane * 16;
+                uint8_t* dst = a.dy7_units + (size_t)wt * 16 * 1024 + lane * 16;
 #pragma unroll
                 for (int kg = 0; kg < HKG; ++kg) *reinterpret_cast<U*>(dst + kg * 1024) = D[kg];
                 sw.drain();

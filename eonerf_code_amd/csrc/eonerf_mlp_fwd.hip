@@ -62,20 +62,23 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
     WStream<P, SLOT> ws;
     ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks;
     ws.wave_b = __builtin_amdgcn_readfirstlane(wave) * 1024; ws.lane_b = lane * 16;
-    if ((int)blockIdx.x * P::TILE >= n_pts) return;      // uniform per workgroup
+    const TileSched<P> sched(n_pts, gridDim.x, blockIdx.x);
+    if (sched.iters() == 0) return;      // uniform per workgroup
     ws.start();
 #ifdef EO_STAMP
     const unsigned long long t_begin = EO_T();
 #endif
 
-    for (int tile = blockIdx.x; tile * P::TILE < n_pts; tile += gridDim.x) {
-        const int p = tile * P::TILE + wave * 32 + c;          // this lane's sample (both halves share it)
+    for (int it = 0; it < sched.iters(); ++it) {
+        const int wt = sched.first(it) + __builtin_amdgcn_readfirstlane(wave);      // this wave's 32 samples
+        if (__builtin_amdgcn_readfirstlane(wave) >= sched.waves(it)) { ws.idle_tile(); continue; }
+        const int p = wt * 32 + c;          // this lane's sample (both halves share it)
         const bool live = p < n_pts;
         const float x = live ? a.px[p] : 0.f, y = live ? a.py[p] : 0.f, z = live ? a.pz[p] : 0.f;
         const EncUnits<P> E = encode_position<P>(x, y, z, h);
         SlabWriter<P, ActMap> sw;                                                   // this wave's sample tile(s) of the activation slab
         if constexpr (TRAIN) {
-            sw.init(a.act, a.p_pad / Slab<P>::TSAMP, tile * P::TILE + wave * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
+            sw.init(a.act, a.p_pad / Slab<P>::TSAMP, wt * 32, lane, smem + 2 * SLOT + wave * 2 * TR_WAVE_B);
 #pragma unroll
             for (int kg = 0; kg < EKG; ++kg)      // encoding slots, rows [0,64)
 #pragma unroll
