@@ -211,7 +211,7 @@ def main():
 
     torch.manual_seed(42)                                     # train_eonerf.py:37
     field = EONerfMLP(N_IMG, radiometric_normalization=True, precision=args.precision).to(dev)
-    trainer = FusedTrainer(field, lr=5e-4, max_rays=RAYS)
+    trainer = FusedTrainer(field, lr=5e-4, max_rays=RAYS, keep_message=os.environ.get("EONERF_KEEP_MESSAGE") == "1")
     trainer.set_noise_seed(1000 + 7919 * rank)
     # the GPU-resident ray table of the launcher (every rank holds the whole table and walks its slice of one shared permutation)
     table = RayTable(*synthetic_batch(RAYS * TABLE_BATCHES * world, N_IMG, seed=1234), dev, seed=42, rank=rank, world=world)

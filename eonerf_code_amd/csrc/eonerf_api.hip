@@ -52,7 +52,7 @@ struct eonerf_ctx {
                                      // written by the kernels, gates eonerf_adam_step, read and cleared only by eonerf_device_status
     bool weights_set = false;
     bool dens_dirty = false;         // density-only streams are re-packed lazily (only the shadow pass reads them) ...
-    bool dens_used = false;          // ... until a step has used them: from then on they are re-packed with the others (one launch fewer per step)
+    bool dens_used = false;          // ... unless the cycle since the last re-pack used them: then they are re-packed with the others (one launch fewer per step)
     // measurement hooks
     int prof_cap = 0;
     std::vector<hipEvent_t> prof_ev[EONERF_PROF_KERNELS][2];
@@ -137,6 +137,7 @@ AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
 }
 
 int ensure_density_streams(eonerf_ctx* ctx, const float* flat, hipStream_t st) {
+    ctx->dens_used = true;
     if (!ctx->dens_dirty) return 0;
     const int rc = ctx->pipe ? pack({&ctx->fwd_dens, &ctx->bwd_dens, &ctx->bwd_dens_heads, &ctx->ig_tail_wt}, flat, st)
                              : pack({&ctx->fwd_dens, &ctx->bwd_dens}, flat, st);
@@ -475,7 +476,7 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     if (!ctx || !flat) return EONERF_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     // pipelined backward: the camera pass reads the heads-only streams + the stage-stationary trunk weights; the density-only streams
-    // ride along once a step has used them (shadow pass on: they would be re-packed a few kernels later anyway)
+    // ride along when something has read them since the last re-pack (shadow pass on: they would be re-packed a few kernels later anyway)
     std::vector<const DevStream*> v;
     v.push_back(&ctx->fwd_full);
     if (ctx->heads_pipe) { v.push_back(&ctx->bwd_full_heads2); v.push_back(&ctx->bwd_rgb_heads2); v.push_back(&ctx->heads_pipe_wt); }
@@ -488,7 +489,7 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
         if (ctx->pipe) { v.push_back(&ctx->bwd_dens_heads); v.push_back(&ctx->ig_tail_wt); }
     }
     const int rc = pack(v, flat, st);
-    if (!rc) { ctx->weights_set = true; ctx->dens_dirty = !with_dens; ctx->full_ig_dirty = true; }
+    if (!rc) { ctx->weights_set = true; ctx->dens_dirty = !with_dens; ctx->full_ig_dirty = true; ctx->dens_used = false; }
     return rc;
 }
 
@@ -942,12 +943,20 @@ int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, in
     return (int)eo_launch_loss(out, pixels, n_rays, kind, d_out, loss, (hipStream_t)stream);
 }
 
-int eonerf_adam_step(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
-                     int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream) {
+static int adam_common(eonerf_ctx* ctx, float* flat, float* d_flat, bool zero_grad, float* exp_avg, float* exp_avg_sq,
+                       int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream) {
     if (!ctx || !flat || !d_flat || !exp_avg || !exp_avg_sq || step < 1) return EONERF_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(eo_launch_adam(flat, d_flat, exp_avg, exp_avg_sq, ctx->pl.total, step, lr, beta1, beta2, eps, grad_scale, ctx->dev_status, fault_flag, st));
+    HIP_TRY(eo_launch_adam(flat, d_flat, zero_grad, exp_avg, exp_avg_sq, ctx->pl.total, step, lr, beta1, beta2, eps, grad_scale, ctx->dev_status, fault_flag, st));
     return eonerf_set_weights(ctx, flat, stream);
+}
+int eonerf_adam_step(eonerf_ctx* ctx, float* flat, const float* d_flat, float* exp_avg, float* exp_avg_sq,
+                     int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream) {
+    return adam_common(ctx, flat, const_cast<float*>(d_flat), false, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale, fault_flag, stream);
+}
+int eonerf_adam_step_zero_grad(eonerf_ctx* ctx, float* flat, float* d_flat, float* exp_avg, float* exp_avg_sq,
+                               int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream) {
+    return adam_common(ctx, flat, d_flat, true, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale, fault_flag, stream);
 }
 
 }  // extern "C"

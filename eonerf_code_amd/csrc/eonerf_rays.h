@@ -137,7 +137,7 @@ hipError_t eo_launch_ambient_points_bwd(const AmbientW& w, const float* sun, con
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st);
 hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st);
 // status: the context's sticky device status word; fault_flag: reduced fault flag of the gradient message or nullptr (see k_adam)
-hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
+hipError_t eo_launch_adam(float* p, float* g, bool zero_grad, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
                           float gscale, int* status, const float* fault_flag, hipStream_t st);
 hipError_t eo_launch_grad_seal(float* tail, const int* status, hipStream_t st);
 hipError_t eo_launch_composite_fwd(const CompositeArgs& a, hipStream_t st);

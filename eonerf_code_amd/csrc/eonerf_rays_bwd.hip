@@ -451,6 +451,38 @@ __global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt,
     if (kind == 1 && blockIdx.x == 0 && threadIdx.x == 0) part += 1.5f;      // the constant 3/2 of the beta term (metrics.py:20)
     if ((threadIdx.x & 63) == 0) atomicAdd(loss, part);
 }
+// the same for batches of a few thousand rays (a training step): ONE workgroup, the scalar is stored, not accumulated -- no memset in front
+__global__ __launch_bounds__(1024) void k_loss_one(const float* out, const float* gt, int n, int kind, float* d_out, float* loss) {
+    __shared__ float wsum[16];
+    float part = 0.f;
+    const float inv = 1.f / (3.f * n);
+    for (int ray = threadIdx.x; ray < n; ray += 1024) {
+        const float* o = out + (size_t)ray * 21;
+        float* d = d_out + (size_t)ray * 21;
+#pragma unroll
+        for (int c = 0; c < 21; ++c) d[c] = 0.f;
+        if (kind == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float df = o[c] - gt[(size_t)ray * 3 + c]; part += df * df * inv; d[c] = 2.f * df * inv; }
+        } else {
+            const float beta = o[12], ib2 = 1.f / (beta * beta);
+            float sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float df = o[c] - gt[(size_t)ray * 3 + c]; sq += df * df; d[c] = df * ib2 * inv; }
+            part += 0.5f * sq * ib2 * inv + 0.5f * logf(beta) / n;
+            d[12] = -sq * ib2 / beta * inv + 0.5f / (n * beta);
+        }
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = kind == 1 ? 1.5f : 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        *loss = t;
+    }
+}
 
 // ---- torch.optim.Adam (no weight decay, no amsgrad) on the flat buffers --------------------------------------
 // ONE step count for every parameter: while epoch_idx < 2 the reference's graph still reaches the transient / ambient heads through
@@ -460,14 +492,20 @@ __global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt,
 // (a watchdog of the pipelined backward fired on this rank: its gradients are invalid) or when the reduced fault flag of the
 // gradient message is non-zero (some rank's are); the latter also raises the local status word so that this rank's next
 // eonerf_device_status reports it.
-__global__ void k_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+// ZERO: the gradient is consumed -- optimizer.step() and the optimizer.zero_grad() of the next iteration (train_eonerf.py:158-161) in
+// one pass; also on a skipped step (the invalid gradients must not leak into the next accumulation).
+template <bool ZERO>
+__global__ void k_adam(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                        float bc1, float bc2_sqrt, float gscale, int* status, const float* fault_flag) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool remote = fault_flag != nullptr && *fault_flag != 0.f;
     if (remote && i == 0) atomicOr(status, 0x100);
-    if (remote || (status != nullptr && *status != 0)) return;
+    const bool skip = remote || (status != nullptr && *status != 0);
     if (i >= n) return;
-    const float gi = g[i] * gscale;
+    const float graw = skip ? 0.f : g[i];
+    if (ZERO) g[i] = 0.f;
+    if (skip) return;
+    const float gi = graw * gscale;
     const float mi = m[i] + (1.f - b1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1-beta1)
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
@@ -534,15 +572,21 @@ hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st) {
+    if (n <= 8192) {
+        hipLaunchKernelGGL(k_loss_one, dim3(1), dim3(1024), 0, st, out, gt, n, kind, d_out, loss);
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_loss, dim3((n + 255) / 256), dim3(256), 0, st, out, gt, n, kind, d_out, loss);
     return hipGetLastError();
 }
-hipError_t eo_launch_adam(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
+hipError_t eo_launch_adam(float* p, float* g, bool zero_grad, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
                           float gscale, int* status, const float* fault_flag, hipStream_t st) {
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, status, fault_flag);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (zero_grad) hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, status, fault_flag);
+    else hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, status, fault_flag);
     return hipGetLastError();
 }
 hipError_t eo_launch_grad_seal(float* tail, const int* status, hipStream_t st) {

@@ -59,7 +59,7 @@ def main():
         rays, ts, rgbs = synthetic_batch(args.synthetic_rays, args.n_images)
     table = RayTable(rays, ts, rgbs, dev, seed=42, rank=rank, world=world)
     field = EONerfMLP(args.n_images, radiometric_normalization=True, precision=args.precision).to(dev)
-    trainer = FusedTrainer(field, lr=args.lr, max_rays=args.batch_size)
+    trainer = FusedTrainer(field, lr=args.lr, max_rays=args.batch_size, keep_message=False)
     trainer.set_noise_seed(42 + 1000003 * rank)                              # per-rank jitter stream
     steps_per_epoch = max(1, table.steps_per_epoch(args.batch_size))
     step, tic = 0, time.time()

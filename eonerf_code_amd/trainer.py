@@ -43,8 +43,14 @@ def rank_slice(n_total, rank, world):
 
 
 class FusedTrainer:
-    def __init__(self, field: EONerfMLP, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_rays: int = 4096):
+    def __init__(self, field: EONerfMLP, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_rays: int = 4096,
+                 keep_message: bool = True):
+        """keep_message=True: the gradient message survives the update (d_flat can be read after step()) and is sealed with the
+        fault flag even when there are no peers -- what tests and debugging want.  The launcher and bench.py pass False: the update
+        consumes the message (eonerf_adam_step_zero_grad: optimizer.step() + the next optimizer.zero_grad(), train_eonerf.py:158-161,
+        in one kernel) and a single process skips the seal (k_adam reads the status word itself): two launches fewer per step."""
         self.field = field
+        self.keep_message = keep_message
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat = field._ensure_packed()
         dev = self.flat.device
@@ -53,6 +59,7 @@ class FusedTrainer:
         self.n_params = self.flat.numel()
         # the gradient MESSAGE: parameters' gradients + 4 control floats ([n_params] = fault flag), one all-reduce unit
         self.d_flat = torch.zeros(self.L.eonerf_grad_floats(self.ctx), dtype=torch.float32, device=dev)
+        self._grad_clean = True      # d_flat holds zeros (fresh, or consumed by the last update)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0     # ONE Adam step count for every parameter (zero gradients still step, see k_adam)
@@ -127,11 +134,17 @@ class FusedTrainer:
                                                 _ptr(u_cam), _ptr(u_retry), _ptr(u_sun), n, flags, _ptr(self.out), _ptr(self.n_samples),
                                                 _ptr(ws), ws.numel(), st))
         loss = self.loss_grad(self.out[:n], pixels.contiguous(), epoch_idx, self.d_out)
-        self.d_flat.zero_()
+        if not self._grad_clean:      # (the update consumes the message: eonerf_adam_step_zero_grad)
+            self.d_flat.zero_()
+        self._grad_clean = False
         _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
                                                  _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
-        _lib.check(self.L.eonerf_grad_seal(self.ctx, _ptr(self.d_flat), st))
+        if self.keep_message or self._exchanges():     # the flag travels with the message; alone, k_adam reads the status word itself
+            _lib.check(self.L.eonerf_grad_seal(self.ctx, _ptr(self.d_flat), st))
         return loss
+
+    def _exchanges(self):
+        return self.dist_on and (self.world > 1 or os.environ.get("EONERF_FORCE_ALLREDUCE") == "1")
 
     def reduce_and_update(self):
         """Second half of a step: the one exchange (sum all-reduce of the message, side stream) and the fused Adam update, which
@@ -139,9 +152,11 @@ class FusedTrainer:
         st = _stream()
         gscale = self._reduce(st)
         self.step_count += 1
-        flag = C.c_void_p(self.d_flat.data_ptr() + 4 * self.n_params)
-        _lib.check(self.L.eonerf_adam_step(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, gscale, flag, st))
+        flag = C.c_void_p(self.d_flat.data_ptr() + 4 * self.n_params) if (self.keep_message or self._exchanges()) else None
+        adam = self.L.eonerf_adam_step if self.keep_message else self.L.eonerf_adam_step_zero_grad
+        _lib.check(adam(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                        self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, gscale, flag, st))
+        self._grad_clean = not self.keep_message
         self.field._packed_version = tuple(p._version for p in self.field.parameters())   # adam_step re-packed the weights
 
     def _reduce(self, st):

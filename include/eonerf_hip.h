@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EONERF_VERSION 300
+#define EONERF_VERSION 301
 
 enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4, EONERF_E_DEVICE = -5 };
 
@@ -193,6 +193,11 @@ int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, in
  * a skip through fault_flag also sets the status word, so the next eonerf_device_status on this rank reports it. */
 int eonerf_adam_step(eonerf_ctx* ctx, float* flat_params, const float* d_flat_params, float* exp_avg, float* exp_avg_sq,
                      int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream);
+/* The same, and the gradient message is CONSUMED: every float of d_flat_params is zero afterwards -- optimizer.step() fused with the
+ * optimizer.zero_grad() of the next iteration (train_eonerf.py:158-161), also when the update is skipped (invalid gradients must not
+ * leak into the next accumulation).  The 4 control floats behind the gradients are left to eonerf_grad_seal. */
+int eonerf_adam_step_zero_grad(eonerf_ctx* ctx, float* flat_params, float* d_flat_params, float* exp_avg, float* exp_avg_sq,
+                               int step, float lr, float beta1, float beta2, float eps, float grad_scale, const float* fault_flag, void* stream);
 
 /* Measurement hooks (no reference counterpart): with profiling enabled every launch of the MFMA kernels is bracketed by hipEvents on
  * the caller's stream, ONE scope per kernel launch (so a scope's time is that kernel's time).  In bf16 mode the backward of a pass is

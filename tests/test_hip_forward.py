@@ -34,7 +34,7 @@ def g8_sd(g):
 
 def test_library_loaded_and_versions():
     from eonerf_code_amd import _lib
-    assert _lib.lib().eonerf_version() == 300
+    assert _lib.lib().eonerf_version() == 301
     assert torch.cuda.is_available()
 
 

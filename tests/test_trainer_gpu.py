@@ -193,3 +193,34 @@ def test_without_radiometric_normalization_matches_the_oracle():
         rg = sdg[name].grad
         if rg is not None and rg.norm() > 0:
             assert ((g.cpu() - rg).norm() / rg.norm()).item() < 5e-3, name
+
+
+def test_lean_step_consumes_the_message_and_matches_the_kept_message_path(monkeypatch):
+    monkeypatch.setenv("EONERF_DETERMINISTIC", "1")                   # fixed-order reductions: the two trainers can be compared bit for bit
+    # keep_message=False (what bench.py and the launcher run): eonerf_adam_step_zero_grad leaves the message zeroed, no seal without
+    # peers, no separate zero fill -- same parameters and moments as the path that keeps the message, step after step
+    from eonerf_code_amd.trainer import FusedTrainer
+    f1, tr1, _ = _make(seed=71, precision="bf16")
+    f2, _, _ = _make(seed=71, precision="bf16")
+    tr2 = FusedTrainer(f2, lr=5e-4, max_rays=R, keep_message=False)
+    rays, img, pix, noise = _batch(seed=72)
+    for epoch in (0, 3, 3):
+        l1 = float(tr1.step(rays, img, pix, epoch, noise=noise))
+        l2 = float(tr2.step(rays, img, pix, epoch, noise=noise))
+        assert l1 == l2
+        assert tr2.d_flat.abs().max().item() == 0.0                   # consumed
+        assert tr1.d_flat[:tr1.n_params].abs().max().item() > 0.0     # kept
+    assert torch.equal(tr1.flat.detach(), tr2.flat.detach()) and torch.equal(tr1.exp_avg_sq, tr2.exp_avg_sq)
+    # a fault: the lean path skips the update through the status word alone and still hands back a clean message
+    from eonerf_code_amd import _lib
+    from eonerf_code_amd.radiance_fields.eonerf import _ptr, _stream
+    tr2.forward_backward(rays, img, pix, 3, noise=noise)
+    flag = torch.ones(1, device="cuda")
+    p0 = tr2.flat.detach().clone()
+    tr2.step_count += 1
+    _lib.check(tr2.L.eonerf_adam_step_zero_grad(tr2.ctx, _ptr(tr2.flat), _ptr(tr2.d_flat), _ptr(tr2.exp_avg), _ptr(tr2.exp_avg_sq),
+                                                tr2.step_count, 5e-4, 0.9, 0.999, 1e-8, 1.0, _ptr(flag), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(tr2.flat.detach(), p0) and tr2.d_flat[:tr2.n_params].abs().max().item() == 0.0
+    with pytest.raises(RuntimeError, match="hand-off"):
+        tr2.check_device_status()
