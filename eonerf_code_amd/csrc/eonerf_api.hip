@@ -29,6 +29,7 @@ struct eonerf_ctx {
     eonerf_config cfg;
     bool bf16;
     int n_cu;
+    int wgrad_riders = 1;   // EONERF_WGRAD_RIDERS=0: the sigma row and the embedding columns as jobs of their own (A/B switch)
     int wgrad_items;      // target number of weight-gradient work items per launch (EONERF_WGRAD_ITEMS, default 48 per job)
     ParamLayout pl;
     DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig, pipe_wt, bwd_full_heads, bwd_rgb_heads, bwd_dens_heads, ig_tail_wt;
@@ -242,6 +243,11 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
     tab.n = 0;
+    memset(&tab.aux, 0, sizeof(tab.aux));
+    tab.aux.job = -1;
+    // riders of the bottleneck-factor job (WgradAux): the sigma row and the embedding columns of the camera pass travel with the job that
+    // streams X_8 / dY_T1 anyway.  Not in deterministic mode (its partial-sum tiles have no room for them) nor with the heads pipeline
+    const bool riders = full && !heads_units && !det_partials && ctx->wgrad_riders;
     const size_t n_tiles = (size_t)p_cap / (ctx->bf16 ? 32 : 16);      // sample tiles of the slabs (block-major layout, eonerf_common.h)
     auto seg0 = [&](const void* slab, SlabBlk blk, int row) {           // (row, sample tile 0)
         return reinterpret_cast<const uint8_t*>(slab) + ((size_t)blk.s * n_tiles + (row - blk.s)) * SEG_B;
@@ -262,7 +268,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     };
     // pipelined: the 256 x 256 products of layers 1..7 (and their biases) were accumulated by the layer-pipelined trunk backward;
     // what is left are the two 256 x 64 products against the encoding (layer 0, skip columns of layer 5) and the sigma row
-    auto trunk_jobs = [&](const PassBuffers& b, bool pipelined) {
+    auto trunk_jobs = [&](const PassBuffers& b, bool pipelined, bool sigma_job) {
         // (pipelined: dY_0 and dY_5 lie in their slab tiles in unit order -- written once by the stages of layers 1 and 6)
         add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
         tab.j[tab.n - 1].a_units = pipelined;
@@ -273,11 +279,11 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
             if (l == 5)   // skip columns 256..318 <- encoding slots
                 { add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1); tab.j[tab.n - 1].a_units = pipelined; }
         }
-        add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
+        if (sigma_job) add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
     };
     if (full) {
         const PassBuffers& c = *full;
-        trunk_jobs(c, full_trunk_done);
+        trunk_jobs(c, full_trunk_done, !riders);
         if (!heads_units) {
         // bottleneck factors M_a = dA1^T X8 (and M_t = dT1^T X8) + the bias gradients db_A1 (db_T1), finished by eo_launch_bott_wgrad
         // below into THREE weight gradients: the bottleneck layer's and the two head layers' that read the bottleneck output (which is
@@ -290,6 +296,16 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         } else {
             add(c, GRD_ROW_A1, 128, ACT_ROW_X1 + 256 * 7, 256, m_bott, 256, db_at, nullptr, 2, 4, 2, 2);
         }
+        if (riders) {
+            WgradAux& x = tab.aux;
+            x.job = tab.n - 1;
+            x.a2 = seg0(c.grd, GrdMap::block(GRD_ROW_SIG), GRD_ROW_SIG); x.a2_stride = (uint32_t)(GrdMap::block(GRD_ROW_SIG).r * SEG_B);
+            x.dw_sig = dptr(pl.sig_w); x.db_sig = dptr(pl.sig_b);
+            if (transient) {
+                x.b2 = seg0(c.act, ActMap::block(ACT_ROW_EMB), ACT_ROW_EMB); x.b2_stride = (uint32_t)(ActMap::block(ACT_ROW_EMB).r * SEG_B);
+                x.dw_emb = dptr(pl.t_w[0]) + 256; x.emb_ld = 260; x.emb_row0 = 128;
+            }
+        }
         }
         add(c, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
         if (transient && heads_units) {
@@ -301,14 +317,14 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
             split_at(128, dptr(pl.t_w[0]) + 256, 260, nullptr);
         }
         if (transient) {
-            if (!heads_units) add(c, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
+            if (!heads_units && !riders) add(c, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
             for (int l = 1; l < 4; ++l)
                 add(c, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
             add(c, GRD_ROW_T5, 2, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);     // row 0: d ts_pre, row 1: d tb_pre
             split_at(1, dptr(pl.tbe_w), 128, dptr(pl.tbe_b));
         }
     }
-    if (dens) trunk_jobs(*dens, dens_trunk_done);
+    if (dens) trunk_jobs(*dens, dens_trunk_done, true);
     // every work item = one slice of one job's sample range.  Equal slices: a K step costs about the same for every job shape
     // (the loop is latency-bound); default 48 slices per job (measured: flat from ~2.4 to 6.5 items per CU, clearly slower below 2)
     tab.items = 0;
@@ -325,9 +341,8 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : (tab.n > 16 ? std::max(fill, 48) : std::min(std::max(fill, 1), 256));
         if (det_partials && sl > 48) sl = 48;       // the partial buffer holds WGRAD_MAX_JOBS x 48 items
         j.slices = sl < 1 ? 1 : sl;
-        j.item0 = tab.items;
-        tab.items += j.slices;
     }
+    for (int k = 0; k < tab.n; ++k) { tab.j[k].item0 = tab.items; tab.items += tab.j[k].slices; }
     { ProfScope ps(ctx, EONERF_PROF_WGRAD, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed)); }
     if (full && !heads_units) {   // the three weight gradients that follow from the bottleneck factors the GEMM above accumulated
         BottWgradArgs bw;
@@ -375,6 +390,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete ctx; return (int)hipErrorNoDevice; }
     ctx->n_cu = prop.multiProcessorCount;
     { const char* e = getenv("EONERF_WGRAD_ITEMS"); ctx->wgrad_items = e && atoi(e) > 0 ? atoi(e) : 0; }
+    { const char* e = getenv("EONERF_WGRAD_RIDERS"); if (e) ctx->wgrad_riders = atoi(e); }
     ctx->pl.build(cfg->n_images);
     int rc = upload(ctx->fwd_full, build_fwd_stream(ctx->pl, ctx->bf16, true));
     if (!rc) rc = upload(ctx->fwd_dens, build_fwd_stream(ctx->pl, ctx->bf16, false));

@@ -177,8 +177,22 @@ hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode
 // pipe: 0 = the whole dX chain; 1 = stop at dY_7 (the trunk is pipelined); 2 (camera pass) = stop at [dY_A1; dY_T1] (heads + trunk pipelined)
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, int pipe = 0);
 constexpr int WGRAD_MAX_JOBS = 32;     // <= 31 used (fp32 chain + GEMM path, full model); the table must fit the 4-KiB kernel-argument segment
-static_assert(sizeof(WgradJob) * WGRAD_MAX_JOBS + 8 <= 4096, "job table exceeds the kernel-argument segment");
-struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; int n; int items; };   // by value in the kernel-argument segment; jobs sorted heaviest first
+static_assert(sizeof(WgradJob) * WGRAD_MAX_JOBS + 8 + 64 <= 4096, "job table exceeds the kernel-argument segment");
+// Riders of ONE job (the bottleneck-factor job [dY_A1; dY_T1] x X_8 of the camera pass): two tiny products whose big operand that job
+// streams anyway, so that nothing reads it a second time --
+//   sigma row : dW_sigma = sum_p d sigma_pre[p] X_8[:, p]: a ONE-row A operand (a2: row 0 of the d sigma_pre block) against the job's own
+//               B fragments, one more MFMA per B fragment on the waves of the first row group (formerly a job of its own: X_8 re-read);
+//   embedding : dW_T1[:, 256:260] = sum_p dY_T1[:, p] emb[:, p]^T: the 4 embedding rows (b2) sit beside the ones column of the bias
+//               MFMA's B fragment -- columns 1..4 of a product that is computed anyway (formerly a job of its own: dY_T1 re-read).
+struct WgradAux {
+    int job;              // index in the table, -1: none
+    int emb_row0, emb_ld; // rows >= emb_row0 of the job are dY_T1; row stride of dw_emb
+    uint32_t a2_stride, b2_stride;
+    const void* a2;       // d sigma_pre block, sample tile 0 (nullptr: no sigma rider)
+    const void* b2;       // embedding block, sample tile 0 (nullptr: no embedding rider)
+    float *dw_sig, *db_sig, *dw_emb;
+};
+struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; WgradAux aux; int n; int items; };   // by value in the kernel-argument segment; jobs sorted heaviest first
 // partials != nullptr (deterministic mode): every work item stores its tile to partials[item] ([256][256] dW | [256] db) instead of
 // adding it atomically, and a second kernel sums the items of a job in slice order
 constexpr int WGRAD_PART_F = 256 * 256 + 256;
