@@ -151,7 +151,10 @@ def kernel_model(wl, piped, n_cam, n_sun, elt):
         # pipelined trunk: dX AND dW of layers 1..7; reads dY_7 + X1..X7, writes dY_5 / dY_0 for the jobs the GEMM keeps
         flop["bwd_pipe_camera"] = 2.0 * (trunk_dx + trunk_dw) * n_cam
         byts["bwd_pipe_camera"] = (256 + 7 * 256 + 2 * 256) * elt * n_cam
-        cam_rows_rd = 2 * 320 + 257 + 131 + (2 * 384 if wl == "rgb" else 2 * 512 + 132 + 3 * 256 + 130)
+        # the GEMM jobs the pipelined trunk leaves: layer 0 and skip columns (256 + 64 rows each), the bottleneck-factor job
+        # ([dY_A1 (; dY_T1)] x X_8, with the sigma row and the 4 embedding rows riding on it), albedo output layer (3 + 128) and, with
+        # the transient head in the graph, its three 128 x 128 layers and the two output rows (2 + 128)
+        cam_rows_rd = 2 * 320 + 131 + ((128 + 256 + 1) if wl == "rgb" else (256 + 256 + 1 + 4) + 3 * 256 + 130)
         flop["wgrad_gemm"] = 2.0 * (MAC_WGRAD - dead - trunk_dw) * n_cam
         byts["wgrad_gemm"] = cam_rows_rd * elt * n_cam
         if wl == "full":

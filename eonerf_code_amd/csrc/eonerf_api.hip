@@ -325,19 +325,27 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         }
     }
     if (dens) trunk_jobs(*dens, dens_trunk_done, true);
-    // every work item = one slice of one job's sample range.  Equal slices: a K step costs about the same for every job shape
-    // (the loop is latency-bound); default 48 slices per job (measured: flat from ~2.4 to 6.5 items per CU, clearly slower below 2)
+    // every work item = one slice of one job's sample range, equal slices for every job; persistent workgroups pull items from one
+    // counter.  Since the K loop is instantiated per tile shape the launch is HBM-bound (5.7 TB/s) and an item's time follows the
+    // bytes its job moves per K step.  Measured rules (scripts/wgrad_items_sweep.sh; slices in proportion to the bytes were tried
+    // twice and lost to equal slices at every item count):
+    //   few jobs (the rgb state: 4): the HEAVY jobs' items (>= 45 % of the heaviest job's bytes per step) fill exactly one round,
+    //     just under one item per CU, and the light jobs' items fill the gaps behind them: 0.227-0.238 ms at 288-320 items against
+    //     0.26 at 512 and 0.28 at 352 (heavy items spill into a second round)
+    //   many jobs (the full state with the pipelined trunk: 11): ~2.5 items per CU: flat (0.472-0.478 ms) from 650 to 830 items,
+    //     0.49-0.50 at 512-600 and at 1,024
+    double wmax = 0.0, wj[WGRAD_MAX_JOBS];
+    for (int k = 0; k < tab.n; ++k) {
+        wj[k] = (double)((tab.j[k].m_rows + 15) / 16 * 16 + (tab.j[k].n_rows + 15) / 16 * 16) * SEG_B;
+        wmax = std::max(wmax, wj[k]);
+    }
+    int n_heavy = 0;
+    for (int k = 0; k < tab.n; ++k) n_heavy += wj[k] >= 0.45 * wmax ? 1 : 0;
     tab.items = 0;
     for (int k = 0; k < tab.n; ++k) {
         WgradJob& j = tab.j[k];
-        // ... but never fewer than ~4 items per CU in the launch: with the trunk's 256 x 256 products gone to the pipelined backward only
-        // 6-9 jobs are left, and 48 slices each would leave most CUs with one item and a few with two
-        // Few jobs (the rgb state: 6): exactly two rounds -- just UNDER 2 items per CU, so that no workgroup starts a third item
-        // (scripts/wgrad_items_sweep.sh: 0.33-0.35 ms at 504-512 items against 0.39 at ~1,024 and 0.36-0.37 at 448 / 640)
-        // Many jobs (the full state with the pipelined trunk: 13): ~2.5 items per CU -- round 3 sweep on one box, twice: 0.583 ms at 650
-        // items against 0.606 at 600, 0.590 at 700, 0.608 at 780-1,040 and 0.617 at the former ~4 per CU (1,027)
         int fill = (int)(2.54 * ctx->n_cu / tab.n + 0.5);
-        if (tab.n <= 8) fill = 2 * ctx->n_cu / tab.n;
+        if (tab.n <= 8) fill = (ctx->n_cu - 1) / std::max(n_heavy, 1);
         int sl = ctx->wgrad_items ? (ctx->wgrad_items + tab.n / 2) / tab.n : (tab.n > 16 ? std::max(fill, 48) : std::min(std::max(fill, 1), 256));
         if (det_partials && sl > 48) sl = 48;       // the partial buffer holds WGRAD_MAX_JOBS x 48 items
         j.slices = sl < 1 ? 1 : sl;
