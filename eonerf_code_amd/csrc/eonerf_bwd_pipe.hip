@@ -65,6 +65,9 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 #ifndef EO_PIPE_SPREAD
 #define EO_PIPE_SPREAD 0
 #endif
+#ifndef EO_PIPE_STAMPS      // 1: the per-phase cycle stamps of scripts/pipe_stamps.py are compiled in (scripts/stamp.sh builds that library)
+#define EO_PIPE_STAMPS 0
+#endif
 constexpr int NSLOT = 4, DEPTH = EO_PIPE_DEPTH;      // LDS ring slots; steps of DMA in flight ahead of the one being multiplied (<= NSLOT - 1)
 static_assert(DEPTH >= 2 && DEPTH <= NSLOT - 1, "prefetch distance");
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
@@ -187,21 +190,29 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     // waves 4..7 -- the critical path of a step -- so the pieces were also issued ONE AT A TIME between the MFMAs of the dW phase
     // (build switch EO_PIPE_SPREAD=1, same vmcnt order, parity green): 1 % SLOWER on the same box (3.82 vs 3.79 ms full, 2.104 vs 2.090
     // rgb).  Left off: the block form is what the partner wave's matrix phase overlaps best.
-    struct Dma { __amdgpu_buffer_rsrc_t rs_d, rs_x, rs_s; uint8_t* slot; uint8_t* dsg; bool on; };
+    // ONE descriptor per source for the whole launch; the step enters through the scalar offset of the load (a descriptor per step
+    // cost ~40 scalar instructions and a handful of branches in every step of every wave: the stage is instruction-issue bound --
+    // 320 instructions per wave and step around 32 MFMAs)
+    const uint32_t lin_stride = (uint32_t)a.n_pipes * IMG_B;      // this pipeline's consecutive steps in a linear buffer (sample tile = pipe + k n_pipes)
+    const bool in_ring = S.has_in && !in_blk;
+    const uint8_t* const d_base = !S.has_in ? a.dy_in + (size_t)S.pipe * IMG_B : (in_blk ? in_blk + (size_t)S.pipe * IMG_B : ring_in);
+    const uint32_t d_mask = in_ring ? PIPE_RING - 1 : 0x7fffffffu, d_mul = in_ring ? IMG_B : lin_stride;
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(d_base), 0, -1, 0x00020000);
+    // X image: rows of the activation slab, written by the forward kernel of an earlier launch (streaming: nt)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(x_base) + (size_t)S.pipe * 256 * SEG_B, 0, -1, 0x00020000);
+    // output: the next stage's ring (MODE 0) or this pipeline's tiles of a linear buffer
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(MODE == 0 ? ring_out : grd_blk + (size_t)S.pipe * IMG_B, 0, -1, 0x00020000);
+    const int v_dy = lane * 16 + (2 * wave) * 1024;               // this wave's two pieces of a 16-KiB unit-order image (loads and stores)
+    struct Dma { uint32_t so_d, so_x; __amdgpu_buffer_rsrc_t rs_s; uint8_t* slot; uint8_t* dsg; bool on; };
     auto dma_prep = [&](int k) {
         Dma d;
         d.on = !((EO_PABL & 8) && k >= DEPTH);
-        const int g = S.pipe + k * a.n_pipes;                          // global step = sample tile
         d.slot = smem + (k & (NSLOT - 1)) * SLOT_B;
         d.dsg = dsig_lds + (k & (NSLOT - 1)) * DSIG_B;
-        // dY image: 16 pieces of 1 KiB, wave w copies pieces 2w, 2w+1
-        const uint8_t* dsrc = !S.has_in ? a.dy_in + (size_t)g * IMG_B
-                            : (in_blk ? in_blk + (size_t)g * IMG_B : ring_in + (size_t)(k & (PIPE_RING - 1)) * IMG_B);
-        d.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dsrc), 0, IMG_B, 0x00020000);
-        // X image: rows of the activation slab, written by the forward kernel of an earlier launch (streaming: nt)
-        d.rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(x_base) + (size_t)g * 256 * SEG_B, 0, 256 * SEG_B, 0x00020000);
+        d.so_d = ((uint32_t)k & d_mask) * d_mul;
+        d.so_x = (uint32_t)k * lin_stride;
         // d sigma_pre of the step's samples (XD): 128 B (lanes 32..63 fall outside the descriptor and bring zeros)
-        d.rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(XD ? a.dsig : nullptr) + (XD ? (size_t)g * TS : 0), 0, TS * 4, 0x00020000);
+        if constexpr (XD) d.rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dsig) + (size_t)(S.pipe + k * a.n_pipes) * TS, 0, TS * 4, 0x00020000);
         return d;
     };
     auto dma_piece = [&](const Dma& d, int i) {      // i: compile-time constant at every call site
@@ -209,14 +220,14 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         if (i < 2) {
             // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
             if (S.has_in)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
-                                                         lane * 16, (2 * wave + i) * 1024, 0, AUX_SC1);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
+                                                         v_dy + i * 1024, d.so_d, 0, AUX_SC1);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
-                                                         lane * 16, (2 * wave + i) * 1024, 0, AUX_NT);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
+                                                         v_dy + i * 1024, d.so_d, 0, AUX_NT);
         } else if (i < 4) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_x, (__attribute__((address_space(3))) void*)(d.slot + IMG_B + (32 * wave + 16 * (i - 2)) * SEG_B), 16,
-                                                     x_voff[i - 2], 0, 0, AUX_NT);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(d.slot + IMG_B + (32 * wave + 16 * (i - 2)) * SEG_B), 16,
+                                                     x_voff[i - 2], d.so_x, 0, AUX_NT);
         } else if constexpr (XD) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_s, (__attribute__((address_space(3))) void*)d.dsg, 4, lane * 4, 0, 0, AUX_NT);
         }
@@ -281,7 +292,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     };
 
     // diagnostics: cycle sums of this wave (total loop, slow-path spins, counted wait, barrier, dX phase, dW phase)
-    const bool stamp = a.stamps != nullptr;
+    const bool stamp = EO_PIPE_STAMPS && a.stamps != nullptr;      // (build switch: scripts/stamp.sh; the production loop carries no stamp code)
     unsigned long long t_slow = 0, t_top = 0, t_bar = 0, t_dx = 0, t_is = 0, t_dw = 0, n_slow = 0;
     const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -391,19 +402,13 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 w8[s] = r;
             }
             if (!(EO_PABL & 16)) {
-                if (MODE == 0) {
-                    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ring_out + (size_t)(k & (PIPE_RING - 1)) * IMG_B, 0, IMG_B, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
-                } else {
-                    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(grd_blk + (size_t)(S.pipe + k * a.n_pipes) * IMG_B, 0, IMG_B, 0x00020000);
-                    if (MODE == 1) {
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_SC1);
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_SC1);
-                    } else {      // read by a LATER launch (the GEMM's jobs; the trunk launch): streaming
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, lane * 16, (2 * wave) * 1024, AUX_NT);
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, lane * 16, (2 * wave + 1) * 1024, AUX_NT);
-                    }
+                const uint32_t so_o = MODE == 0 ? ((uint32_t)k & (PIPE_RING - 1)) * IMG_B : (uint32_t)k * lin_stride;
+                if (MODE == 0 || MODE == 1) {      // read inside this launch: write-through
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, v_dy, so_o, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, v_dy + 1024, so_o, AUX_SC1);
+                } else {      // read by a LATER launch (the GEMM's jobs; the trunk launch): streaming
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, v_dy, so_o, AUX_NT);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, v_dy + 1024, so_o, AUX_NT);
                 }
             }
         };
