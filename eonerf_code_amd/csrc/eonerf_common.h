@@ -136,16 +136,20 @@ template <class P, int SLOT_BYTES> struct WStream {
     // scalar arithmetic, a scalar branch for the tail): a round costs the wave a handful of scalar instructions besides the
     // DMA itself.  The tail piece is copied whole (chunks are padded to 1 KiB by rounding the copy up: the slot is a multiple
     // of 1 KiB and the stream allocation carries 1 KiB of slack).
+    // (buffer form: ONE descriptor for the launch, the piece enters through the scalar offset -- the flat form cost a 64-bit scalar add
+    // and a 64-bit vector add per round, 240 rounds per sample tile)
+    __amdgpu_buffer_rsrc_t rs;
     EO_DEV void round() {
         const uint32_t o = pf_base + wave_b;
         if (o < pf_bytes)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + pf_off + o + lane_b),
-                                             (__attribute__((address_space(3))) void*)(lds + pf_slot * SLOT_BYTES + o), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + pf_slot * SLOT_BYTES + o), 16,
+                                                     lane_b, pf_off + o, 0, 0);
         pf_base += ROUND_B;
     }
     // first chunk of the launch
     EO_DEV void start() {
         q = 0; par = 0;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g), 0, -1, 0x00020000);
         const ChunkDesc d = desc(0);
         pf_off = d.off; pf_bytes = d.bytes; pf_base = 0; pf_slot = 0;
         while (pf_base < pf_bytes) round();
