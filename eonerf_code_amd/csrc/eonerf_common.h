@@ -401,6 +401,16 @@ EO_DEV Sl<PF32> relu_slice(PF32, const f32x16& acc, int s, uint32_t& bits) {
     bits = s == 0 ? t : (bits | t);
     return Sl<PF32>{p0 ? a0 : 0.f, p1 ? a1 : 0.f};
 }
+// forward, ReLU only (nobody reads this layer's mask bits)
+EO_DEV Sl<PBf16> relu_only_slice(PBf16, const f32x16& acc, int s) {
+    const s16x2 z = {0, 0};
+    const uint32_t wi = cvt_pk_bf16(acc[2 * s], acc[2 * s + 1]);
+    return Sl<PBf16>{__builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wi), z))};
+}
+EO_DEV Sl<PF32> relu_only_slice(PF32, const f32x16& acc, int s) {
+    const float a0 = acc[2 * s], a1 = acc[2 * s + 1];
+    return Sl<PF32>{a0 > 0.f ? a0 : 0.f, a1 > 0.f ? a1 : 0.f};
+}
 // after the last slice: fold the tile's flags into the mask dword of its tile PAIR
 EO_DEV void mask_commit(PBf16, int mt, uint32_t bits, uint32_t& m) { m = (mt & 1) ? (m | (bits << 8)) : bits; }
 EO_DEV void mask_commit(PF32, int mt, uint32_t bits, uint32_t& m) { m = (mt & 1) ? (m | (bits << 16)) : bits; }

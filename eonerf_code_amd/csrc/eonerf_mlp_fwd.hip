@@ -44,7 +44,9 @@ EO_DEV EncUnits<P> encode_position(float x, float y, float z, int h) {
 // MODE 0: inference.  1: training, everything saved.  2: training with the transient head OUTSIDE the autograd graph
 // (epoch_idx < 2: s = 1 and the loss is MSE on rgb -- train_eonerf.py:139-141, sat_rendering.py:269-272): its forward still
 // runs (ts / beta are outputs) but nothing of it is saved.
-template <class P, bool FULL, int MODE>
+// TMASK = false: the ReLU bits of trunk layers 0..6 are not needed (the pipelined trunk backward derives ReLU' from the saved
+// activations themselves, a.mask_from >= 7): their two VALU operations per epilogue slice are compiled out.
+template <class P, bool FULL, int MODE, bool TMASK = true>
 __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
     constexpr bool TRAIN = MODE != 0, TSAVE = MODE == 1;
     constexpr int SLOT = FwdSlot<P>::BYTES;
@@ -98,6 +100,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             if (s == EPI_SLICES - 1) mask_commit(P(), mt, tbits, mbits[mt >> 1]);
             if constexpr (TRAIN) sw.stage(act_row + 32 * mt, s, v);
         };
+        auto relu_epi_nomask = [&](U* dst, int act_row, int mt, const f32x16& accv, int s) {      // trunk layers 0..6 with TMASK = false
+            const Sl<P> v = relu_only_slice(P(), accv, s);
+            put_slice(P(), dst, mt, s, v);
+            if constexpr (TRAIN) sw.stage(act_row + 32 * mt, s, v);
+        };
         auto relu_epi_t = [&](U* dst, int act_row, int mt, const f32x16& accv, int s) {      // transient head layers
             const Sl<P> v = relu_slice(P(), accv, s, tbits);
             put_slice(P(), dst, mt, s, v);
@@ -113,24 +120,40 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             }
         };
         auto plain_layer = [&](U* src, U* dst, int l) {
-            run_layer<P, SLOT, HKG, 8, true, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
-                [&](int mt, const f32x16& v, int s) { relu_epi(dst, ACT_ROW_X1 + 256 * l, mt, v, s); });
-            save_mask(l, 4);
+            if (TMASK || l == 7) {
+                run_layer<P, SLOT, HKG, 8, true, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
+                    [&](int mt, const f32x16& v, int s) { relu_epi(dst, ACT_ROW_X1 + 256 * l, mt, v, s); });
+                save_mask(l, 4);
+            } else {
+                run_layer<P, SLOT, HKG, 8, true, NST>(ws, mid, lane, h, [&](int kg) { return src[kg]; },
+                    [&](int mt, const f32x16& v, int s) { relu_epi_nomask(dst, ACT_ROW_X1 + 256 * l, mt, v, s); });
+            }
         };
 
         // layer 0: enc(64) -> 256
-        run_layer<P, SLOT, EKG, 8, true, NST>(ws, mid, lane, h, [&](int kg) { return E.u[kg]; },
-            [&](int mt, const f32x16& v, int s) { relu_epi(H, ACT_ROW_X1, mt, v, s); });
-        save_mask(0, 4);
+        if constexpr (TMASK) {
+            run_layer<P, SLOT, EKG, 8, true, NST>(ws, mid, lane, h, [&](int kg) { return E.u[kg]; },
+                [&](int mt, const f32x16& v, int s) { relu_epi(H, ACT_ROW_X1, mt, v, s); });
+            save_mask(0, 4);
+        } else {
+            run_layer<P, SLOT, EKG, 8, true, NST>(ws, mid, lane, h, [&](int kg) { return E.u[kg]; },
+                [&](int mt, const f32x16& v, int s) { relu_epi_nomask(H, ACT_ROW_X1, mt, v, s); });
+        }
         plain_layer(H, N, 1);
         plain_layer(N, H, 2);
         plain_layer(H, N, 3);
         plain_layer(N, H, 4);
         // layer 5 consumes [h, enc] (skip-concat after layer 4, mlp.py:92-97)
-        run_layer<P, SLOT, HKG + EKG, 8, true, NST>(ws, mid, lane, h,
-            [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : E.u[kg >= HKG ? kg - HKG : 0]; },
-            [&](int mt, const f32x16& v, int s) { relu_epi(N, ACT_ROW_X1 + 256 * 5, mt, v, s); });
-        save_mask(5, 4);
+        if constexpr (TMASK) {
+            run_layer<P, SLOT, HKG + EKG, 8, true, NST>(ws, mid, lane, h,
+                [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : E.u[kg >= HKG ? kg - HKG : 0]; },
+                [&](int mt, const f32x16& v, int s) { relu_epi(N, ACT_ROW_X1 + 256 * 5, mt, v, s); });
+            save_mask(5, 4);
+        } else {
+            run_layer<P, SLOT, HKG + EKG, 8, true, NST>(ws, mid, lane, h,
+                [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : E.u[kg >= HKG ? kg - HKG : 0]; },
+                [&](int mt, const f32x16& v, int s) { relu_epi_nomask(N, ACT_ROW_X1 + 256 * 5, mt, v, s); });
+        }
         plain_layer(N, H, 6);
         plain_layer(H, N, 7);
         // after l=7 (odd) the trunk output X8 lives in N
@@ -205,16 +228,16 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 #endif
 }
 
-template <class P, bool FULL, int MODE>
+template <class P, bool FULL, int MODE, bool TMASK = true>
 hipError_t launch(const MlpFwdArgs& a, int grid, hipStream_t st) {
     constexpr int SMEM = 2 * FwdSlot<P>::BYTES + (MODE ? SlabWriter<P, ActMap>::LDS_BYTES : 0);
     static EoAttrOnce attr;
     {
-        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, MODE>),
+        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<P, FULL, MODE, TMASK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); });
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_mlp_fwd<P, FULL, MODE>), dim3(grid), dim3(P::NT), SMEM, st, a);
+    hipLaunchKernelGGL((k_mlp_fwd<P, FULL, MODE, TMASK>), dim3(grid), dim3(P::NT), SMEM, st, a);
     return hipGetLastError();
 }
 
@@ -227,6 +250,10 @@ template <class P> hipError_t dispatch(const MlpFwdArgs& a, bool full, int mode,
 
 // mode: 0 inference, 1 training, 2 training with the transient head outside the autograd graph (full variant only)
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st) {
+    if (bf16 && mode != 0 && a.mask_from >= 7) {      // training pass in front of the pipelined trunk backward: no trunk mask bits
+        if (!full) return launch<PBf16, false, 1, false>(a, grid, st);
+        return mode == 1 ? launch<PBf16, true, 1, false>(a, grid, st) : launch<PBf16, true, 2, false>(a, grid, st);
+    }
     return bf16 ? dispatch<PBf16>(a, full, mode, grid, st) : dispatch<PF32>(a, full, mode, grid, st);
 }
 
