@@ -451,39 +451,6 @@ __global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt,
     if (kind == 1 && blockIdx.x == 0 && threadIdx.x == 0) part += 1.5f;      // the constant 3/2 of the beta term (metrics.py:20)
     if ((threadIdx.x & 63) == 0) atomicAdd(loss, part);
 }
-// the same for batches of a few thousand rays (a training step): ONE workgroup, the scalar is stored, not accumulated -- no memset in front
-__global__ __launch_bounds__(1024) void k_loss_one(const float* out, const float* gt, int n, int kind, float* d_out, float* loss) {
-    __shared__ float wsum[16];
-    float part = 0.f;
-    const float inv = 1.f / (3.f * n);
-    for (int ray = threadIdx.x; ray < n; ray += 1024) {
-        const float* o = out + (size_t)ray * 21;
-        float* d = d_out + (size_t)ray * 21;
-#pragma unroll
-        for (int c = 0; c < 21; ++c) d[c] = 0.f;
-        if (kind == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const float df = o[c] - gt[(size_t)ray * 3 + c]; part += df * df * inv; d[c] = 2.f * df * inv; }
-        } else {
-            const float beta = o[12], ib2 = 1.f / (beta * beta);
-            float sq = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const float df = o[c] - gt[(size_t)ray * 3 + c]; sq += df * df; d[c] = df * ib2 * inv; }
-            part += 0.5f * sq * ib2 * inv + 0.5f * logf(beta) / n;
-            d[12] = -sq * ib2 / beta * inv + 0.5f / (n * beta);
-        }
-    }
-    part = wave_sum(part);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = kind == 1 ? 1.5f : 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) t += wsum[w];
-        *loss = t;
-    }
-}
-
 // ---- torch.optim.Adam (no weight decay, no amsgrad) on the flat buffers --------------------------------------
 // ONE step count for every parameter: while epoch_idx < 2 the reference's graph still reaches the transient / ambient heads through
 // torch.cat + slicing (sat_rendering.py:294,311-312,322), so they receive defined ZERO gradients, torch.optim.Adam creates their
@@ -572,10 +539,6 @@ hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st) {
-    if (n <= 8192) {
-        hipLaunchKernelGGL(k_loss_one, dim3(1), dim3(1024), 0, st, out, gt, n, kind, d_out, loss);
-        return hipGetLastError();
-    }
     hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_loss, dim3((n + 255) / 256), dim3(256), 0, st, out, gt, n, kind, d_out, loss);
