@@ -27,4 +27,8 @@ tr = FusedTrainer(f)
 for _ in range(3): tr.step(rays, img, rgbs, 0)
 rd("warm", "fwd"); rd("warm", "bwd")
 for _ in range(5): tr.step(rays, img, rgbs, 0)
-rd("fwd train", "fwd"); rd("bwd train", "bwd")
+rd("fwd train (rgb state)", "fwd"); rd("bwd heads chain (rgb state)", "bwd")
+for _ in range(3): tr.step(rays, img, rgbs, 3)
+rd("warm", "fwd"); rd("warm", "bwd")
+for _ in range(5): tr.step(rays, img, rgbs, 3)
+rd("fwd train (full state: camera + sun launches)", "fwd"); rd("bwd heads chains (full state: camera + sun)", "bwd")
