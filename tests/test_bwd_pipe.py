@@ -170,3 +170,25 @@ def test_four_times_the_bench_batch_and_the_size_guard():
                                  C.c_void_p(tr.zsteps.data_ptr()), None, None, None, big, _lib.F_TRAIN | _lib.F_RGB_LOSS,
                                  C.c_void_p(dummy.data_ptr()), None, C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), None)
     assert rc == -4, rc                                   # EONERF_E_UNSUPPORTED, before anything is launched
+
+
+@pytest.mark.parametrize("R,epoch", [(4096, 3), (4096, 0), (37, 3)])
+def test_gemm_riders_match_the_jobs_they_replace(R, epoch, monkeypatch):
+    """The sigma row and the transient head's embedding columns ride on the bottleneck-factor job of the weight-gradient GEMM
+    (WgradAux, csrc/eonerf_wgrad.hip) instead of being jobs of their own (EONERF_WGRAD_RIDERS=0): the same products on the same
+    operands, summed in another order -- every tensor to 1e-4, the two that the riders produce looked at by name."""
+    monkeypatch.setenv("EONERF_WGRAD_RIDERS", "0")
+    f_jobs = _field(True, seed=11)
+    monkeypatch.delenv("EONERF_WGRAD_RIDERS")
+    f_riders = _field(True, seed=11)
+    l0, g0, _ = _grads(f_jobs, R, epoch)
+    l1, g1, _ = _grads(f_riders, R, epoch)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    seen = set()
+    for (name, _), a, b in zip(f_jobs.named_parameters(), f_jobs.grad_views(g0), f_riders.grad_views(g1)):
+        assert (a - b).norm().item() <= 1e-4 * a.norm().item() + 1e-10, name
+        if name in ("sigma_layer.output_layer.weight", "sigma_layer.output_layer.bias", "transient_mlp.hidden_layers.0.weight"):
+            seen.add(name)
+            if epoch >= 2 or "sigma" in name:
+                assert a.norm().item() > 0, name
+    assert len(seen) == 3
