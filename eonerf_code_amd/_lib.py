@@ -38,6 +38,10 @@ class EonerfConfig(C.Structure):
 
 def build(verbose=False):
     """Compile libeonerf_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile"]
+    srcs.append(os.path.join(_HERE, "..", "include", "eonerf_hip.h"))
+    if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in srcs):
+        return LIB_PATH         # up to date (the object files do not travel to the GPU box: never rebuild a current library there)
     cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:

@@ -1,6 +1,6 @@
 // Workspace carving of the C ABI (eonerf_render_workspace_bytes / eonerf_render_forward / _backward; eonerf_field_*): plain host code,
-// no HIP runtime calls -- shared by eonerf_api.hip and the host-only sanitizer test (tests/host/host_checks.cpp, built with
-// -fsanitize=address,undefined on the CPU).  The caller (PyTorch) owns the workspace; these functions only lay it out.
+// no HIP runtime calls -- shared by eonerf_api.hip and the host-only sanitizer test (tests/host/host_checks.cpp, built for the CPU
+// under the address + undefined-behaviour sanitizers).  The caller (PyTorch) owns the workspace; these functions only lay it out.
 #pragma once
 #include <stdint.h>
 #include <string.h>

@@ -104,6 +104,9 @@ class EONerfMLP(nn.Module):
         self._ctx = None          # eonerf_ctx*
         self._ctx_eval = None     # second native context (fp32) for export renders of a bf16 field, created on first use
         self._packed_version_eval = None
+        self._native_gen = 0      # bumped by whoever changes the parameters through raw pointers (FusedTrainer's Adam kernel: no
+        #                           tensor ._version moves), so that every OTHER context over the flat buffer re-packs before its next call
+        self._noise_seed = None
         self._flat = None         # flat fp32 parameter buffer (device)
         self._layout = None
         self._packed_version = None
@@ -143,7 +146,9 @@ class EONerfMLP(nn.Module):
             ctx = C.c_void_p()
             _lib.check(L.eonerf_create(C.byref(ctx), C.byref(cfg)))
             self._ctx_eval = ctx
-        ver = (flat.data_ptr(),) + tuple(p._version for p in self.parameters())
+            if self._noise_seed is not None:
+                _lib.check(L.eonerf_set_noise_seed(ctx, self._noise_seed))
+        ver = (flat.data_ptr(), self._native_gen) + tuple(p._version for p in self.parameters())
         if ver != self._packed_version_eval:
             _lib.check(L.eonerf_set_weights(self._ctx_eval, _ptr(flat), _stream()))
             self._packed_version_eval = ver
@@ -189,7 +194,15 @@ class EONerfMLP(nn.Module):
     def set_noise_seed(self, seed):
         """Key of the sampler's in-kernel jitter stream (what torch.manual_seed is to perturb_z_vals' rand_like)."""
         self._context()
-        _lib.check(_lib.lib().eonerf_set_noise_seed(self._ctx, int(seed)))
+        self._noise_seed = int(seed)
+        _lib.check(_lib.lib().eonerf_set_noise_seed(self._ctx, self._noise_seed))
+        if self._ctx_eval is not None:      # the export context draws from the same stream as the main one
+            _lib.check(_lib.lib().eonerf_set_noise_seed(self._ctx_eval, self._noise_seed))
+
+    def weights_changed_natively(self):
+        """Tell the module that its flat parameter buffer was updated through raw pointers (a native optimizer step): contexts whose
+        packed weight streams were NOT refreshed by that update (the fp32 export context) re-pack before their next call."""
+        self._native_gen += 1
 
     def grad_views(self, d_flat):
         """Views of a flat gradient buffer in named_parameters() order (None for tensors absent from the layout)."""

@@ -157,7 +157,8 @@ class FusedTrainer:
         _lib.check(adam(self.ctx, _ptr(self.flat), _ptr(self.d_flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                         self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, gscale, flag, st))
         self._grad_clean = not self.keep_message
-        self.field._packed_version = tuple(p._version for p in self.field.parameters())   # adam_step re-packed the weights
+        self.field._packed_version = tuple(p._version for p in self.field.parameters())   # adam_step re-packed the weights of self.ctx
+        self.field.weights_changed_natively()      # ... and of no other context: the fp32 export context re-packs at its next render
 
     def _reduce(self, st):
         """The gradient all-reduce on a SIDE stream: it starts when the last gradient kernel of the backward has
@@ -182,7 +183,7 @@ class FusedTrainer:
 
     def set_noise_seed(self, seed):
         """Key of the in-kernel jitter stream; data-parallel ranks must use different seeds (train_dp.py: seed + rank)."""
-        _lib.check(self.L.eonerf_set_noise_seed(self.ctx, int(seed)))
+        self.field.set_noise_seed(seed)
 
     # ---- measurement hooks ----
     def profile_enable(self, max_launches):

@@ -1,4 +1,4 @@
-// Host-only checks of the C ABI's host logic, built for the CPU with -fsanitize=address,undefined (tests/test_host_sanitizers.py):
+// Host-only checks of the C ABI's host logic, built for the CPU under the address + undefined-behaviour sanitizers (tests/test_host_sanitizers.py):
 //   * eonerf_pack.cpp: the flat parameter layout and every packed weight stream (gather maps) for several image counts -- every
 //     destination inside its stream, every source inside the flat buffer, no byte written twice, chunk tables consistent with the
 //     grouping the chain kernels walk;

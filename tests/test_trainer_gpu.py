@@ -224,3 +224,36 @@ def test_lean_step_consumes_the_message_and_matches_the_kept_message_path(monkey
     assert torch.equal(tr2.flat.detach(), p0) and tr2.d_flat[:tr2.n_params].abs().max().item() == 0.0
     with pytest.raises(RuntimeError, match="hand-off"):
         tr2.check_device_status()
+
+
+def test_export_render_after_native_updates_uses_the_current_weights():
+    # the fp32 export context of a bf16 field is a SECOND packed copy of the weights; FusedTrainer's Adam kernel
+    # updates the flat buffer through raw pointers (no tensor ._version moves), so the export context must be told.  train -> export
+    # -> train -> export: the second export equals the export of a fresh module loaded from the state_dict.
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    from eonerf_code_amd.sat_rendering import render_image
+    from eonerf_code_amd.datasets.satellite import define_satrays_from_tensors
+    f, tr, _ = _make(precision="bf16")
+    tr.lr = 5e-3                                                           # large steps: stale weights would be far off
+    rays, img, pix, noise = _batch()
+    sr = define_satrays_from_tensors(rays, img[:, None])
+
+    def export(field):
+        field.eval()
+        with torch.no_grad():
+            res, _ = render_image(field, None, sr, None, None, epoch_idx=3, chunk=R, render_step_size=2.0 / 128, noise=[noise], eval=True)
+        field.train()
+        return torch.cat([res["rgb"], res["depth"], res["albedo_rgb"]], 1)
+
+    for _ in range(3):
+        tr.step(rays, img, pix, 3, noise=noise)
+    first = export(f)
+    assert f._ctx_eval is not None
+    for _ in range(5):
+        tr.step(rays, img, pix, 3, noise=noise)
+    second = export(f)
+    fresh = EONerfMLP(N_IMG, radiometric_normalization=True, precision="bf16")
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in f.state_dict().items()}, strict=True)
+    ref = export(fresh.cuda())
+    assert (second - ref).abs().max().item() < 1e-6, (second - ref).abs().max().item()
+    assert (first - ref).abs().max().item() > 1e-4                         # the weights did move between the two exports
