@@ -2,6 +2,7 @@
 """bench.py -- train rays/sec of the EO-NeRF hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: starts the N ranks itself, self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one complete optimisation step of the launcher's loop (eonerf_code_amd/train_dp.py) on rays that are already
@@ -122,6 +123,27 @@ def cpu_baseline(workloads, n_rays=1024, reps=3):
     return out
 
 
+def self_launch(n):
+    """Start `n` ranks of this script on one node (one process per GPU, RCCL over xGMI) and return the job's exit code.  Fails fast,
+    in the parent, when the node has fewer than `n` GPUs (torch.cuda.device_count() does not initialise HIP on this image);
+    EONERF_BENCH_REHEARSAL=1 (every rank on cuda:0, gloo) is the one-GPU rehearsal of the path, not a measurement."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if os.environ.get("EONERF_BENCH_REHEARSAL") != "1" and have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs on this node, {have} visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def split_blocks(k, n_blocks=3):
     """K timed steps as (at most) three consecutive blocks of nearly equal length."""
     n = max(1, min(n_blocks, k))
@@ -189,7 +211,14 @@ def main():
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the untimed per-kernel event pass (rocprof runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher -- BEFORE any HIP call (a process that has
+        # initialised the GPU must not be replaced or forked into ranks) -- and starts one rank per GPU through torch.distributed.run
+        # as child processes; rank 0's JSON line goes to the inherited stdout, the exit code is the job's.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -314,6 +343,28 @@ def main():
             print(f"[bench] {wl}: {recs[wl]['rays_per_s']:.0f} rays/s, {recs[wl]['ms_per_step']:.3f} ms/step "
                   f"(blocks {', '.join(f'{b:.3f}' for b in recs[wl]['blocks_ms_per_step'])})", file=sys.stderr, flush=True)
         first += args.warmup + 2 * args.steps
+    dist_info = None
+    if world > 1:
+        # what a SCALE record needs to prove the collective saw N ranks: the group's own size and backend, every rank's device, and the
+        # stand-alone latency of the ONE exchange of a step (the 2.7-MB gradient message, sum all-reduce) -- median of 50
+        dist = torch.distributed
+        ids = [None] * world
+        dist.all_gather_object(ids, {"rank": rank, "device": str(dev), "pid": os.getpid(),
+                                     "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))})
+        msg = torch.zeros_like(trainer.d_flat)
+        lat = []
+        for i in range(60):
+            barrier()
+            t0 = time.perf_counter()
+            dist.all_reduce(msg, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            if i >= 10:
+                lat.append((time.perf_counter() - t0) * 1e6)
+        t = torch.tensor([statistics.median(lat)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist_info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "devices": ids,
+                     "allreduce_us": t.item(), "allreduce_bytes": msg.numel() * 4,
+                     "rehearsal_one_gpu_gloo": rehearsal}
     if rank == 0:
         head = recs[workloads[0]]
         names = {"rgb": "JAX_068-like synthetic rays, sigma+albedo path (shadow pass off, epoch<2, MSE), 4096 rays x 128 samples per GPU",
@@ -343,6 +394,8 @@ def main():
         }
         for wl in workloads[1:]:
             result[wl] = nested(wl)
+        if world > 1:
+            result["dist"] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(workloads)
         print(json.dumps(result))

@@ -5,6 +5,8 @@ flat gradient over RCCL."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.multiprocessing as mp
 
@@ -117,3 +119,21 @@ def test_eight_ranks_share_one_permutation_and_average_their_gradients(tmp_path)
     assert seen.numel() == 32 and seen.unique().numel() == 32
     assert all(torch.equal(r[1], res[0][1]) for r in res)
     assert float(res[0][1][0]) == 4.5                   # mean of 1..8
+
+
+def test_bench_gpus_n_fails_fast_in_the_parent_without_the_gpus():
+    """`python bench.py --gpus 2` on a node with fewer than 2 GPUs: the self-launching parent refuses before it starts any rank
+    (and before any HIP call); a launcher/flag mismatch is an error too."""
+    import subprocess
+    import sys
+    import torch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("node has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EONERF_BENCH_REHEARSAL")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=repo, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "needs 2 GPUs" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "1", "--warmup", "0"], cwd=repo, env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr

@@ -181,6 +181,23 @@ def test_bench_n_gt_1_path_rehearsal_two_ranks_on_one_card():
     assert "cpu_baseline" not in line                                  # rank 0 at N = 1 only
 
 
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher in the command (the form the driver's N = 1 record shows): the parent starts the two
+    ranks itself (bench.self_launch) and relays rank 0's line, which carries the proof that the collective saw two ranks."""
+    import json
+    env = dict(os.environ, EONERF_BENCH_REHEARSAL="1", EONERF_PIPE="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-pass",
+                        "--workload", "rgb"], cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2"
+    d = line["dist"]
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["rehearsal_one_gpu_gloo"] is True
+    assert sorted(x["rank"] for x in d["devices"]) == [0, 1] and len({x["pid"] for x in d["devices"]}) == 2
+    assert d["allreduce_us"] > 0 and d["allreduce_bytes"] > 2_700_000
+
+
 def test_launcher_two_ranks_keeps_replicas_identical(tmp_path):
     """train_dp.py under torch.distributed.run with two ranks (one card, gloo rehearsal): broadcast at start, per-rank slices of one
     shared permutation, per-rank jitter seeds, one all-reduce per step -- the replicas end bit-identical."""
