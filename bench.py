@@ -160,7 +160,7 @@ def kernel_model(wl, piped, n_cam, n_sun, elt):
     enc_dw = 2 * 63 * 256                               # layer 0 and the skip columns of layer 5 against the 63 encoding columns
     flop, byts = {}, {}
     flop["fwd_chain_camera"] = 2.0 * MAC_FWD * n_cam
-    rows_w = 2496 if wl == "rgb" else 3012              # enc 64 + X1..X8 2048 + bottleneck 256 + A1 128 (+ T 512 + emb 4)
+    rows_w = 2240 if wl == "rgb" else 2756              # enc 64 + X1..X8 2048 + A1 128 (+ T 512 + emb 4); the bottleneck output has no rows
     masks = 9 if wl == "rgb" else 13
     byts["fwd_chain_camera"] = (rows_w * elt + masks * 32) * n_cam
     if wl == "full":

@@ -35,12 +35,8 @@ struct eonerf_ctx {
     DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig, pipe_wt, bwd_full_heads, bwd_rgb_heads, bwd_dens_heads, ig_tail_wt;
     bool pipe = false;               // layer-pipelined trunk backward (bf16 camera pass; EONERF_PIPE=0 switches back to chain + GEMM)
     int n_pipes = 0;
-    bool heads_pipe = false;         // EONERF_HEADS_PIPE=1: the camera pass's two wide head layers as a second pipelined launch.  OFF by default:
-                                     // measured on the same box (round 3) it moves 0.26 ms out of the heads chain, the GEMM and the
-                                     // bottleneck factor product and spends 0.30 ms in the launch (120 steps per pipeline: fill, drain and the
-                                     // stationary-dW flush are a third of it) -- the step gets no faster
-    int n_pipes_heads = 0;
-    DevStream bwd_full_heads2, bwd_rgb_heads2, heads_pipe_wt;
+    float* fold = nullptr;           // [FOLD_FLOATS] fp32: the heads' first layers folded with the bottleneck layer (eonerf_pack.h), re-computed
+                                     // by k_fold in front of every re-pack
     int pipe_fault_stage = -1;       // test hook (EONERF_PIPE_FAULT)
     bool deterministic = false;      // EONERF_DETERMINISTIC=1: every atomic flush of the backward is replaced by partials + a fixed-order sum
     bool pipe_partials = false;      // the pipelined launches flush their stationary dW through partial buffers + a reduction kernel (always
@@ -64,8 +60,8 @@ namespace {
 
 CarveCfg carve_cfg(const eonerf_ctx* ctx) {
     CarveCfg c;
-    c.bf16 = ctx->bf16; c.pipe = ctx->pipe; c.heads_pipe = ctx->heads_pipe; c.deterministic = ctx->deterministic; c.pipe_partials = ctx->pipe_partials;
-    c.n_pipes = ctx->n_pipes; c.n_pipes_heads = ctx->n_pipes_heads;
+    c.bf16 = ctx->bf16; c.pipe = ctx->pipe; c.deterministic = ctx->deterministic; c.pipe_partials = ctx->pipe_partials;
+    c.n_pipes = ctx->n_pipes;
     return c;
 }
 
@@ -98,24 +94,66 @@ void release(DevStream& d) {
 constexpr int PACK_MAX_JOBS = 16;
 struct PackJob { const PackEntry* e; int n; uint8_t* data; int is16; };
 struct PackJobs { PackJob j[PACK_MAX_JOBS]; };
-__global__ void k_pack(const float* flat, PackJobs jobs) {
+// sources >= fold_base come from the fold buffer (ParamLayout::fold_w / fold_b)
+__global__ void k_pack(const float* flat, const float* fold, int fold_base, PackJobs jobs) {
     const PackJob jb = jobs.j[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
         const PackEntry pe = jb.e[i];
-        const float v = pe.src < 0 ? 0.f : flat[pe.src];
+        const float v = pe.src < 0 ? 0.f : (pe.src >= fold_base ? fold[pe.src - fold_base] : flat[pe.src]);
         if (jb.is16) *reinterpret_cast<__bf16*>(jb.data + pe.dst) = (__bf16)v;
         else *reinterpret_cast<float*>(jb.data + pe.dst) = v;
     }
 }
-int pack(const std::vector<const DevStream*>& streams, const float* flat, hipStream_t st) {
+// (a stream set that needs more than PACK_MAX_JOBS jobs goes out in several launches: today's largest set is 9 streams, 13 jobs)
+int pack(const eonerf_ctx* ctx, const std::vector<const DevStream*>& streams, const float* flat, hipStream_t st) {
     PackJobs jobs;
     int n = 0, most = 1;
+    auto flush = [&]() {
+        if (n) hipLaunchKernelGGL(k_pack, dim3(std::min((most + 255) / 256, 1024), n), dim3(256), 0, st, flat, ctx->fold, (int)ctx->pl.total, jobs);
+        n = 0; most = 1;
+    };
     for (const DevStream* d : streams) {
+        if (n + 2 > PACK_MAX_JOBS) flush();
         if (d->n16) jobs.j[n++] = PackJob{d->e16, d->n16, d->data, 1};
         if (d->n32) jobs.j[n++] = PackJob{d->e32, d->n32, d->data, 0};
         most = std::max(most, std::max(d->n16, d->n32));
     }
-    hipLaunchKernelGGL(k_pack, dim3(std::min((most + 255) / 256, 1024), n), dim3(256), 0, st, flat, jobs);
+    flush();
+    return (int)hipGetLastError();
+}
+
+// The heads' first layers folded with the bottleneck layer (eonerf_pack.h): fold[o][i] = sum_k W_AT[o][k] W_b[k][i], b_f[o] = sum_k
+// W_AT[o][k] b_b[k] + b_AT[o], with W_AT = [W_A1; W_T1[:, :256]].  fp32 FMAs in k order (deterministic).  Block = 4 output rows,
+// thread = column i (thread 0..255) -- 16.8 M MACs on 64 workgroups, a few microseconds in front of every re-pack.
+struct FoldArgs { const float *w_a1, *b_a1, *w_t1, *b_t1, *w_b, *b_b; float* fold; };
+__global__ __launch_bounds__(256) void k_fold(FoldArgs a) {
+    __shared__ float wat[4][256];
+    const int o0 = blockIdx.x * 4, i = threadIdx.x;
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + r;
+        wat[r][i] = o < 128 ? a.w_a1[(size_t)o * 256 + i] : a.w_t1[(size_t)(o - 128) * 260 + i];
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 256; ++k) {
+        const float wb = a.w_b[(size_t)k * 256 + i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaf(wat[r][k], wb, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a.fold[(size_t)(o0 + r) * 256 + i] = acc[r];
+    if (i < 4) {
+        const int o = o0 + i;
+        float b = 0.f;
+        for (int k = 0; k < 256; ++k) b = fmaf(wat[i][k], a.b_b[k], b);
+        a.fold[256 * 256 + o] = b + (o < 128 ? a.b_a1[o] : a.b_t1[o - 128]);
+    }
+}
+int fold_heads(const eonerf_ctx* ctx, const float* flat, hipStream_t st) {
+    const ParamLayout& pl = ctx->pl;
+    FoldArgs a{flat + pl.t[pl.a1_w].offset, flat + pl.t[pl.a1_b].offset, flat + pl.t[pl.t_w[0]].offset, flat + pl.t[pl.t_b[0]].offset,
+               flat + pl.t[pl.bot_w].offset, flat + pl.t[pl.bot_b].offset, ctx->fold};
+    hipLaunchKernelGGL(k_fold, dim3(64), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -140,8 +178,8 @@ AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
 int ensure_density_streams(eonerf_ctx* ctx, const float* flat, hipStream_t st) {
     ctx->dens_used = true;
     if (!ctx->dens_dirty) return 0;
-    const int rc = ctx->pipe ? pack({&ctx->fwd_dens, &ctx->bwd_dens, &ctx->bwd_dens_heads, &ctx->ig_tail_wt}, flat, st)
-                             : pack({&ctx->fwd_dens, &ctx->bwd_dens}, flat, st);
+    const int rc = ctx->pipe ? pack(ctx, {&ctx->fwd_dens, &ctx->bwd_dens, &ctx->bwd_dens_heads, &ctx->ig_tail_wt}, flat, st)
+                             : pack(ctx, {&ctx->fwd_dens, &ctx->bwd_dens}, flat, st);
     if (!rc) ctx->dens_dirty = false;
     return rc;
 }
@@ -157,9 +195,8 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     a.sigma = b.sigma; a.albedo = b.albedo; a.ts = b.ts; a.tb = b.tb;
     a.act = b.act; a.masks = b.masks;
     // training passes of the render path with the pipelined backward: the trunk's ReLU' comes from the X images, only the heads chain
-    // reads mask bits (slot 7 = X_8 for its last layer; from slot 8 on with the heads pipeline)
-    a.mask_from = (render_train && ctx->pipe) ? ((full && ctx->heads_pipe) ? 8 : 7) : 0;
-    a.save_bott = (render_train && full && ctx->heads_pipe) ? 1 : 0;
+    // reads mask bits (slot 7 = X_8 for its last layer)
+    a.mask_from = (render_train && ctx->pipe) ? 7 : 0;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
     if (prof_id < 0) return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, mode, grid, st);
@@ -211,34 +248,12 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
     return 0;
 }
 
-// the two wide head layers of the camera pass: [dY_A1; dY_T1] (w.pipe.dy_heads, from the heads chain) -> d bottleneck -> dY_7
-// (w.pipe.dy_in), with the weight gradients of both heads' first layers (bottleneck columns) and of the bottleneck layer
-int run_heads_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, bool transient, hipStream_t st, int slot, bool first_of_backward) {
-    const ParamLayout& pl = ctx->pl;
-    { const int rc = pipe_clear(w, first_of_backward, slot, st); if (rc) return rc; }
-    ProfScope ps(ctx, EONERF_PROF_HEADS_PIPE_CAMERA, st);
-    BwdPipeArgs pa;
-    pipe_common(ctx, w, b, p_cap, d_flat, slot, ctx->n_pipes_heads, HEADS_STAGES, pa);
-    pa.wt = ctx->heads_pipe_wt.data; pa.wsig = ctx->heads_pipe_wt.data + HEADS_WSIG_OFF;
-    pa.dy_in = w.pipe.dy_heads; pa.dy_out = w.pipe.dy_in; pa.dsig = b.dsig;
-    // stage 0: rows 0..127 = albedo head's first layer, rows 128..255 = transient head's first layer (bottleneck columns, ld 260)
-    pa.dw_off[0] = pl.t[pl.a1_w].offset; pa.db_off[0] = pl.t[pl.a1_b].offset; pa.dw_ld[0] = 256;
-    pa.dw_off2[0] = pl.t[pl.t_w[0]].offset; pa.db_off2[0] = pl.t[pl.t_b[0]].offset; pa.dw_ld2[0] = 260;
-    pa.split[0] = 1; pa.skip_hi[0] = transient ? 0 : 1;
-    pa.dw_off[1] = pl.t[pl.bot_w].offset; pa.db_off[1] = pl.t[pl.bot_b].offset; pa.dw_ld[1] = 256;
-    HIP_TRY(eo_launch_heads_pipe(pa, st));
-    if (pa.partials) HIP_TRY(eo_launch_pipe_reduce(pa, st));
-    return 0;
-}
-
 // Weight gradients of up to two MLP passes in ONE split-K launch (eonerf_wgrad.hip) + the bottleneck factor product:
 //   full: a pass through the whole field (camera pass / EONerfMLP.forward), with or without the transient head in the graph;
 //   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
                          const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false,
-                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false, const uint8_t* heads_units = nullptr) {
-    // heads_units != nullptr: the two wide head layers ran in the heads pipeline (run_heads_pipe): their weight gradients are done, the
-    // bottleneck factor product is not needed, and [dY_A1; dY_T1] lies in unit-order tiles there (the embedding-column job reads it)
+                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false) {
     const ParamLayout& pl = ctx->pl;
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
@@ -246,8 +261,8 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     memset(&tab.aux, 0, sizeof(tab.aux));
     tab.aux.job = -1;
     // riders of the bottleneck-factor job (WgradAux): the sigma row and the embedding columns of the camera pass travel with the job that
-    // streams X_8 / dY_T1 anyway.  Not in deterministic mode (its partial-sum tiles have no room for them) nor with the heads pipeline
-    const bool riders = full && !heads_units && !det_partials && ctx->wgrad_riders;
+    // streams X_8 / dY_T1 anyway.  Not in deterministic mode (its partial-sum tiles have no room for them)
+    const bool riders = full && !det_partials && ctx->wgrad_riders;
     const size_t n_tiles = (size_t)p_cap / (ctx->bf16 ? 32 : 16);      // sample tiles of the slabs (block-major layout, eonerf_common.h)
     auto seg0 = [&](const void* slab, SlabBlk blk, int row) {           // (row, sample tile 0)
         return reinterpret_cast<const uint8_t*>(slab) + ((size_t)blk.s * n_tiles + (row - blk.s)) * SEG_B;
@@ -284,7 +299,6 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     if (full) {
         const PassBuffers& c = *full;
         trunk_jobs(c, full_trunk_done, !riders);
-        if (!heads_units) {
         // bottleneck factors M_a = dA1^T X8 (and M_t = dT1^T X8) + the bias gradients db_A1 (db_T1), finished by eo_launch_bott_wgrad
         // below into THREE weight gradients: the bottleneck layer's and the two head layers' that read the bottleneck output (which is
         // therefore never saved by the forward, nor read back here: see BottWgradArgs)
@@ -306,18 +320,9 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
                 x.dw_emb = dptr(pl.t_w[0]) + 256; x.emb_ld = 260; x.emb_row0 = 128;
             }
         }
-        }
         add(c, GRD_ROW_A2, 3, ACT_ROW_A1, 128, dptr(pl.a2_w), 128, dptr(pl.a2_b), nullptr, 1, 4, 1, 1);
-        if (transient && heads_units) {
-            // embedding columns of the transient head's first layer: rows 128..255 of the unit-order [dY_A1; dY_T1] tile against the 4
-            // embedding rows; rows < 128 (dY_A1) have no destination
-            add(c, GRD_ROW_A1, 256, ACT_ROW_EMB, 4, nullptr, 260, nullptr, nullptr, 4, 2, 2, 1);
-            WgradJob& j = tab.j[tab.n - 1];
-            j.a = heads_units; j.a_stride = PIPE_UNIT_B; j.a_units = 1;
-            split_at(128, dptr(pl.t_w[0]) + 256, 260, nullptr);
-        }
         if (transient) {
-            if (!heads_units && !riders) add(c, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
+            if (!riders) add(c, GRD_ROW_T1, 128, ACT_ROW_EMB, 4, dptr(pl.t_w[0]) + 256, 260, nullptr, nullptr, 4, 1, 1, 1);
             for (int l = 1; l < 4; ++l)
                 add(c, GRD_ROW_T1 + 128 * l, 128, ACT_ROW_T1 + 128 * (l - 1), 128, dptr(pl.t_w[l]), 128, dptr(pl.t_b[l]), nullptr, 2, 4, 2, 1);
             add(c, GRD_ROW_T5, 2, ACT_ROW_T1 + 384, 128, dptr(pl.tsc_w), 128, dptr(pl.tsc_b), nullptr, 1, 4, 1, 1);     // row 0: d ts_pre, row 1: d tb_pre
@@ -352,7 +357,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     }
     for (int k = 0; k < tab.n; ++k) { tab.j[k].item0 = tab.items; tab.items += tab.j[k].slices; }
     { ProfScope ps(ctx, EONERF_PROF_WGRAD, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed)); }
-    if (full && !heads_units) {   // the three weight gradients that follow from the bottleneck factors the GEMM above accumulated
+    if (full) {   // the three weight gradients that follow from the bottleneck factors the GEMM above accumulated
         BottWgradArgs bw;
         bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_at = m_bott + 2 * 128 * 256;
         bw.w_t1 = transient ? flat + pl.t[pl.t_w[0]].offset : nullptr; bw.m_t = m_bott + 128 * 256;
@@ -415,18 +420,11 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
         if (!rc && ctx->pipe) rc = upload(ctx->bwd_rgb_heads, build_bwd_stream(ctx->pl, true, true, false, false, 1));
         if (!rc && ctx->pipe) rc = upload(ctx->bwd_dens_heads, build_bwd_stream(ctx->pl, true, false, true, false, 1));
         if (!rc && ctx->pipe) rc = upload(ctx->ig_tail_wt, build_ig_tail_stream(ctx->pl));
-        {
-            const char* hp = getenv("EONERF_HEADS_PIPE");
-            ctx->n_pipes_heads = ctx->n_cu / HEADS_STAGES;
-            ctx->heads_pipe = ctx->pipe && ctx->n_pipes_heads >= 1 && hp && atoi(hp) != 0;
-            if (!rc && ctx->heads_pipe) rc = upload(ctx->bwd_full_heads2, build_bwd_stream(ctx->pl, true, true, false, true, 2));
-            if (!rc && ctx->heads_pipe) rc = upload(ctx->bwd_rgb_heads2, build_bwd_stream(ctx->pl, true, true, false, false, 2));
-            if (!rc && ctx->heads_pipe) rc = upload(ctx->heads_pipe_wt, build_heads_pipe_stream(ctx->pl));
-        }
         { const char* f = getenv("EONERF_PIPE_FAULT"); ctx->pipe_fault_stage = f ? atoi(f) : -1; }
         { const char* f = getenv("EONERF_PIPE_STAMPS");
           if (!rc && ctx->pipe && f && atoi(f)) rc = (int)hipMalloc(&ctx->pipe_stamps, (size_t)ctx->n_pipes * PIPE_STAGES * 128 * sizeof(unsigned long long)); }
     }
+    if (!rc) rc = (int)hipMalloc(&ctx->fold, FOLD_FLOATS * sizeof(float));
     if (!rc) rc = (int)hipMalloc(&ctx->dev_status, 64 * sizeof(int));
     if (!rc) rc = (int)hipMemset(ctx->dev_status, 0, 64 * sizeof(int));
     if (!rc) {
@@ -456,7 +454,7 @@ int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches) {
 
 const char* eonerf_profile_name(int kernel) {
     static const char* const names[EONERF_PROF_KERNELS] = {"fwd_chain_camera", "bwd_chain_camera", "wgrad_gemm", "fwd_chain_sun", "bwd_chain_sun",
-                                                           "bwd_pipe_camera", "bwd_pipe_sun", "ig_tail_sun", "heads_pipe_camera"};
+                                                           "bwd_pipe_camera", "bwd_pipe_sun", "ig_tail_sun"};
     return kernel >= 0 && kernel < EONERF_PROF_KERNELS ? names[kernel] : nullptr;
 }
 
@@ -476,7 +474,8 @@ int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launc
 int eonerf_destroy(eonerf_ctx* ctx) {
     if (!ctx) return EONERF_E_ARG;
     for (int k = 0; k < EONERF_PROF_KERNELS; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
-    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads); release(ctx->bwd_dens_heads); release(ctx->ig_tail_wt); release(ctx->bwd_full_heads2); release(ctx->bwd_rgb_heads2); release(ctx->heads_pipe_wt);
+    release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads); release(ctx->bwd_dens_heads); release(ctx->ig_tail_wt);
+    if (ctx->fold) (void)hipFree(ctx->fold);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     if (ctx->pipe_stamps) (void)hipFree(ctx->pipe_stamps);
     if (ctx->dev_status) (void)hipFree(ctx->dev_status);
@@ -503,8 +502,7 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     // ride along when something has read them since the last re-pack (shadow pass on: they would be re-packed a few kernels later anyway)
     std::vector<const DevStream*> v;
     v.push_back(&ctx->fwd_full);
-    if (ctx->heads_pipe) { v.push_back(&ctx->bwd_full_heads2); v.push_back(&ctx->bwd_rgb_heads2); v.push_back(&ctx->heads_pipe_wt); }
-    else if (ctx->pipe) { v.push_back(&ctx->bwd_full_heads); v.push_back(&ctx->bwd_rgb_heads); }
+    if (ctx->pipe) { v.push_back(&ctx->bwd_full_heads); v.push_back(&ctx->bwd_rgb_heads); }
     else { v.push_back(&ctx->bwd_full); v.push_back(&ctx->bwd_rgb); }
     if (ctx->pipe) v.push_back(&ctx->pipe_wt);
     const bool with_dens = ctx->dens_used;
@@ -512,7 +510,8 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
         v.push_back(&ctx->fwd_dens); v.push_back(&ctx->bwd_dens);
         if (ctx->pipe) { v.push_back(&ctx->bwd_dens_heads); v.push_back(&ctx->ig_tail_wt); }
     }
-    const int rc = pack(v, flat, st);
+    int rc = fold_heads(ctx, flat, st);      // the folded head weights are a gather source of the streams below
+    if (!rc) rc = pack(ctx, v, flat, st);
     if (!rc) { ctx->weights_set = true; ctx->dens_dirty = !with_dens; ctx->full_ig_dirty = true; ctx->dens_used = false; }
     return rc;
 }
@@ -631,7 +630,7 @@ int eonerf_field_backward(eonerf_ctx* ctx, const float* flat, const float* sun, 
     PassBuffers& b = w.b;
     HIP_TRY(eo_launch_field_grads_to_soa(g_sigma, g_albedo, g_ts, g_tb, n, p_cap, b.g_sigma, b.g_albedo, b.g_ts, b.g_tb, st));
     if (full && ctx->full_ig_dirty) {
-        const int rc = pack({&ctx->bwd_full_ig}, flat, st);
+        const int rc = pack(ctx, {&ctx->bwd_full_ig}, flat, st);
         if (rc) return rc;
         ctx->full_ig_dirty = false;
     }
@@ -891,22 +890,17 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     mc.n_pts = w.cam.n_pts; mc.p_pad = p_cap;
     const bool transient = shadows || !(flags & EONERF_F_RGB_LOSS);
     const bool pipe = ctx->pipe && w.pipe.dy_in;
-    const bool hpipe = pipe && ctx->heads_pipe && w.pipe.dy_heads;
-    const DevStream& bs = hpipe ? (transient ? ctx->bwd_full_heads2 : ctx->bwd_rgb_heads2)
-                        : pipe ? (transient ? ctx->bwd_full_heads : ctx->bwd_rgb_heads) : (transient ? ctx->bwd_full : ctx->bwd_rgb);
+    const DevStream& bs = pipe ? (transient ? ctx->bwd_full_heads : ctx->bwd_rgb_heads) : (transient ? ctx->bwd_full : ctx->bwd_rgb);
     mc.stream = bs.data; mc.chunks = bs.chunks; mc.n_chunks = bs.n_chunks;
     mc.sigma = w.cam.sigma; mc.albedo = w.cam.albedo; mc.ts = w.cam.ts; mc.tb = w.cam.tb;
     mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
     mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
-    mc.dy7_units = hpipe ? w.pipe.dy_heads : (pipe ? w.pipe.dy_in : nullptr);
-    mc.dsig_out = hpipe ? w.cam.dsig : nullptr;
-    { ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_CAMERA, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st, hpipe ? 2 : (pipe ? 1 : 0))); }
-    if (hpipe) { const int rch = run_heads_pipe(ctx, w, w.cam, p_cap, d_flat, transient, st, 1, !shadows); if (rch) return rch; }
-    if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 2, !shadows && !hpipe); if (rcp) return rcp; }
+    mc.dy7_units = pipe ? w.pipe.dy_in : nullptr;
+    { ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_CAMERA, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st, pipe ? 1 : 0)); }
+    if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, !shadows); if (rcp) return rcp; }
 
     {
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.queue, st, pipe, pipe && shadows, w.det.wgrad_part, pipe,
-                                             hpipe ? w.pipe.dy_heads : nullptr);
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.queue, st, pipe, pipe && shadows, w.det.wgrad_part, pipe);
         if (rcw) return rcw;
     }
 

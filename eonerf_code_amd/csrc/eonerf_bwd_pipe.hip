@@ -25,14 +25,6 @@
 // (s_memrealtime): on expiry the stage raises *error, tells its workgroup through LDS and leaves -- the launch always drains.
 // Residency: grid = 7 x pipelines <= CU count, one workgroup per CU (LDS), roles taken from an arrival counter, so every pipeline
 // that processes samples is complete as soon as its last workgroup is scheduled.
-//
-// Round 3: the SAME stage body also runs the two wide layers between the heads and the trunk of the camera pass as a second launch shape
-// (k_heads_pipe, 2 stages x CUs / 2 pipelines, see eonerf_kernels.h): stage "AT1" takes [dY_A1; dY_T1] from the heads chain, multiplies
-// with [W_A1; W_T1]^T (no ReLU' -- the bottleneck has an identity activation) and accumulates both heads' first-layer weight gradients
-// against the bottleneck output; stage "bott" adds the sigma row's rank-1 term as a 17th k-group, applies ReLU'(X_8), accumulates the
-// bottleneck layer's weight gradient and writes dY_7 in unit order where the trunk launch reads it.  This removes the two largest
-// layers from the heads chain, the two largest jobs ([dA1; dT1] against X_8 and against the bottleneck output: 64 KB of operand reads per
-// 32 samples) from the weight-gradient GEMM, and the bottleneck factor product.
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
 
@@ -73,9 +65,6 @@ static_assert(DEPTH >= 2 && DEPTH <= NSLOT - 1, "prefetch distance");
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
 constexpr int CTRL_B = 64;
 constexpr int SMEM_B = NSLOT * SLOT_B + CTRL_B;
-constexpr int WSIG_B = 8 * 1024;                  // heads launch: the sigma row's A units (one 1-KiB unit per wave) behind the control words,
-constexpr int DSIG_B = 256;                       // then per ring slot one LDS-DMA piece of d sigma_pre (32 samples x fp32 used)
-constexpr int SMEM_HEADS_B = SMEM_B + WSIG_B + NSLOT * DSIG_B;
 constexpr int AUX_SC1 = 16, AUX_NT = 2;
 constexpr unsigned long long WATCHDOG_TICKS = 30000000ull;     // 0.3 s of the 100 MHz s_memrealtime clock
 
@@ -85,10 +74,9 @@ EO_DEV int wg_swz16(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16
 
 // ops a wave issues per step, in program order: [CTRL: 2 flag stores, 2 flag polls] .. 2 payload stores .. N_DMA pieces
 // second order (waves 4..7): N_DMA pieces .. 2 payload stores
-// XD: extra LDS-DMA pieces this wave issues per step with the others (the "bott" stage's d sigma_pre line, wave 1)
 constexpr int NST = 2;
-template <bool CTRL, bool ORDB, int XD = 0> struct Cnt {
-    static constexpr int ND = N_DMA + XD;
+template <bool CTRL, bool ORDB> struct Cnt {
+    static constexpr int ND = N_DMA;
     static constexpr int C = (CTRL ? 4 : 0) + NST + ND;
     // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s.
     // First order: the pieces of step s-2 and all of step s-1 are younger than those stores; second order: only step s-1
@@ -105,21 +93,16 @@ struct Stage {
     bool has_in;               // false: stage 0, its input comes from an earlier launch (a.dy_in)
     int x_row;                 // first row of the 256-row block of the activation slab this stage reads as its X image
     const uint8_t* in_lin;     // != nullptr: the input tiles lie in a linear buffer [global step][16 KiB] written inside this launch (layer 5: dY_5 in the gradient slab)
-    uint8_t* out_lin;          // MODE 1 / 2 / 3: the linear output buffer [global step][16 KiB]
+    uint8_t* out_lin;          // MODE 1 / 2: the linear output buffer [global step][16 KiB]
 };
 
 // MODE 0: the output goes to the next stage's ring; 1 (layer 6): the output goes, write-through like a ring slot, to its tile of the
 // dY_5 block of the gradient slab, which the layer-5 stage reads as its "ring" and the skip-column GEMM job reads later; 2 (layer 1): the
-// output dY_0 goes to its tile of the dY_0 block (streaming stores, nobody in this launch reads it); 3 (heads launch, "bott" stage): as 2
-// into a.dy_out, plus the sigma row's rank-1 term w_sigma x d sigma_pre as a 17th k-group of the dX product.
-// MASK = false (heads launch, "AT1" stage): the stage's output feeds an identity activation -- no ReLU' on dX.
-// XD = 1: this wave also copies the step's d sigma_pre line (MODE 3).
-template <bool CTRL, int MODE, bool ORDB = false, bool MASK = true, int XD = 0>
+// output dY_0 goes to its tile of the dY_0 block (streaming stores, nobody in this launch reads it).
+template <bool CTRL, int MODE, bool ORDB = false>
 EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int tid) {
     constexpr bool HAS_OUT = MODE == 0 || MODE == 1;   // a consumer inside this launch (flags)
     constexpr bool RING_OUT = MODE == 0;       // ... whose ring slots come back through the tail counter
-    constexpr bool SIGMA = MODE == 3;
-    static_assert(XD == 0 || SIGMA, "only the sigma stage has an extra piece");
     typedef PBf16 P;
     typedef P::U U;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
@@ -163,20 +146,9 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     gu32* const my_scratch = (gu32*)(a.scratch_word + (size_t)(S.pipe * a.n_stages + S.st) * 32);
 
     // linear unit-order buffers (one 16-KiB tile per 32 samples): this stage's output (MODE 1, 2: its tile of a 256-row block of the
-    // gradient slab, same footprint as the feature-major tile the chain + GEMM path keeps there; MODE 3: a.dy_out), its input (layer 5)
+    // gradient slab, same footprint as the feature-major tile the chain + GEMM path keeps there), its input (layer 5)
     uint8_t* const grd_blk = S.out_lin;
     const uint8_t* const in_blk = S.in_lin;
-
-    // sigma row (MODE 3): the A unit of the 17th k-group for this wave's m-tile lives in LDS (copied once; read into a free slot of the
-    // operand window late in every dX phase: kept in registers it pushed the stage over the 256-register budget), and d sigma_pre of the
-    // step's 32 samples arrives as a fifth LDS-DMA piece of ONE wave (XD), next to the ring slot it belongs to.
-    uint8_t* const wsig_lds = smem + SMEM_B + wave * 1024 + lane * 16;
-    uint8_t* const dsig_lds = smem + SMEM_B + WSIG_B;
-    if constexpr (SIGMA) {
-        const U wu = *reinterpret_cast<const U*>(a.wsig + ((size_t)wave * 64 + lane) * 16);
-        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), see wt above
-        *reinterpret_cast<U*>(wsig_lds) = wu;     // wave-private: the wave's own lgkmcnt orders this write and its reads
-    }
 
     // per-lane DMA source offsets of the X image: wave w stages rows 32w..32w+31, 16 rows per piece, chunks XOR-swizzled
     int x_voff[2];
@@ -185,7 +157,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         const int row = 32 * wave + 16 * j + (lane >> 2);
         x_voff[j] = row * SEG_B + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
     }
-    // DMA of this pipeline's k-th step (clamped by the caller) into LDS slot k & 3: N_DMA (+ XD) pieces of 1 KiB per wave, issued in a
+    // DMA of this pipeline's k-th step (clamped by the caller) into LDS slot k & 3: N_DMA pieces of 1 KiB per wave, issued in a
     // block of their own between the phases.  In-kernel stamps (round 3) put that block at 320 cycles per step on waves 0..3 and 530 on
     // waves 4..7 -- the critical path of a step -- so the pieces were also issued ONE AT A TIME between the MFMAs of the dW phase
     // (build switch EO_PIPE_SPREAD=1, same vmcnt order, parity green): 1 % SLOWER on the same box (3.82 vs 3.79 ms full, 2.104 vs 2.090
@@ -203,16 +175,13 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     // output: the next stage's ring (MODE 0) or this pipeline's tiles of a linear buffer
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(MODE == 0 ? ring_out : grd_blk + (size_t)S.pipe * IMG_B, 0, -1, 0x00020000);
     const int v_dy = lane * 16 + (2 * wave) * 1024;               // this wave's two pieces of a 16-KiB unit-order image (loads and stores)
-    struct Dma { uint32_t so_d, so_x; __amdgpu_buffer_rsrc_t rs_s; uint8_t* slot; uint8_t* dsg; bool on; };
+    struct Dma { uint32_t so_d, so_x; uint8_t* slot; bool on; };
     auto dma_prep = [&](int k) {
         Dma d;
         d.on = !((EO_PABL & 8) && k >= DEPTH);
         d.slot = smem + (k & (NSLOT - 1)) * SLOT_B;
-        d.dsg = dsig_lds + (k & (NSLOT - 1)) * DSIG_B;
         d.so_d = ((uint32_t)k & d_mask) * d_mul;
         d.so_x = (uint32_t)k * lin_stride;
-        // d sigma_pre of the step's samples (XD): 128 B (lanes 32..63 fall outside the descriptor and bring zeros)
-        if constexpr (XD) d.rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dsig) + (size_t)(S.pipe + k * a.n_pipes) * TS, 0, TS * 4, 0x00020000);
         return d;
     };
     auto dma_piece = [&](const Dma& d, int i) {      // i: compile-time constant at every call site
@@ -225,17 +194,15 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
                                                          v_dy + i * 1024, d.so_d, 0, AUX_NT);
-        } else if (i < 4) {
+        } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(d.slot + IMG_B + (32 * wave + 16 * (i - 2)) * SEG_B), 16,
                                                      x_voff[i - 2], d.so_x, 0, AUX_NT);
-        } else if constexpr (XD) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rs_s, (__attribute__((address_space(3))) void*)d.dsg, 4, lane * 4, 0, 0, AUX_NT);
         }
     };
     auto issue = [&](int k) {      // all pieces in one block (prologue)
         const Dma d = dma_prep(k);
 #pragma unroll
-        for (int i = 0; i < N_DMA + XD; ++i) dma_piece(d, i);
+        for (int i = 0; i < N_DMA; ++i) dma_piece(d, i);
     };
 
     // ---- per-lane LDS read offsets ----
@@ -305,13 +272,13 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     for (int d = 0; d < DEPTH; ++d) issue(d < n_k ? d : n_k - 1);
     // step 0 only: nothing but the other two prologue steps is younger than its pieces (the loop's counted wait assumes the
     // steady state, where two whole steps of stores and pieces are)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * (N_DMA + XD)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * N_DMA) : "memory");
 
     for (int k = 0; k < n_k; ++k) {
         uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
         // ---- top of the step ----
         const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTRL ? Cnt<CTRL, ORDB, XD>::TOP_CTRL : Cnt<CTRL, ORDB, XD>::TOP) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTRL ? Cnt<CTRL, ORDB>::TOP_CTRL : Cnt<CTRL, ORDB>::TOP) : "memory");
         const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         if (CTRL) {
             // the flag values polled in the previous step have landed behind the counted wait
@@ -359,9 +326,8 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             f32x16 acc = zero_acc();
             {
                 const uint8_t* bp = slot + lane * 16;
-                // operand window: WIN reads ahead of the MFMA that consumes them (the sigma stage affords 2: its working set is at the
-                // 256-register limit, one unit more and the compiler spills a W^T unit to scratch and reloads it behind vmcnt(0))
-                constexpr int WIN = SIGMA ? 2 : 3;
+                // operand window: WIN reads ahead of the MFMA that consumes them
+                constexpr int WIN = 3;
                 U fr[WIN];
 #pragma unroll
                 for (int d = 0; d < WIN; ++d) fr[d] = lds_unit<P>(bp + d * 1024);
@@ -369,19 +335,10 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 for (int kg = 0; kg < 16; ++kg) {
                     if (!(EO_PABL & 2)) acc = P::mma(wt[kg], fr[kg % WIN], acc);
                     if (!(EO_PABL & 4) && kg + WIN < 16) fr[kg % WIN] = lds_unit<P>(bp + (kg + WIN) * 1024);
-                    // 17th k-group (sigma row): its A unit comes out of LDS into the window slot that is no longer refilled
-                    if (SIGMA && kg == 16 - WIN) fr[kg % WIN] = lds_unit<P>(wsig_lds);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (SIGMA) {      // feature 256 = d sigma_pre: element 0 of the h == 0 lanes of the B unit
-                    U du = P::zero();
-                    const float ds = *reinterpret_cast<const float*>(dsig_lds + (k & (NSLOT - 1)) * DSIG_B + c * 4);
-                    du[0] = (__bf16)(h == 0 ? ds : 0.f);
-                    acc = P::mma(fr[(16 - WIN) % WIN], du, acc);
                 }
             }
             u32x2 xm[4] = {};
-            if constexpr (MASK)
             asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
                          "ds_read_b64_tr_b16 %1, %5\n\t"
                          "ds_read_b64_tr_b16 %2, %6\n\t"
@@ -394,7 +351,6 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #pragma unroll
             for (int s = 0; s < 8; ++s) {      // word s = accumulator registers 2s, 2s+1 <-> activation word s of the transposed reads
                 if (EO_PABL & 32) { w8[s] = xm[s >> 1][s & 1]; continue; }
-                if constexpr (!MASK) { w8[s] = cvt_pk_bf16(acc[2 * s], acc[2 * s + 1]); continue; }
                 uint32_t flags, r;
                 const uint32_t xw = xm[s >> 1][s & 1];
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(flags) : "v"(xw), "v"(0x00010001u));        // post-ReLU bf16 >= 0: 1 where > 0
@@ -471,7 +427,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                     if (!(EO_PABL & 1)) dw[j] = P::mma(af, bf[j & 1], dw[j]);
                     if (!(EO_PABL & 4) && j + 2 < 8) bf[j & 1] = lds_unit<P>(xb + (j + 2) * 2048);
 #if EO_PIPE_SPREAD
-                    if ((j & 1) && 4 * ks + (j >> 1) < N_DMA + XD) dma_piece(dma, 4 * ks + (j >> 1));      // pieces 0..3 behind MFMAs 1, 3, 5, 7 of the first K step, piece 4 (XD) behind MFMA 1 of the second
+                    if ((j & 1) && 4 * ks + (j >> 1) < N_DMA) dma_piece(dma, 4 * ks + (j >> 1));      // pieces 0..3 behind MFMAs 1, 3, 5, 7 of the first K step
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -487,7 +443,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         auto issue_block = [&]() {
 #if !EO_PIPE_SPREAD
 #pragma unroll
-            for (int i = 0; i < N_DMA + XD; ++i) dma_piece(dma, i);
+            for (int i = 0; i < N_DMA; ++i) dma_piece(dma, i);
 #endif
         };
         if (!ORDB) {
@@ -567,13 +523,10 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         return;
     }
     if (EO_PABL & 64) return;      // diagnostic: no flush at all (what the 64 K atomics per workgroup cost)
-    // rows >= 128 of a split stage (heads launch, "AT1": [albedo head; transient head]) belong to a second tensor; wave-uniform choice
-    const bool hi = a.split[S.st] && wave >= 4;
-    if (hi && a.skip_hi[S.st]) return;             // transient head outside the autograd graph: its rows carried zeros
-    float* dwp = a.d_flat + (hi ? a.dw_off2[S.st] : a.dw_off[S.st]);
-    float* dbp = a.d_flat + (hi ? a.db_off2[S.st] : a.db_off[S.st]);
-    const int ld = hi ? a.dw_ld2[S.st] : a.dw_ld[S.st];
-    const int row0 = hi ? 32 * (wave - 4) : 32 * wave;
+    float* dwp = a.d_flat + a.dw_off[S.st];
+    float* dbp = a.d_flat + a.db_off[S.st];
+    const int ld = a.dw_ld[S.st];
+    const int row0 = 32 * wave;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -622,26 +575,6 @@ __global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
     }
 }
 
-// heads launch (camera pass): stage 0 "AT1", stage 1 "bott" (see eonerf_kernels.h)
-__global__ __launch_bounds__(NT) void k_heads_pipe(BwdPipeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x;
-    Stage S;
-    if (!take_role(a, smem, tid, S)) return;
-    const int wv = tid >> 6;
-    if (S.st == 0) {
-        S.x_row = ACT_ROW_BOTT;                    // the bottleneck output: input of both heads' first layers
-        if (wv == 0) run_stage<true, 0, false, false>(a, S, smem, tid); else if (wv < 4) run_stage<false, 0, false, false>(a, S, smem, tid); else run_stage<false, 0, true, false>(a, S, smem, tid);
-    } else {
-        S.x_row = ACT_ROW_X1 + 256 * 7;            // X_8: input of the bottleneck and sigma layers
-        S.out_lin = a.dy_out;
-        if (wv == 0) run_stage<true, 3>(a, S, smem, tid);
-        else if (wv == 1) run_stage<false, 3, false, true, 1>(a, S, smem, tid);      // also copies d sigma_pre
-        else if (wv < 4) run_stage<false, 3>(a, S, smem, tid);
-        else run_stage<false, 3, true>(a, S, smem, tid);
-    }
-}
-
 // deterministic mode: block = (stage, row), thread = column; pipelines that had no step wrote nothing and are skipped
 __global__ __launch_bounds__(256) void k_pipe_reduce(BwdPipeArgs a) {
     const int st = blockIdx.y, row = blockIdx.x, col = threadIdx.x;
@@ -653,11 +586,8 @@ __global__ __launch_bounds__(256) void k_pipe_reduce(BwdPipeArgs a) {
         acc += pt[row * 256 + col];
         if (col == 0) accb += pt[256 * 256 + row];
     }
-    const bool hi = a.split[st] && row >= 128;
-    if (hi && a.skip_hi[st]) return;
-    const int r = hi ? row - 128 : row;
-    a.d_flat[(hi ? a.dw_off2[st] : a.dw_off[st]) + (size_t)r * (hi ? a.dw_ld2[st] : a.dw_ld[st]) + col] += acc;
-    if (col == 0) a.d_flat[(hi ? a.db_off2[st] : a.db_off[st]) + r] += accb;
+    a.d_flat[a.dw_off[st] + (size_t)row * a.dw_ld[st] + col] += acc;
+    if (col == 0) a.d_flat[a.db_off[st] + row] += accb;
 }
 
 }  // namespace
@@ -677,16 +607,5 @@ hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_bwd_pipe, dim3(a.n_pipes * PIPE_STAGES), dim3(NT), SMEM_B, st, a);
-    return hipGetLastError();
-}
-
-hipError_t eo_launch_heads_pipe(const BwdPipeArgs& a, hipStream_t st) {
-    if (a.n_stages != HEADS_STAGES || !a.dy_out || !a.dsig || !a.wsig) return hipErrorInvalidValue;
-    static EoAttrOnce attr;
-    {
-        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_heads_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_HEADS_B); });
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(k_heads_pipe, dim3(a.n_pipes * HEADS_STAGES), dim3(NT), SMEM_HEADS_B, st, a);
     return hipGetLastError();
 }

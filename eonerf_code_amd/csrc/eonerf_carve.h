@@ -12,8 +12,8 @@
 constexpr int BOTT_SCRATCH_F = 2 * 128 * 256 + 256;       // bottleneck factors M_a | M_t, then db_A1 | db_T1
 
 struct CarveCfg {          // what the layout depends on besides (n_rays, flags): see eonerf_ctx
-    bool bf16 = true, pipe = false, heads_pipe = false, deterministic = false, pipe_partials = false;
-    int n_pipes = 0, n_pipes_heads = 0;
+    bool bf16 = true, pipe = false, deterministic = false, pipe_partials = false;
+    int n_pipes = 0;
 };
 
 // bump allocator over the caller's workspace (256-byte aligned); with base == nullptr it only measures
@@ -34,18 +34,16 @@ struct PassBuffers {       // one MLP pass (camera or sun) over up to p_cap samp
     int* simg;
     void *act, *grd; uint32_t* masks;
     float *g_sigma, *g_albedo, *g_ts, *g_tb, *g_emb, *g_pos;
-    float* dsig;           // heads pipeline: d sigma_pre per sample (fp32), written by the heads chain
 };
 
 struct PipeWs {            // layer-pipelined backward (eonerf_bwd_pipe.hip)
-    uint8_t* dy_in;        // dY_7 in unit order: p_cap x 512 B (heads chain or heads pipeline -> trunk pipeline)
-    uint8_t* dy_heads;     // [dY_A1; dY_T1] in unit order: p_cap x 512 B (heads chain -> heads pipeline, and the embedding-column GEMM job)
-    uint8_t* rings;        // [pipelines][edges][PIPE_RING][16 KiB], sized for the larger of the two launch shapes
-    uint32_t* sync;        // PIPE_LAUNCHES consecutive blocks, one per pipelined launch of a backward call (sun trunk, camera heads, camera
-                           // trunk): [32] role counter, [64..) one scratch line per workgroup, then the edge flags -- all zeroed by ONE memset
+    uint8_t* dy_in;        // dY_7 in unit order: p_cap x 512 B (heads chain -> trunk pipeline)
+    uint8_t* rings;        // [pipelines][edges][PIPE_RING][16 KiB]
+    uint32_t* sync;        // PIPE_LAUNCHES consecutive blocks, one per pipelined launch of a backward call (sun trunk, camera trunk):
+                           // [32] role counter, [64..) one scratch line per workgroup, then the edge flags -- all zeroed by ONE memset
     size_t sync_bytes;     // of one block
 };
-constexpr int PIPE_LAUNCHES = 3;
+constexpr int PIPE_LAUNCHES = 2;
 
 struct DetWs {             // EONERF_DETERMINISTIC: partial sums instead of atomics
     float* pipe_part;      // [n_pipes * 7][256 * 256 + 256]
@@ -85,7 +83,6 @@ inline void carve_pass(Carver& c, PassBuffers& b, int n_rays, int p_cap, bool fu
     b.tb = full ? c.take<float>(p_cap) : nullptr;
     b.act = b.grd = nullptr; b.masks = nullptr;
     b.g_sigma = b.g_albedo = b.g_ts = b.g_tb = b.g_emb = b.g_pos = nullptr;
-    b.dsig = nullptr;
     if (train) {
         b.act = c.take<uint8_t>((size_t)(full ? ACT_ROWS_FULL : ACT_ROWS_DENSITY) * p_cap * act_bytes);
         b.grd = c.take<uint8_t>((size_t)(full ? GRD_ROWS_FULL : GRD_ROWS_DENSITY) * p_cap * act_bytes);
@@ -95,7 +92,6 @@ inline void carve_pass(Carver& c, PassBuffers& b, int n_rays, int p_cap, bool fu
             b.g_albedo = c.take<float>(3 * (size_t)p_cap);
             b.g_ts = c.take<float>(p_cap); b.g_tb = c.take<float>(p_cap);
             b.g_emb = c.take<float>(4 * (size_t)p_cap);
-            b.dsig = c.take<float>(p_cap);
         }
         if (input_grad) b.g_pos = c.take<float>(3 * (size_t)p_cap);
     }
@@ -118,18 +114,16 @@ inline RenderWs carve_render(const CarveCfg& cfg, void* base, int n_rays, int fl
     w.queue = w.m_bott ? reinterpret_cast<int*>(w.m_bott + BOTT_SCRATCH_F) : nullptr;      // (measuring pass: no arithmetic on a null base)
     memset(&w.pipe, 0, sizeof(w.pipe));
     if (train && ctx->pipe) {
-        // one sync block fits either launch shape: 7 x n_pipes or 2 x n_pipes_heads workgroups, 6 x n_pipes or 1 x n_pipes_heads edges
-        const size_t wgs = std::max((size_t)ctx->n_pipes * PIPE_STAGES, (size_t)ctx->n_pipes_heads * HEADS_STAGES);
-        const size_t edges = std::max((size_t)ctx->n_pipes * (PIPE_STAGES - 1), (size_t)ctx->n_pipes_heads * (HEADS_STAGES - 1));
+        const size_t wgs = (size_t)ctx->n_pipes * PIPE_STAGES;
+        const size_t edges = (size_t)ctx->n_pipes * (PIPE_STAGES - 1);
         w.pipe.sync_bytes = (64 + wgs * 32 + edges * 64) * sizeof(uint32_t);
         w.pipe.sync = c.take<uint32_t>(PIPE_LAUNCHES * w.pipe.sync_bytes / sizeof(uint32_t));
         w.pipe.dy_in = c.take<uint8_t>((size_t)p_cap * 512);
-        w.pipe.dy_heads = ctx->heads_pipe ? c.take<uint8_t>((size_t)p_cap * 512) : nullptr;
         w.pipe.rings = c.take<uint8_t>(edges * PIPE_RING * PIPE_UNIT_B);
     }
     memset(&w.det, 0, sizeof(w.det));
     if (train && ctx->pipe && ctx->pipe_partials)
-        w.det.pipe_part = c.take<float>(std::max((size_t)ctx->n_pipes * PIPE_STAGES, (size_t)ctx->n_pipes_heads * HEADS_STAGES) * WGRAD_PART_F);
+        w.det.pipe_part = c.take<float>((size_t)ctx->n_pipes * PIPE_STAGES * WGRAD_PART_F);
     if (train && ctx->deterministic) {
         w.det.wgrad_part = c.take<float>((size_t)WGRAD_MAX_JOBS * 48 * WGRAD_PART_F);
         w.det.rad_rays = c.take<float>((size_t)n_rays * 6);

@@ -21,37 +21,36 @@ struct EoAttrOnce {
 // ---- rows of the saved-activation slab [ACT_ROWS][p_pad] (feature-major, see eonerf_mlp_fwd.hip) ----
 constexpr int ACT_ROW_ENC = 0;        // 64 encoding slots (slot order, see enc_col_of_hq)
 constexpr int ACT_ROW_X1 = 64;        // X1..X8 : outputs of trunk layers 0..7, 256 rows each
-constexpr int ACT_ROW_BOTT = 64 + 8 * 256;          // 2112
-constexpr int ACT_ROW_A1 = ACT_ROW_BOTT + 256;      // 2368, albedo hidden (128)
-constexpr int ACT_ROW_T1 = ACT_ROW_A1 + 128;        // 2496, transient hidden T1..T4 (4 x 128)
-constexpr int ACT_ROW_EMB = ACT_ROW_T1 + 512;       // 3008, transient embedding rows (8 used, 4 real)
-constexpr int ACT_ROWS_FULL = ACT_ROW_EMB + 32;     // 3040
-constexpr int ACT_ROWS_DENSITY = ACT_ROW_BOTT;      // 2112 (trunk only)
+constexpr int ACT_ROW_HEADS = 64 + 8 * 256;         // 2112 (the bottleneck OUTPUT has no rows: the layer is folded into the heads, eonerf_pack.h)
+constexpr int ACT_ROW_A1 = ACT_ROW_HEADS;           // 2112, albedo hidden (128)
+constexpr int ACT_ROW_T1 = ACT_ROW_A1 + 128;        // 2240, transient hidden T1..T4 (4 x 128)
+constexpr int ACT_ROW_EMB = ACT_ROW_T1 + 512;       // 2752, transient embedding rows (8 used, 4 real)
+constexpr int ACT_ROWS_FULL = ACT_ROW_EMB + 32;     // 2784
+constexpr int ACT_ROWS_DENSITY = ACT_ROW_HEADS;     // 2112 (trunk only)
 
 // ---- rows of the saved-gradient slab [GRD_ROWS][p_pad] written by the backward chain ----
 constexpr int GRD_ROW_Y0 = 0;                       // dY of trunk layers 0..7 (pre-activation grads), 256 rows each
-constexpr int GRD_ROW_BOTT = 8 * 256;               // 2048: d bottleneck (256)
-constexpr int GRD_ROW_SIG = GRD_ROW_BOTT + 256;     // 2304: d sigma_pre (1 row used of 32)
-constexpr int GRD_ROW_A2 = GRD_ROW_SIG + 32;        // 2336: d albedo_pre (3 rows used of 32)
-constexpr int GRD_ROW_A1 = GRD_ROW_A2 + 32;         // 2368: dY albedo hidden (128) ...
-constexpr int GRD_ROW_T1 = GRD_ROW_A1 + 128;        // 2496: ... and dY T1 (128) share ONE 256-row block (both multiply X8 and the bottleneck output:
-                                                    //       one weight-gradient job each instead of two), then dY T2..T4 (3 x 128)
-constexpr int GRD_ROW_T5 = GRD_ROW_T1 + 512;        // 3008: d {ts_pre, tb_pre} (2 rows used of 32)
-constexpr int GRD_ROWS_FULL = GRD_ROW_T5 + 32;      // 3040
-constexpr int GRD_ROWS_DENSITY = GRD_ROW_SIG + 32;  // 2336
+constexpr int GRD_ROW_SIG = 8 * 256;                // 2048: d sigma_pre (1 row used of 32)   (d bottleneck is never formed: eonerf_pack.h)
+constexpr int GRD_ROW_A2 = GRD_ROW_SIG + 32;        // 2080: d albedo_pre (3 rows used of 32)
+constexpr int GRD_ROW_A1 = GRD_ROW_A2 + 32;         // 2112: dY albedo hidden (128) ...
+constexpr int GRD_ROW_T1 = GRD_ROW_A1 + 128;        // 2240: ... and dY T1 (128) share ONE 256-row block (both multiply X8: one weight-gradient
+                                                    //       job, the bottleneck factors), then dY T2..T4 (3 x 128)
+constexpr int GRD_ROW_T5 = GRD_ROW_T1 + 512;        // 2752: d {ts_pre, tb_pre} (2 rows used of 32)
+constexpr int GRD_ROWS_FULL = GRD_ROW_T5 + 32;      // 2784
+constexpr int GRD_ROWS_DENSITY = GRD_ROW_SIG + 32;  // 2080
 
 // row blocks of the two slabs (block-major layout, see eonerf_common.h): the operand units of the weight-gradient jobs
 struct ActMap {
     __host__ __device__ static constexpr SlabBlk block(int row) {
         if (row < ACT_ROW_X1) return SlabBlk{ACT_ROW_ENC, 64};
-        if (row < ACT_ROW_A1) return SlabBlk{ACT_ROW_X1 + (row - ACT_ROW_X1) / 256 * 256, 256};     // X1..X8, bottleneck
+        if (row < ACT_ROW_A1) return SlabBlk{ACT_ROW_X1 + (row - ACT_ROW_X1) / 256 * 256, 256};     // X1..X8
         if (row < ACT_ROW_EMB) return SlabBlk{ACT_ROW_A1 + (row - ACT_ROW_A1) / 128 * 128, 128};    // A1, T1..T4
         return SlabBlk{ACT_ROW_EMB, 32};
     }
 };
 struct GrdMap {
     __host__ __device__ static constexpr SlabBlk block(int row) {
-        if (row < GRD_ROW_SIG) return SlabBlk{row / 256 * 256, 256};                                 // dY0..dY7, d bottleneck
+        if (row < GRD_ROW_SIG) return SlabBlk{row / 256 * 256, 256};                                 // dY0..dY7
         if (row < GRD_ROW_A2) return SlabBlk{GRD_ROW_SIG, 32};
         if (row < GRD_ROW_A1) return SlabBlk{GRD_ROW_A2, 32};
         if (row < GRD_ROW_T1 + 128) return SlabBlk{GRD_ROW_A1, 256};                                 // dY A1 | dY T1
@@ -78,8 +77,6 @@ struct MlpFwdArgs {
     float *sigma, *albedo, *ts, *tb;   // outputs: sigma[p_pad], albedo[3][p_pad], ts[p_pad], tb[p_pad]
     void* act;                     // TRAIN: [ACT_ROWS][p_pad] of P::act_t
     uint32_t* masks;               // TRAIN: [MASK_SLOTS][p_pad][2][4] ReLU masks
-    int save_bott;                 // TRAIN: also save the bottleneck OUTPUT rows (only the heads pipeline reads them: the chain + GEMM path gets
-                                   // the heads' first-layer weight gradients from the bottleneck factors, see BottWgradArgs)
     int mask_from;                 // TRAIN: first mask slot the backward will read (the pipelined trunk backward derives ReLU' from the saved
                                    // activations themselves: slots below are not written)
 };
@@ -97,9 +94,8 @@ struct MlpBwdArgs {
     float* g_emb;                  // FULL: [p_pad][4] grad wrt the per-sample transient embedding
     const float *px, *py, *pz;     // INPUT_GRAD: positions (encoder derivative)
     float* g_pos;                  // INPUT_GRAD: [3][p_pad]
-    uint8_t* dy7_units;            // PIPE 1: dY_7, PIPE 2: [dY_A1; dY_T1], in B-operand unit order [step of 32 samples][16 KiB]; the rest of the
-                                   // dX chain is left to eonerf_bwd_pipe.hip
-    float* dsig_out;               // PIPE 2: [p_pad] d sigma_pre per sample for the heads pipeline's "bott" stage
+    uint8_t* dy7_units;            // PIPE 1: dY_7 in B-operand unit order [step of 32 samples][16 KiB]; the rest of the dX chain is left to
+                                   // eonerf_bwd_pipe.hip
 };
 
 // One weight-gradient GEMM job:  dW[m][col_map[n]] += sum_p  dY^T[m][p] * X^T[n][p]
@@ -121,16 +117,8 @@ struct WgradJob {
     int a_units;          // bf16: a's tiles are in B-operand unit order (written by eonerf_bwd_pipe.hip), not feature-major rows
 };
 
-// ---- layer-pipelined backward (eonerf_bwd_pipe.hip): two launch shapes built from one stage body ----
-//   trunk : 7 stages = trunk layers 7..1 (input dY_7, X images X_7..X_1), floor(CUs / 7) pipelines
-//   heads : 2 stages = the two wide layers between the heads and the trunk (camera pass only), CUs / 2 pipelines:
-//             stage 0 "AT1"  [dY_A1; dY_T1] (256) -> d bottleneck   X image = the bottleneck output (identity activation: no mask),
-//                            dW = the first layers of the albedo head (rows 0..127) and of the transient head (rows 128..255, bottleneck
-//                            columns; its 4 embedding columns stay with the GEMM)
-//             stage 1 "bott" d bottleneck (+ the sigma row's rank-1 term) -> dY_7 = (W_bott^T d_bott + w_sigma d sigma_pre) .* (X_8 > 0),
-//                            written in unit order to the buffer the trunk launch reads; dW = the bottleneck layer
+// ---- layer-pipelined backward (eonerf_bwd_pipe.hip): 7 stages = trunk layers 7..1 (input dY_7, X images X_7..X_1), floor(CUs / 7) pipelines
 constexpr int PIPE_STAGES = 7;        // trunk layers 7..1, one workgroup each
-constexpr int HEADS_STAGES = 2;
 constexpr int PIPE_MAX_STAGES = 7;
 constexpr int PIPE_TS = 32;           // samples per step = one sample tile of the bf16 slabs
 constexpr int PIPE_RING = 16;         // slots (steps) of an inter-stage ring
@@ -138,7 +126,7 @@ constexpr int PIPE_UNIT_B = 16 * 1024;   // one step of a 256-feature tensor in 
 struct BwdPipeArgs {
     const int* n_pts; int p_pad;
     int n_pipes;
-    int n_stages;             // PIPE_STAGES (trunk launch) or HEADS_STAGES (heads launch)
+    int n_stages;             // PIPE_STAGES
     const uint8_t* wt;        // stage-stationary W^T: [stage][m-tile 8][k-group 16][lane 64][16 B] bf16 (eonerf_pack.cpp)
     const uint8_t* dy_in;     // input of stage 0 of every step in unit order [step][16 KiB] (written by an earlier launch)
     const void* act;          // activation slab (block-major feature-major tiles, eonerf_common.h)
@@ -149,19 +137,14 @@ struct BwdPipeArgs {
     int* role_counter;        // zeroed per launch
     int* error;               // the context's STICKY status word: watchdog bits are OR-ed in, never cleared by a launch
     float* d_flat;
-    // weight / bias gradient destinations per stage; rows >= 128 of a stage with split != 0 go to the second destination (row - 128)
-    size_t dw_off[PIPE_MAX_STAGES], db_off[PIPE_MAX_STAGES], dw_off2[PIPE_MAX_STAGES], db_off2[PIPE_MAX_STAGES];
-    int dw_ld[PIPE_MAX_STAGES], dw_ld2[PIPE_MAX_STAGES], split[PIPE_MAX_STAGES], skip_hi[PIPE_MAX_STAGES];   // skip_hi: rows >= 128 carry no gradient (transient head outside the graph)
+    // weight / bias gradient destinations per stage
+    size_t dw_off[PIPE_MAX_STAGES], db_off[PIPE_MAX_STAGES];
+    int dw_ld[PIPE_MAX_STAGES];
     unsigned long long* stamps;   // diagnostics (EONERF_PIPE_STAMPS): [workgroup role][2 waves][8] cycle sums, or nullptr
     float* partials;          // deterministic mode: [pipeline][stage][256 x 256 dW | 256 db] instead of the atomic flush (reduced in pipeline order)
     int fault_stage;          // test hook (EONERF_PIPE_FAULT): this stage never publishes its tiles -> every watchdog downstream must fire; -1 = off
-    // heads launch only
-    uint8_t* dy_out;          // dY_7 of every step in unit order [step][16 KiB]: the trunk launch's dy_in
-    const float* dsig;        // [p_pad] d sigma_pre per sample (written by the heads chain)
-    const uint8_t* wsig;      // [m-tile 8][lane 64][16 B]: the sigma row as the A units of a 17th k-group (k = 0: w_sigma[32 mt + r])
 };
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st);
-hipError_t eo_launch_heads_pipe(const BwdPipeArgs& a, hipStream_t st);
 // input-gradient tail of a pipelined density pass (eonerf_ig_tail.hip)
 struct IgTailArgs {
     const int* n_pts; int p_pad;
@@ -174,7 +157,7 @@ hipError_t eo_launch_ig_tail(const IgTailArgs& a, int n_wg, hipStream_t st);
 size_t eo_bwd_pipe_lds_bytes();
 
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);
-// pipe: 0 = the whole dX chain; 1 = stop at dY_7 (the trunk is pipelined); 2 (camera pass) = stop at [dY_A1; dY_T1] (heads + trunk pipelined)
+// pipe: 0 = the whole dX chain; 1 = stop at dY_7 (the trunk is pipelined)
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, int pipe = 0);
 constexpr int WGRAD_MAX_JOBS = 32;     // <= 31 used (fp32 chain + GEMM path, full model); the table must fit the 4-KiB kernel-argument segment
 static_assert(sizeof(WgradJob) * WGRAD_MAX_JOBS + 8 + 64 <= 4096, "job table exceeds the kernel-argument segment");

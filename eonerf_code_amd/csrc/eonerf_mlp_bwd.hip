@@ -27,10 +27,9 @@ template <class P> EO_DEV typename P::U small_unit(const float (&v)[4], int h) {
 // TRANS = false: the transient head is outside the autograd graph (see k_mlp_fwd MODE 2): its layers are skipped.
 // PIPE 1 (bf16): the kernel stops at dY_7 and hands it, in B-operand unit order, to the layer-pipelined trunk backward
 // (eonerf_bwd_pipe.hip), which computes dY_6..dY_0 AND the trunk weight gradients without parking dY in HBM.
-// PIPE 2 (bf16, camera pass): the kernel stops one layer pair earlier, at [dY_A1; dY_T1] -- the two wide layers behind it (both heads'
-// first layers -> d bottleneck, [d bottleneck; d sigma_pre] -> dX_8) run as the heads launch of the pipelined backward, which also
-// accumulates their weight gradients.  What stays here: the narrow head layers (transient tail, albedo output layer), the four
-// embedding columns of the transient head's first layer (d embedding), and d sigma_pre per sample for the pipeline's sigma term.
+// The bottleneck layer (identity activation) does not appear: the heads' first layers are folded with it (eonerf_pack.h), so
+// [dY_A1; dY_T1; d sigma_pre] goes to dX_8 in ONE layer; the bottleneck layer's own weight gradient follows from the bottleneck
+// factors (BottWgradArgs).
 template <class P, bool FULL, bool IG, bool TRANS, int PIPE = 0>
 __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     constexpr int SLOT = FwdSlot<P>::BYTES;
@@ -69,26 +68,16 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         };
         // dX tile -> (optional ReLU mask) -> units of the next backward layer + feature-major save for the wgrad GEMM
         // (slice s of the epilogue of m-tile mt, see chunk_compute)
-        // d bottleneck: identity activation, handed on in registers only.  Its weight gradient is computed WITHOUT the saved
-        // tensor: dW_bott = W_A1^T (dA1^T X8) [+ W_T1^T (dT1^T X8)] -- two 128-row jobs of the weight-gradient GEMM on operands
-        // that are saved anyway, and a 256x128x256 product afterwards (eo_launch_bott_wgrad), instead of 256 more rows written
-        // here and read back there.
-        auto bott_epi = [&](U* dst, int mt, const f32x16& accv, int s) { put_slice(P(), dst, mt, s, pack_slice(P(), accv, s)); };
         auto grad_epi = [&](U* dst, int grd_row, bool masked, int mt, const f32x16& accv, int s) {
             const Sl<P> v = masked ? mask_slice(P(), accv, s, mt, mb[mt >> 1]) : pack_slice(P(), accv, s);
             put_slice(P(), dst, mt, s, v);
             sw.stage(grd_row + 32 * mt, s, v);
-        };
-        // PIPE 2: dY_A1 / dY_T1 are handed on in unit order only (their weight-gradient products run in the heads pipeline)
-        auto grad_epi_units = [&](U* dst, int mt, const f32x16& accv, int s) {
-            put_slice(P(), dst, mt, s, mask_slice(P(), accv, s, mt, mb[mt >> 1]));
         };
 
         // ---------------- output heads: activation derivatives from the saved forward outputs ----------------
         const float sg = live ? a.sigma[p] : 0.f;
         float dsig[4] = {live ? a.g_sigma[p] * (1.f - expf(-sg)) : 0.f, 0.f, 0.f, 0.f};    // softplus' = 1 - exp(-softplus)
         sw.elem(GRD_ROW_SIG, h == 0 ? dsig[0] : 0.f);
-        if constexpr (PIPE == 2) { if (h == 0) a.dsig_out[p] = dsig[0]; }      // (p < p_pad: tiles are whole; dead samples carry 0)
 
         U D[HKG], N[HKG];
         if constexpr (FULL) {
@@ -125,61 +114,33 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v, s); });
                 load_mask(9, 2);
-                if constexpr (PIPE == 2)
-                    run_layer<P, SLOT, QKG, 4, false>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
-                        [&](int mt, const f32x16& v, int s) { grad_epi_units(TB, mt, v, s); });                    // TB = dY_T1
-                else
                 run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TB, GRD_ROW_T1, true, mt, v, s); });        // TB = dY_T1
             }
             // ---- albedo head backwards: albedo_pre -> A1 ----
             const U u_al = small_unit<P>(dalb, h);
             load_mask(8, 2);
-            if constexpr (PIPE == 2)
-                run_layer<P, SLOT, 1, 4, false>(ws, mid, lane, h, [&](int) { return u_al; },
-                    [&](int mt, const f32x16& v, int s) { grad_epi_units(DA1, mt, v, s); });
-            else
             run_layer<P, SLOT, 1, 4, false, NST>(ws, mid, lane, h, [&](int) { return u_al; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(DA1, GRD_ROW_A1, true, mt, v, s); });
-            if constexpr (PIPE == 2) {
-                if constexpr (TRANS) {
-                    // ---- dY_T1 -> d embedding: the four embedding columns of the transient head's first layer (one m-tile, rows 0..3) ----
-                    run_layer<P, SLOT, QKG, 1, false>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
-                        [&](int, const f32x16& v, int s) {
-                            if (s == 0 && h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
-                        });
-                }
-                // this wave's 32 samples = step wt of the heads pipeline: units 0..7 = dY_A1, 8..15 = dY_T1 (zeros when the
-                // transient head is outside the graph)
-                uint8_t* dst = a.dy7_units + (size_t)wt * 16 * 1024 + lane * 16;
-#pragma unroll
-                for (int kg = 0; kg < QKG; ++kg) {
-                    *reinterpret_cast<U*>(dst + kg * 1024) = DA1[kg];
-                    if constexpr (TRANS) *reinterpret_cast<U*>(dst + (QKG + kg) * 1024) = TB[kg];
-                    else *reinterpret_cast<U*>(dst + (QKG + kg) * 1024) = P::zero();
-                }
-                sw.drain();
-                continue;
-            }
             if constexpr (TRANS) {
-                // ---- [dY_A1, dY_T1] -> d bottleneck (tiles 0..7, identity) and d embedding (tile 8, rows 0..3) ----
-                run_layer<P, SLOT, 2 * QKG, 9, false>(ws, mid, lane, h,
-                    [&](int kg) { return kg < QKG ? DA1[kg < QKG ? kg : 0] : TB[kg >= QKG ? kg - QKG : 0]; },
-                    [&](int mt, const f32x16& v, int s) {
-                        if (mt < 8) { bott_epi(N, mt, v, s); return; }
+                // ---- dY_T1 -> d embedding: the four embedding columns of the transient head's first layer (one m-tile, rows 0..3) ----
+                run_layer<P, SLOT, QKG, 1, false>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
+                    [&](int, const f32x16& v, int s) {
                         if (s == 0 && h == 0 && live) *reinterpret_cast<f32x4*>(a.g_emb + 4 * (size_t)p) = f32x4{v[0], v[1], v[2], v[3]};
                     });
-            } else {
-                // ---- dY_A1 -> d bottleneck ----
-                run_layer<P, SLOT, QKG, 8, false>(ws, mid, lane, h, [&](int kg) { return DA1[kg]; },
-                    [&](int mt, const f32x16& v, int s) { bott_epi(N, mt, v, s); });
             }
-            // ---- [d bottleneck, d sigma_pre] -> dX8 -> mask(layer 7) -> dY7 ----
+            // ---- [dY_A1, dY_T1 (transient head in the graph), d sigma_pre] -> dX8 -> mask(layer 7) -> dY7, through the heads' first
+            //      layers folded with the bottleneck layer ----
+            constexpr int AKG = TRANS ? 2 * QKG : QKG;
             const U u_sg = small_unit<P>(dsig, h);
             load_mask(7, 4);
+            auto src = [&](int kg) {
+                if (kg < QKG) return DA1[kg < QKG ? kg : 0];
+                if constexpr (TRANS) { if (kg < AKG) return TB[(kg >= QKG && kg < AKG) ? kg - QKG : 0]; }
+                return u_sg;
+            };
             if constexpr (PIPE == 1) {
-                run_layer<P, SLOT, HKG + 1, 8, false>(ws, mid, lane, h,
-                    [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
+                run_layer<P, SLOT, AKG + 1, 8, false>(ws, mid, lane, h, src,
                     [&](int mt, const f32x16& v, int s) { put_slice(P(), D, mt, s, mask_slice(P(), v, s, mt, mb[mt >> 1])); });
                 // this wave's 32 samples = step wt of the pipeline: 16 units of 1 KiB
                 uint8_t* dst = a.dy7_units + (size_t)wt * 16 * 1024 + lane * 16;
@@ -188,8 +149,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 sw.drain();
                 continue;
             }
-            run_layer<P, SLOT, HKG + 1, 8, false, NST>(ws, mid, lane, h,
-                [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : u_sg; },
+            run_layer<P, SLOT, AKG + 1, 8, false, NST>(ws, mid, lane, h, src,
                 [&](int mt, const f32x16& v, int s) { grad_epi(D, GRD_ROW_Y0 + 7 * 256, true, mt, v, s); });
         } else {
             const U u_sg = small_unit<P>(dsig, h);
@@ -298,10 +258,6 @@ template <class P> hipError_t dispatch(const MlpBwdArgs& a, bool full, bool inpu
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, int pipe) {
     if (!full && !input_grad) return hipErrorInvalidValue;
     if (full && input_grad && !transient) return hipErrorInvalidValue;
-    if (pipe == 2) {      // camera pass, narrow head layers only; the wide layers and the trunk run in eonerf_bwd_pipe.hip
-        if (!bf16 || !a.dy7_units || !a.dsig_out || !full || input_grad) return hipErrorInvalidValue;
-        return transient ? launch<PBf16, true, false, true, 2>(a, grid, st) : launch<PBf16, true, false, false, 2>(a, grid, st);
-    }
     if (pipe) {      // heads only; the trunk runs in eonerf_bwd_pipe.hip (bf16), the input gradient in eonerf_ig_tail.hip
         if (!bf16 || !a.dy7_units || (full && input_grad)) return hipErrorInvalidValue;
         if (!full) return launch<PBf16, false, true, false, 1>(a, grid, st);

@@ -1,6 +1,7 @@
 // Fused EO-NeRF field forward (H4+H5+H6 of SURVEY.md 8a):
-//   positional encoding -> 8x256 trunk (skip-concat after layer 4) -> sigma | bottleneck -> albedo head,
-//   transient head (radiance_fields/eonerf.py:154-170, radiance_fields/mlp.py:87-101,190-208).
+//   positional encoding -> 8x256 trunk (skip-concat after layer 4) -> sigma | albedo head, transient head
+//   (radiance_fields/eonerf.py:154-170, radiance_fields/mlp.py:87-101,190-208); the identity-activation bottleneck layer between the
+//   trunk and the heads is folded into the heads' first layers (eonerf_pack.h).
 // One persistent workgroup walks tiles of P::TILE samples.  Activations never leave registers (transposed
 // H^T chain, see eonerf_common.h); weights stream L2 -> LDS in packed fragment order (eonerf_pack.cpp).
 // TRAIN additionally saves, per layer, the post-activation tensor feature-major [F][P_pad] (the B operand
@@ -157,28 +158,25 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         plain_layer(N, H, 6);
         plain_layer(H, N, 7);
         // after l=7 (odd) the trunk output X8 lives in N
-        // ---------------- sigma (+ bottleneck) ----------------
+        // ---------------- sigma (+ heads) ----------------
         float sigma_raw = 0.f;
         if constexpr (!FULL) {
             run_layer<P, SLOT, HKG, 1, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
                 [&](int, const f32x16& v, int s) { if (s == 0) sigma_raw = v[0]; });
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
         } else {
-            // m-tile 0 = sigma row, m-tiles 1..8 = bottleneck (identity activation) -> H
-            run_layer<P, SLOT, HKG, 9, true>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
+            // The bottleneck layer (identity activation) is never evaluated: both heads' first layers read X_8 through weights FOLDED
+            // with it (eonerf_pack.h).  m-tiles 0..3 = albedo hidden: 256 -> 128 (ReLU), m-tile 4 = sigma row
+            U A1[QKG];
+            run_layer<P, SLOT, HKG, 5, true, NST>(ws, mid, lane, h, [&](int kg) { return N[kg]; },
                 [&](int mt, const f32x16& v, int s) {
-                    if (mt == 0) { if (s == 0) sigma_raw = v[0]; return; }
-                    const Sl<P> x = pack_slice(P(), v, s);
-                    put_slice(P(), H, mt - 1, s, x);
-                    if constexpr (TRAIN) { if (a.save_bott) sw.stage(ACT_ROW_BOTT + 32 * (mt - 1), s, x); }      // wave-uniform
+                    if (mt == 4) { if (s == 0) sigma_raw = v[0]; return; }
+                    relu_epi(A1, ACT_ROW_A1, mt, v, s);
                 });
+            save_mask(8, 2);
             if (h == 0 && live) a.sigma[p] = softplus_f(sigma_raw);
 
-            // ---------------- albedo head: 256 -> 128 (ReLU) -> 3 (Sigmoid) ----------------
-            U A1[QKG];
-            run_layer<P, SLOT, HKG, 4, true, NST>(ws, mid, lane, h, [&](int kg) { return H[kg]; },
-                [&](int mt, const f32x16& v, int s) { relu_epi(A1, ACT_ROW_A1, mt, v, s); });
-            save_mask(8, 2);
+            // ---------------- albedo head, output layer: 128 -> 3 (Sigmoid) ----------------
             run_layer<P, SLOT, QKG, 1, true>(ws, mid, lane, h, [&](int kg) { return A1[kg]; },
                 [&](int, const f32x16& v, int s) {
                     if (s == 0 && h == 0 && live) {
@@ -188,7 +186,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                     }
                 });
 
-            // ---------------- transient head: [bottleneck, emb(img)] (260) -> 4x128 (ReLU) -> {Sigmoid, Softplus} ----
+            // ---------------- transient head: [bottleneck(X_8), emb(img)] (260) -> 4x128 (ReLU) -> {Sigmoid, Softplus} ----
             U EMB = P::zero();
             if (h == 0) {
                 const int im = live ? a.simg[p] : 0;
@@ -202,7 +200,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             }
             U T1[QKG], T2[QKG];
             run_layer<P, SLOT, HKG + 1, 4, true, NST_T>(ws, mid, lane, h,
-                [&](int kg) { return kg < HKG ? H[kg < HKG ? kg : 0] : EMB; },
+                [&](int kg) { return kg < HKG ? N[kg < HKG ? kg : 0] : EMB; },
                 [&](int mt, const f32x16& v, int s) { relu_epi_t(T1, ACT_ROW_T1, mt, v, s); });
             if constexpr (TSAVE) save_mask(9, 2);
             run_layer<P, SLOT, QKG, 4, true, NST_T>(ws, mid, lane, h, [&](int kg) { return T1[kg]; },

@@ -109,18 +109,23 @@ PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full) {
             dense(pl.trunk_w[l], pl.trunk_b[l], 256, 256, HKG, 8);
         }
     }
-    // m-tile 0 = sigma row (sigma_layer), m-tiles 1..8 = bottleneck_layer (FULL only)
-    append_layer(s, bf16, PackLayer{HKG, full ? 9 : 1, true,
-        [&](int row, int slot) {
-            if (row == 0) return pl.at(pl.sig_w, 0, slot);
-            if (row >= 32) return pl.at(pl.bot_w, row - 32, slot);
-            return -1;
-        },
-        [&](int row) { return row == 0 ? pl.at(pl.sig_b, 0, 0) : (row >= 32 ? pl.at(pl.bot_b, 0, row - 32) : -1); }});
-    if (!full) return s;
-    dense(pl.a1_w, pl.a1_b, 128, 256, HKG, 4);
+    if (!full) {      // one m-tile: the sigma row (sigma_layer)
+        append_layer(s, bf16, PackLayer{HKG, 1, true,
+            [&](int row, int slot) { return row == 0 ? pl.at(pl.sig_w, 0, slot) : -1; },
+            [&](int row) { return row == 0 ? pl.at(pl.sig_b, 0, 0) : -1; }});
+        return s;
+    }
+    // m-tiles 0..3 = the albedo head's first layer FOLDED with the bottleneck layer (eonerf_pack.h: the kernels never evaluate the
+    // bottleneck itself), m-tile 4 = sigma row.  (The sigma tile comes LAST: it saves nothing, and the counted wait of a chunk barrier
+    // -- run_layer / WStream::advance -- relies on a slab flush from a layer's third m-tile on.)
+    append_layer(s, bf16, PackLayer{HKG, 5, true,
+        [&](int row, int slot) { return row < 128 ? pl.fold_w(row, slot) : (row == 128 ? pl.at(pl.sig_w, 0, slot) : -1); },
+        [&](int row) { return row < 128 ? pl.fold_b(row) : (row == 128 ? pl.at(pl.sig_b, 0, 0) : -1); }});
     dense(pl.a2_w, pl.a2_b, 3, 128, QKG, 1);
-    dense(pl.t_w[0], pl.t_b[0], 128, 260, HKG + 1, 4);          // slots 256..259 = embedding columns
+    // transient head's first layer on [X_8 (folded with the bottleneck), emb(img)]: slots 256..259 = embedding columns
+    append_layer(s, bf16, PackLayer{HKG + 1, 4, true,
+        [&](int row, int slot) { return slot < 256 ? pl.fold_w(128 + row, slot) : (slot < 260 ? pl.at(pl.t_w[0], row, slot) : -1); },
+        [&](int row) { return pl.fold_b(128 + row); }});
     for (int l = 1; l < 4; ++l) dense(pl.t_w[l], pl.t_b[l], 128, 128, QKG, 4);
     append_layer(s, bf16, PackLayer{QKG, 1, true,
         [&](int row, int slot) { return row == 0 ? pl.at(pl.tsc_w, 0, slot) : (row == 1 ? pl.at(pl.tbe_w, 0, slot) : -1); },
@@ -146,26 +151,15 @@ PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool 
         }
         // d albedo_pre (slots 0..2) -> A1 (128)
         transposed(pl.a2_w, 3, 128, 1, 4);
-        if (heads == 2) {
-            // dY_T1 (slots 0..127) -> d embedding: rows 0..3 = the embedding columns 256..259 of the transient head's first layer
-            if (transient)
-                append_layer(s, bf16, PackLayer{QKG, 1, false,
-                    [&](int row, int slot) { return (row < 4 && slot < 128) ? pl.at(pl.t_w[0], slot, 256 + row) : -1; }, nullptr});
-            return s;
-        }
-        if (transient) {
-            // [dY_A1 (slots 0..127), dY_T1 (slots 128..255)] -> bottleneck rows 0..255, embedding rows 256..259
-            append_layer(s, bf16, PackLayer{2 * QKG, 9, false,
-                [&](int row, int slot) {
-                    if (slot < 128) return row < 256 ? pl.at(pl.a1_w, slot, row) : -1;
-                    return row < 260 ? pl.at(pl.t_w[0], slot - 128, row) : -1;
-                }, nullptr});
-        } else {
-            transposed(pl.a1_w, 128, 256, QKG, 8);      // dY_A1 -> d bottleneck
-        }
-        // [d bottleneck (slots 0..255), d sigma_pre (slot 256)] -> X8
-        append_layer(s, bf16, PackLayer{HKG + 1, 8, false,
-            [&](int row, int slot) { return slot < 256 ? pl.at(pl.bot_w, slot, row) : (slot == 256 ? pl.at(pl.sig_w, 0, row) : -1); }, nullptr});
+        // dY_T1 (slots 0..127) -> d embedding: rows 0..3 = the embedding columns 256..259 of the transient head's first layer
+        if (transient)
+            append_layer(s, bf16, PackLayer{QKG, 1, false,
+                [&](int row, int slot) { return (row < 4 && slot < 128) ? pl.at(pl.t_w[0], slot, 256 + row) : -1; }, nullptr});
+        // [dY_A1 (slots 0..127), dY_T1 (slots 128..255, with the transient head in the graph), d sigma_pre (next slot)] -> dX8, through the
+        // FOLDED first layers of the heads (eonerf_pack.h): d bottleneck is never formed
+        const int ns = transient ? 256 : 128;
+        append_layer(s, bf16, PackLayer{ns / KF + 1, 8, false,
+            [&, ns](int row, int slot) { return slot < ns ? pl.fold_w(slot, row) : (slot == ns ? pl.at(pl.sig_w, 0, row) : -1); }, nullptr});
     } else {
         append_layer(s, bf16, PackLayer{1, 8, false,
             [&](int row, int slot) { return slot == 0 ? pl.at(pl.sig_w, 0, row) : -1; }, nullptr});
@@ -206,35 +200,6 @@ PackedStream build_pipe_stream(const ParamLayout& pl) {
                 }
         s.bytes += 8 * 16 * 1024;
     }
-    s.chunks.push_back(ChunkDesc{0, (uint32_t)s.bytes});
-    return s;
-}
-
-// Heads launch of the pipelined backward (see eonerf_pack.h): A units of dX = W^T dY, lane (r,h) of m-tile mt: input feature 32 mt + r,
-// k elements = output features PBf16::feat(kg, h, e)
-PackedStream build_heads_pipe_stream(const ParamLayout& pl) {
-    PackedStream s;
-    for (int st = 0; st < 2; ++st) {
-        for (int mt = 0; mt < 8; ++mt)
-            for (int kg = 0; kg < 16; ++kg)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int r = lane & 31, h = lane >> 5;
-                    for (int e = 0; e < 8; ++e) {
-                        const int o = PBf16::feat(kg, h, e), i = 32 * mt + r;
-                        const int idx = st == 1 ? pl.at(pl.bot_w, o, i) : (o < 128 ? pl.at(pl.a1_w, o, i) : pl.at(pl.t_w[0], o - 128, i));
-                        s.e16.push_back(PackEntry{(uint32_t)(s.bytes + (size_t)(mt * 16 + kg) * 1024 + lane * 16 + e * 2), idx});
-                    }
-                }
-        s.bytes += 8 * 16 * 1024;
-    }
-    // 17th k-group of the "bott" stage: feature 256 = d sigma_pre -> only k element (h = 0, e = 0) carries a weight
-    for (int mt = 0; mt < 8; ++mt)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int r = lane & 31, h = lane >> 5;
-            for (int e = 0; e < 8; ++e)
-                s.e16.push_back(PackEntry{(uint32_t)(s.bytes + (size_t)mt * 1024 + lane * 16 + e * 2), (h == 0 && e == 0) ? pl.at(pl.sig_w, 0, 32 * mt + r) : -1});
-        }
-    s.bytes += 8 * 1024;
     s.chunks.push_back(ChunkDesc{0, (uint32_t)s.bytes});
     return s;
 }

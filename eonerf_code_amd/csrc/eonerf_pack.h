@@ -22,7 +22,19 @@ struct ParamLayout {
     int t_w[4], t_b[4], tsc_w, tsc_b, tbe_w, tbe_b, am1_w, am1_b, am2_w, am2_b;
     void build(int n_images);
     int at(int ti, int r, int c) const { return (int)(t[ti].offset + (size_t)r * t[ti].cols + c); }
+    // FOLDED head weights (see FOLD_FLOATS): gather sources beyond the flat parameter buffer -- index total + k = element k of the
+    // context's fold buffer.  Row o < 128: albedo head's first layer, o >= 128: transient head's first layer (its 256 bottleneck columns)
+    int fold_w(int o, int i) const { return (int)(total + (size_t)o * 256 + i); }
+    int fold_b(int o) const { return (int)(total + 256 * 256 + o); }
 };
+// The bottleneck layer has an IDENTITY activation (radiance_fields/eonerf.py:108-113: output_activation = nn.Identity), so the first
+// layers of the two heads that read it compose with it exactly:
+//     ReLU(W_A1 (W_b x + b_b) + b_A1) = ReLU((W_A1 W_b) x + (W_A1 b_b + b_A1))          (and W_T1[:, :256] likewise)
+// The chain kernels therefore never evaluate the bottleneck layer: they multiply X_8 by the folded 256 x 256 matrix [W_A1 W_b; W_T1' W_b]
+// (fp32 product of the fp32 master weights, re-computed by k_fold after every optimizer step, rounded ONCE to the stream's precision),
+// forward and backward -- 65,536 MACs per camera sample fewer in each direction.  The three layers' weight gradients follow from the
+// bottleneck factors M = [dA1; dT1]^T X_8 as before (BottWgradArgs).  Layout of the fold buffer: [256][256] W_f | [256] b_f.
+constexpr int FOLD_FLOATS = 256 * 256 + 256;
 
 struct PackEntry { uint32_t dst; int32_t src; };     // dst: byte offset into the stream
 
@@ -42,14 +54,9 @@ struct PackLayer {
 
 void append_layer(PackedStream& s, bool bf16, const PackLayer& L);
 PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full);
-// heads: 0 = the whole chain; 1 = the stream ends behind the [d bottleneck, d sigma_pre] -> dX8 layer (the chain kernel's PIPE 1 variant
-// leaves the trunk to eonerf_bwd_pipe.hip); 2 = only the narrow head layers and the embedding columns (PIPE 2: the two wide layers run in
-// the heads launch of the pipelined backward).  The stream is consumed cyclically, so it must hold exactly the layers one tile walks.
+// heads: 0 = the whole chain; 1 = the stream ends behind the [dY_A1, dY_T1, d sigma_pre] -> dX8 layer (the chain kernel's PIPE 1 variant
+// leaves the trunk to eonerf_bwd_pipe.hip).  The stream is consumed cyclically, so it must hold exactly the layers one tile walks.
 PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient = true, int heads = 0);
 PackedStream build_pipe_stream(const ParamLayout& pl);      // stage-stationary W_l^T of trunk layers 7..1 (eonerf_bwd_pipe.hip), bf16
-// heads launch of the pipelined backward: stage 0 [W_A1; W_T1 (bottleneck columns)]^T, stage 1 W_bott^T, then the sigma row as the A
-// units of a 17th k-group ([m-tile 8][lane][16 B], offset HEADS_WSIG_OFF)
-PackedStream build_heads_pipe_stream(const ParamLayout& pl);
-constexpr size_t HEADS_WSIG_OFF = (size_t)2 * 8 * 16 * 1024;
 PackedStream build_ig_tail_stream(const ParamLayout& pl);   // W_0^T and the skip columns of W_5^T as A units (eonerf_ig_tail.hip), bf16
 int enc_col_of_slot(bool bf16, int slot);      // reference encoding column (mlp.py:190-208) of an encoding slot, -1 = pad

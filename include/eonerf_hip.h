@@ -201,13 +201,13 @@ int eonerf_adam_step_zero_grad(eonerf_ctx* ctx, float* flat_params, float* d_fla
 
 /* Measurement hooks (no reference counterpart): with profiling enabled every launch of the MFMA kernels is bracketed by hipEvents on
  * the caller's stream, ONE scope per kernel launch (so a scope's time is that kernel's time).  In bf16 mode the backward of a pass is
- * heads chain -> [heads pipeline] -> trunk pipeline -> [input-gradient tail], then one weight-gradient GEMM for the jobs the pipelines
- * leave; in fp32 mode (or EONERF_PIPE=0) the two chain scopes cover the whole dX chain and the GEMM every weight gradient.
+ * heads chain -> trunk pipeline -> [input-gradient tail], then one weight-gradient GEMM for the jobs the pipeline
+ * leaves; in fp32 mode (or EONERF_PIPE=0) the two chain scopes cover the whole dX chain and the GEMM every weight gradient.
  * eonerf_profile_read synchronises on the recorded events and returns the summed duration and launch count;
  * eonerf_profile_name gives the scope's name (NULL beyond the last). */
 enum { EONERF_PROF_FWD_CHAIN_CAMERA = 0, EONERF_PROF_BWD_CHAIN_CAMERA = 1, EONERF_PROF_WGRAD = 2, EONERF_PROF_FWD_CHAIN_SUN = 3,
        EONERF_PROF_BWD_CHAIN_SUN = 4, EONERF_PROF_BWD_PIPE_CAMERA = 5, EONERF_PROF_BWD_PIPE_SUN = 6, EONERF_PROF_IG_TAIL_SUN = 7,
-       EONERF_PROF_HEADS_PIPE_CAMERA = 8, EONERF_PROF_KERNELS = 9 };
+       EONERF_PROF_KERNELS = 8 };
 int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches_per_kernel);
 int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launches);
 const char* eonerf_profile_name(int kernel);

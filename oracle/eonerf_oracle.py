@@ -108,15 +108,39 @@ class Field:
         """radiance_fields/eonerf.py:154-170."""
         h = self.trunk(x)
         sigma = F.softplus(self._lin(h, "sigma_layer.output_layer"))
+        emb = self.sd["transient_encoder.weight"][img_indices.reshape(-1)]
+        ambient = self.ambient(sun_dirs)
+        if self.bf16:
+            return (sigma,) + self._heads_bf16_model(h, emb, ambient)
         bott = self._lin(h, "bottleneck_layer.output_layer")
         a = self._mlp(bott, "albedo_mlp", 1, None)
         albedo = torch.sigmoid(self._lin(a, "albedo_mlp.output_layer"))
-        ambient = self.ambient(sun_dirs)
-        emb = self.sd["transient_encoder.weight"][img_indices.reshape(-1)]
         t = self._mlp(torch.cat([bott, emb], dim=-1), "transient_mlp", 4, None)
         ts = torch.sigmoid(self._lin(t, "transient_scalar.output_layer"))
         tb = F.softplus(self._lin(t, "transient_beta.output_layer"))
         return sigma, albedo, ambient, ts, tb
+
+
+def _heads_bf16_model(self, h, emb, ambient):
+    """Arithmetic model of the HIP bf16 kernels behind the trunk (NOT a reference function: the fp32 path above is the reference's
+    graph, radiance_fields/eonerf.py:157-168).  The bottleneck layer has an identity activation (eonerf.py:108-113), so the kernels
+    compose it with the two head layers that read it -- W_f = W_head W_bott and b_f = W_head b_bott + b_head, formed in fp32 from the
+    fp32 master weights -- and round the product ONCE to bf16 (csrc/eonerf_pack.h); the bottleneck output itself is never formed."""
+    sd = self.sd
+    Wb, bb = sd["bottleneck_layer.output_layer.weight"], sd["bottleneck_layer.output_layer.bias"]
+    Wa, ba = sd["albedo_mlp.hidden_layers.0.weight"], sd["albedo_mlp.hidden_layers.0.bias"]
+    Wt, bt = sd["transient_mlp.hidden_layers.0.weight"], sd["transient_mlp.hidden_layers.0.bias"]
+    a = torch.relu(_bf16(h) @ _bf16(Wa @ Wb).t() + (Wa @ bb + ba))
+    albedo = torch.sigmoid(self._lin(a, "albedo_mlp.output_layer"))
+    t = torch.relu(_bf16(h) @ _bf16(Wt[:, :256] @ Wb).t() + _bf16(emb) @ _bf16(Wt[:, 256:]).t() + (Wt[:, :256] @ bb + bt))
+    for i in range(1, 4):
+        t = torch.relu(self._lin(t, f"transient_mlp.hidden_layers.{i}"))
+    ts = torch.sigmoid(self._lin(t, "transient_scalar.output_layer"))
+    tb = F.softplus(self._lin(t, "transient_beta.output_layer"))
+    return albedo, ambient, ts, tb
+
+
+Field._heads_bf16_model = _heads_bf16_model
 
 
 # --------------------------------------------------------------------------- sampler

@@ -22,7 +22,8 @@ static void check_stream(const char* name, const PackedStream& s, const ParamLay
     auto walk = [&](const std::vector<PackEntry>& e, int esz) {
         for (const PackEntry& pe : e) {
             CHECK((size_t)pe.dst + esz <= s.bytes, "%s: destination %u beyond the stream (%zu bytes)", name, pe.dst, s.bytes);
-            CHECK(pe.src >= -1 && (pe.src < 0 || (size_t)pe.src < pl.total), "%s: source %d outside the flat buffer (%zu floats)", name, pe.src, pl.total);
+            // sources beyond the flat buffer index the fold buffer (ParamLayout::fold_w / fold_b, eonerf_pack.h)
+            CHECK(pe.src >= -1 && (pe.src < 0 || (size_t)pe.src < pl.total + FOLD_FLOATS), "%s: source %d outside the flat + fold buffers (%zu + %d floats)", name, pe.src, pl.total, FOLD_FLOATS);
             CHECK(pe.dst % esz == 0, "%s: misaligned destination %u", name, pe.dst);
             if ((size_t)pe.dst + esz <= s.bytes)
                 for (int k = 0; k < esz; ++k) { CHECK(!hit[pe.dst + k], "%s: byte %u written twice", name, pe.dst + k); hit[pe.dst + k] = 1; }
@@ -65,17 +66,33 @@ static void check_layout(int n_img) {
         check_stream(("bwd rgb " + tag).c_str(), build_bwd_stream(pl, bf16, true, false, false), pl, true);
         check_stream(("bwd dens " + tag).c_str(), build_bwd_stream(pl, bf16, false, true), pl, true);
     }
-    for (int heads = 1; heads <= 2; ++heads) {
-        check_stream("bwd full heads", build_bwd_stream(pl, true, true, false, true, heads), pl, true);
-        check_stream("bwd rgb heads", build_bwd_stream(pl, true, true, false, false, heads), pl, true);
+    check_stream("bwd full heads", build_bwd_stream(pl, true, true, false, true, 1), pl, true);
+    check_stream("bwd rgb heads", build_bwd_stream(pl, true, true, false, false, 1), pl, true);
+    {   // the fold: every element of the folded matrix and bias is a source of the full forward stream exactly once, and of the backward
+        // streams (transient head in the graph) exactly once; the bottleneck layer's own weights are a source of NO chain stream
+        const PackedStream ff = build_fwd_stream(pl, true, true), bf = build_bwd_stream(pl, true, true, false, true, 1), br = build_bwd_stream(pl, true, true, false, false, 1);
+        std::vector<int> nf(FOLD_FLOATS, 0), nb(FOLD_FLOATS, 0), nr(FOLD_FLOATS, 0);
+        const size_t bot_lo = pl.t[pl.bot_w].offset, bot_hi = pl.t[pl.bot_b].offset + 256;
+        auto count = [&](const PackedStream& st, std::vector<int>& n) {
+            for (const std::vector<PackEntry>* e : {&st.e16, &st.e32})
+                for (const PackEntry& pe : *e) {
+                    if (pe.src >= (int)pl.total) n[pe.src - pl.total]++;
+                    CHECK(pe.src < 0 || (size_t)pe.src < bot_lo || (size_t)pe.src >= bot_hi, "bottleneck weight %d is a source of a chain stream", pe.src);
+                }
+        };
+        count(ff, nf); count(bf, nb); count(br, nr);
+        for (int k = 0; k < FOLD_FLOATS; ++k) {
+            const bool bias = k >= 256 * 256, albedo = bias ? k - 256 * 256 < 128 : k < 128 * 256;
+            CHECK(nf[k] == 1, "fold element %d: %d sources in the forward stream", k, nf[k]);
+            CHECK(nb[k] == (bias ? 0 : 1), "fold element %d: %d sources in the backward stream", k, nb[k]);
+            CHECK(nr[k] == ((bias || !albedo) ? 0 : 1), "fold element %d: %d sources in the rgb backward stream", k, nr[k]);
+        }
     }
     check_stream("bwd dens heads", build_bwd_stream(pl, true, false, true, false, 1), pl, true);
-    const PackedStream pw = build_pipe_stream(pl), hw = build_heads_pipe_stream(pl), iw = build_ig_tail_stream(pl);
+    const PackedStream pw = build_pipe_stream(pl), iw = build_ig_tail_stream(pl);
     check_stream("pipe W^T", pw, pl, false);
-    check_stream("heads pipe W^T", hw, pl, false);
     check_stream("ig tail W^T", iw, pl, false);
     CHECK(pw.bytes == (size_t)PIPE_STAGES * 8 * 16 * 1024, "pipe stream size");
-    CHECK(hw.bytes == HEADS_WSIG_OFF + 8 * 1024, "heads pipe stream size");
     for (int s = 0; s < 64; ++s) {
         const int c16 = enc_col_of_slot(true, s), c32 = enc_col_of_slot(false, s);
         CHECK(c16 >= -1 && c16 < 63 && c32 >= -1 && c32 < 63, "encoding slot %d -> %d / %d", s, c16, c32);
@@ -95,7 +112,7 @@ static void add_pass(std::vector<Span>& v, const PassBuffers& b, int n_rays, siz
     add(v, "grd", b.grd, (size_t)(full ? GRD_ROWS_FULL : GRD_ROWS_DENSITY) * p_cap * ab, base);
     add(v, "masks", b.masks, (size_t)(full ? MASK_SLOTS_FULL : MASK_SLOTS_DENSITY) * p_cap * 32, base);
     add(v, "g_sigma", b.g_sigma, 4 * p_cap, base); add(v, "g_albedo", b.g_albedo, 12 * p_cap, base); add(v, "g_ts", b.g_ts, 4 * p_cap, base);
-    add(v, "g_tb", b.g_tb, 4 * p_cap, base); add(v, "g_emb", b.g_emb, 16 * p_cap, base); add(v, "g_pos", b.g_pos, 12 * p_cap, base); add(v, "dsig", b.dsig, 4 * p_cap, base);
+    add(v, "g_tb", b.g_tb, 4 * p_cap, base); add(v, "g_emb", b.g_emb, 16 * p_cap, base); add(v, "g_pos", b.g_pos, 12 * p_cap, base);
 }
 
 static void check_carve(const CarveCfg& cfg, int n_rays, int flags) {
@@ -114,16 +131,16 @@ static void check_carve(const CarveCfg& cfg, int n_rays, int flags) {
     add(v, "m_bott+queue", w.m_bott, 4 * (BOTT_SCRATCH_F + 64), base);
     if (w.pipe.sync) {
         add(v, "sync", w.pipe.sync, PIPE_LAUNCHES * w.pipe.sync_bytes, base);
-        add(v, "dy_in", w.pipe.dy_in, p_cap * 512, base); add(v, "dy_heads", w.pipe.dy_heads, p_cap * 512, base);
-        const size_t edges = std::max((size_t)cfg.n_pipes * (PIPE_STAGES - 1), (size_t)cfg.n_pipes_heads * (HEADS_STAGES - 1));
+        add(v, "dy_in", w.pipe.dy_in, p_cap * 512, base);
+        const size_t edges = (size_t)cfg.n_pipes * (PIPE_STAGES - 1);
         add(v, "rings", w.pipe.rings, edges * PIPE_RING * PIPE_UNIT_B, base);
         // the ONE memset of a backward call runs from m_bott to the end of the sync blocks: they must be adjacent
         CHECK(reinterpret_cast<uint8_t*>(w.pipe.sync) >= reinterpret_cast<uint8_t*>(w.m_bott) + 4 * (BOTT_SCRATCH_F + 64) &&
               reinterpret_cast<uint8_t*>(w.pipe.sync) - (reinterpret_cast<uint8_t*>(w.m_bott) + 4 * (BOTT_SCRATCH_F + 64)) < 256, "sync block not behind the GEMM queue");
-        const size_t wgs = std::max((size_t)cfg.n_pipes * PIPE_STAGES, (size_t)cfg.n_pipes_heads * HEADS_STAGES);
+        const size_t wgs = (size_t)cfg.n_pipes * PIPE_STAGES;
         CHECK(w.pipe.sync_bytes >= (64 + wgs * 32 + edges * 64) * 4, "sync block too small");
     }
-    add(v, "pipe_part", w.det.pipe_part, std::max((size_t)cfg.n_pipes * PIPE_STAGES, (size_t)cfg.n_pipes_heads * HEADS_STAGES) * WGRAD_PART_F * 4, base);
+    add(v, "pipe_part", w.det.pipe_part, (size_t)cfg.n_pipes * PIPE_STAGES * WGRAD_PART_F * 4, base);
     add(v, "wgrad_part", w.det.wgrad_part, (size_t)WGRAD_MAX_JOBS * 48 * WGRAD_PART_F * 4, base);
     add(v, "rad_rays", w.det.rad_rays, 24 * (size_t)n_rays, base); add(v, "emb_rays", w.det.emb_rays, 16 * (size_t)n_rays, base);
     add_pass(v, w.cam, n_rays, p_cap, !od, ab, base);
@@ -143,10 +160,10 @@ int main() {
     for (int n_img : {1, 19, 20, 2048}) check_layout(n_img);
     CarveCfg cfgs[5];
     cfgs[0].bf16 = false;
-    cfgs[1].pipe = true; cfgs[1].n_pipes = 36; cfgs[1].n_pipes_heads = 128;
-    cfgs[2] = cfgs[1]; cfgs[2].heads_pipe = true;
-    cfgs[3] = cfgs[2]; cfgs[3].deterministic = cfgs[3].pipe_partials = true;
-    cfgs[4] = cfgs[1]; cfgs[4].n_pipes = 1; cfgs[4].n_pipes_heads = 1;
+    cfgs[1].pipe = true; cfgs[1].n_pipes = 36;
+    cfgs[2] = cfgs[1]; cfgs[2].pipe_partials = true;
+    cfgs[3] = cfgs[1]; cfgs[3].deterministic = cfgs[3].pipe_partials = true;
+    cfgs[4] = cfgs[1]; cfgs[4].n_pipes = 1;
     const int flag_sets[] = {0, EONERF_F_SHADOWS, EONERF_F_ONLY_DEPTH, EONERF_F_TRAIN | EONERF_F_RGB_LOSS, EONERF_F_TRAIN | EONERF_F_SHADOWS,
                              EONERF_F_SHADOWS | EONERF_F_EVAL, EONERF_F_TRAIN | EONERF_F_SHADOWS | EONERF_F_EVAL};
     for (const CarveCfg& c : cfgs)
