@@ -22,7 +22,7 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering", "eonerf_generate_rays",
            "eonerf_field_train_workspace_bytes", "eonerf_field_forward_train",
            "eonerf_field_backward", "eonerf_set_noise_seed", "eonerf_render_status", "eonerf_device_status", "eonerf_grad_floats",
-           "eonerf_grad_seal", "eonerf_profile_name", "eonerf_adam_step_zero_grad"]
+           "eonerf_grad_seal", "eonerf_profile_name", "eonerf_adam_step_zero_grad", "eonerf_rendering_train", "eonerf_rendering_backward"]
 
 
 class EonerfRpc(C.Structure):
@@ -100,6 +100,8 @@ def lib():
     L.eonerf_sample_rays.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_set_noise_seed.argtypes = [vp, C.c_uint64]
     L.eonerf_rendering.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.eonerf_rendering_train.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.eonerf_rendering_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_profile_enable.argtypes = [vp, i]
     L.eonerf_profile_read.argtypes = [vp, i, C.POINTER(fp), C.POINTER(i)]
     L.eonerf_profile_name.restype = C.c_char_p

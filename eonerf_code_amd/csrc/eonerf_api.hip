@@ -690,6 +690,67 @@ int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double
     return (int)eo_launch_raygen(a, (hipStream_t)stream);
 }
 
+// The camera pass backwards, from the gradient of the per-ray record (w.g_ray): compositing -> heads chain -> [pipelined trunk] -> weight
+// gradients (together with the sun pass' remaining jobs, if any) -> embedding table and, with `ambient`, the per-ray ambient head.
+// density_only: the pass was a density-only one (render_depth): its gradient flows through the sigma row alone.
+static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat, const float* rays, const int64_t* img_idx, int n_rays, int p_cap,
+                           float* d_flat, bool transient, bool ambient, bool first_pipe, const PassBuffers* sun, bool density_only, hipStream_t st) {
+    const ParamLayout& pl = ctx->pl;
+    const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
+    const int grid = std::min(ctx->n_cu, p_cap / tile);
+    auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
+    CompositeBwdArgs cb;
+    memset(&cb, 0, sizeof(cb));
+    cb.rays = rays; cb.p_pad = p_cap; cb.n_rays = n_rays; cb.ray_rec = w.ray_rec; cb.g_ray = w.g_ray;
+    cb.offsets = w.cam.offsets; cb.counts = w.cam.counts; cb.sigma = w.cam.sigma; cb.delta = w.cam.delta; cb.tmid = w.cam.tmid;
+    cb.albedo = w.cam.albedo; cb.ts = w.cam.ts; cb.tb = w.cam.tb;
+    cb.g_sigma = w.cam.g_sigma; cb.g_albedo = w.cam.g_albedo; cb.g_ts = w.cam.g_ts; cb.g_tb = w.cam.g_tb;
+    cb.depth_only = density_only ? 1 : 0;
+    HIP_TRY(eo_launch_cam_composite_bwd(cb, st));
+    MlpBwdArgs mc;
+    memset(&mc, 0, sizeof(mc));
+    mc.n_pts = w.cam.n_pts; mc.p_pad = p_cap;
+    const bool pipe = ctx->pipe && w.pipe.dy_in;
+    if (density_only) { const int rc = ensure_density_streams(ctx, flat, st); if (rc) return rc; }
+    const DevStream& bs = density_only ? (pipe ? ctx->bwd_dens_heads : ctx->bwd_dens)
+                        : pipe ? (transient ? ctx->bwd_full_heads : ctx->bwd_rgb_heads) : (transient ? ctx->bwd_full : ctx->bwd_rgb);
+    mc.stream = bs.data; mc.chunks = bs.chunks; mc.n_chunks = bs.n_chunks;
+    mc.sigma = w.cam.sigma; mc.albedo = w.cam.albedo; mc.ts = w.cam.ts; mc.tb = w.cam.tb;
+    mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
+    mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
+    mc.px = w.cam.px; mc.py = w.cam.py; mc.pz = w.cam.pz; mc.g_pos = w.cam.g_pos;      // (density variants only: the chain + GEMM path ends in d position)
+    mc.dy7_units = pipe ? w.pipe.dy_in : nullptr;
+    { ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_CAMERA, st);
+      HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, !density_only, density_only, transient && !density_only, grid, st, pipe ? 1 : 0)); }
+    if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, first_pipe); if (rcp) return rcp; }
+
+    {
+        const PassBuffers* full = density_only ? nullptr : &w.cam;
+        const PassBuffers* dens = density_only ? &w.cam : sun;
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, full, transient, dens, p_cap, w.m_bott, w.queue, st, pipe, pipe && dens, w.det.wgrad_part, pipe);
+        if (rcw) return rcw;
+    }
+    if (density_only) return EONERF_OK;
+
+    // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
+    if (transient) {
+        EmbGradArgs eg;
+        eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays; eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0;
+        eg.d_emb_rays = w.det.emb_rays;
+        HIP_TRY(eo_launch_emb_grad(eg, st));
+        if (eg.d_emb_rays) HIP_TRY(eo_launch_table_reduce(eg.d_emb_rays, img_idx, n_rays, 4, 4, ctx->cfg.n_images, 0, eg.d_emb, st));
+    }
+    if (!ambient) return EONERF_OK;      // s == 1: rgb = albedo, the ambient head is outside the graph (sat_rendering.py:269-276,294)
+    // (27 -> 128 -> 3, fp32, ~35 us on a few dozen workgroups.  Running it on a side stream beside the weight-gradient GEMM was tried
+    //  and bought nothing: every large kernel of the step holds the whole register file of its CUs -- 8 waves x 256 registers -- so
+    //  the small kernel's workgroups only start when the large one's leave)
+    AmbientBwdArgs ag;
+    ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
+    ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
+    HIP_TRY(eo_launch_ambient_bwd(ag, st, ctx->deterministic));
+    return EONERF_OK;
+}
+
 int eonerf_set_noise_seed(eonerf_ctx* ctx, uint64_t seed) {
     if (!ctx) return EONERF_E_ARG;
     ctx->noise_seed = seed; ctx->noise_call = 0;
@@ -748,6 +809,60 @@ int eonerf_rendering(eonerf_ctx* ctx, const float* flat, const float* rays, cons
     HIP_TRY(eo_launch_composite_fwd(ca, st));
     RenderingOutArgs ro{w.ray_rec, n_rays, depth_only ? nullptr : albedo, depth, beta, transient_s, ambient, entropy};
     return (int)eo_launch_rendering_out(ro, st);
+}
+
+// EONerfMLP.rendering / render_depth under autograd (radiance_fields/eonerf.py:172-248): the same kernels with the training-mode
+// forward chain (activations, masks and the compositing inputs stay in the workspace for eonerf_rendering_backward)
+int eonerf_rendering_train(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
+                           const float* t_starts, const float* t_ends, const int64_t* ray_indices, int n, int n_rays, int depth_only,
+                           float* albedo, float* depth, float* beta, float* transient_s, float* ambient, float* entropy,
+                           void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx || !flat || !rays || !depth || n < 0 || n_rays < 1 || !ws) return EONERF_E_ARG;
+    if (n > 0 && (!t_starts || !t_ends || !ray_indices)) return EONERF_E_ARG;
+    if (!depth_only && (!albedo || !beta || !transient_s || !ambient || !entropy || !img_idx)) return EONERF_E_ARG;
+    if (!ctx->weights_set) return EONERF_E_STATE;
+    if (n > n_rays * 127) return EONERF_E_UNSUPPORTED;           // at most 127 intervals per ray (n_samples = 128)
+    if (n_rays > (1 << 24) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays))) return EONERF_E_UNSUPPORTED;
+    const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
+    RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    const int p_cap = p_cap_of(n_rays);
+    PackedArgs pa;
+    pa.rays = rays; pa.img_idx = img_idx; pa.t_starts = t_starts; pa.t_ends = t_ends; pa.ray_indices = ray_indices;
+    pa.n = n; pa.n_rays = n_rays; pa.counts = w.cam.counts; pa.offsets = w.cam.offsets; pa.n_pts = w.cam.n_pts;
+    pa.px = w.cam.px; pa.py = w.cam.py; pa.pz = w.cam.pz; pa.tmid = w.cam.tmid; pa.delta = w.cam.delta; pa.simg = w.cam.simg;
+    HIP_TRY(eo_launch_from_packed(pa, st));
+    int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !depth_only, 1, st, -1, true);
+    if (rc) return rc;
+    CompositeArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.rays = rays; ca.offsets = w.cam.offsets; ca.counts = w.cam.counts;
+    ca.sigma = w.cam.sigma; ca.delta = w.cam.delta; ca.tmid = w.cam.tmid; ca.albedo = w.cam.albedo; ca.ts = w.cam.ts; ca.tb = w.cam.tb;
+    ca.p_pad = p_cap; ca.n_rays = n_rays; ca.depth_only = depth_only ? 1 : 0; ca.amb = ambient_w(ctx, flat); ca.ray_out = w.ray_rec;
+    ca.amb_save = depth_only ? nullptr : w.amb_save;
+    HIP_TRY(eo_launch_composite_fwd(ca, st));
+    RenderingOutArgs ro{w.ray_rec, n_rays, depth_only ? nullptr : albedo, depth, beta, transient_s, ambient, entropy};
+    return (int)eo_launch_rendering_out(ro, st);
+}
+
+// gradients of the per-ray outputs (row-major as autograd hands them over; null = zero) -> ACCUMULATED parameter gradients.  `ws` must be
+// the workspace an eonerf_rendering_train call with the same (rays, img_idx, n_rays, depth_only) filled.
+int eonerf_rendering_backward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx, int n_rays, int depth_only,
+                              const float* g_albedo, const float* g_depth, const float* g_beta, const float* g_transient_s, const float* g_ambient,
+                              float* d_flat, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx || !flat || !rays || !d_flat || n_rays < 1 || !ws) return EONERF_E_ARG;
+    if (!depth_only && !img_idx) return EONERF_E_ARG;
+    if (!ctx->weights_set) return EONERF_E_STATE;
+    const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
+    RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    const int p_cap = p_cap_of(n_rays);
+    RenderingOutBwdArgs rb{w.ray_rec, n_rays, depth_only ? nullptr : g_albedo, g_depth, depth_only ? nullptr : g_beta,
+                           depth_only ? nullptr : g_transient_s, depth_only ? nullptr : g_ambient, w.g_ray};
+    HIP_TRY(eo_launch_rendering_out_bwd(rb, st));
+    return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, true, !depth_only, true, nullptr, depth_only != 0, st);
 }
 
 int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
@@ -880,47 +995,8 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         HIP_TRY(eo_launch_sun_depth_grad(cs, st));
     }
 
-    // ---- camera pass backwards -----------------------------------------------------------------------------
-    cb.offsets = w.cam.offsets; cb.counts = w.cam.counts; cb.sigma = w.cam.sigma; cb.delta = w.cam.delta; cb.tmid = w.cam.tmid;
-    cb.albedo = w.cam.albedo; cb.ts = w.cam.ts; cb.tb = w.cam.tb;
-    cb.g_sigma = w.cam.g_sigma; cb.g_albedo = w.cam.g_albedo; cb.g_ts = w.cam.g_ts; cb.g_tb = w.cam.g_tb;
-    HIP_TRY(eo_launch_cam_composite_bwd(cb, st));
-    MlpBwdArgs mc;
-    memset(&mc, 0, sizeof(mc));
-    mc.n_pts = w.cam.n_pts; mc.p_pad = p_cap;
-    const bool transient = shadows || !(flags & EONERF_F_RGB_LOSS);
-    const bool pipe = ctx->pipe && w.pipe.dy_in;
-    const DevStream& bs = pipe ? (transient ? ctx->bwd_full_heads : ctx->bwd_rgb_heads) : (transient ? ctx->bwd_full : ctx->bwd_rgb);
-    mc.stream = bs.data; mc.chunks = bs.chunks; mc.n_chunks = bs.n_chunks;
-    mc.sigma = w.cam.sigma; mc.albedo = w.cam.albedo; mc.ts = w.cam.ts; mc.tb = w.cam.tb;
-    mc.g_sigma = w.cam.g_sigma; mc.g_albedo = w.cam.g_albedo; mc.g_ts = w.cam.g_ts; mc.g_tb = w.cam.g_tb;
-    mc.masks = w.cam.masks; mc.grd = w.cam.grd; mc.g_emb = w.cam.g_emb;
-    mc.dy7_units = pipe ? w.pipe.dy_in : nullptr;
-    { ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_CAMERA, st); HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, true, false, transient, grid, st, pipe ? 1 : 0)); }
-    if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, !shadows); if (rcp) return rcp; }
-
-    {
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, shadows ? &w.sun : nullptr, p_cap, w.m_bott, w.queue, st, pipe, pipe && shadows, w.det.wgrad_part, pipe);
-        if (rcw) return rcw;
-    }
-
-    // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
-    if (transient) {
-        EmbGradArgs eg;
-        eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays; eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0;
-        eg.d_emb_rays = w.det.emb_rays;
-        HIP_TRY(eo_launch_emb_grad(eg, st));
-        if (eg.d_emb_rays) HIP_TRY(eo_launch_table_reduce(eg.d_emb_rays, img_idx, n_rays, 4, 4, ctx->cfg.n_images, 0, eg.d_emb, st));
-    }
-    if (!shadows) return EONERF_OK;      // s == 1: rgb = albedo, the ambient head is outside the graph (sat_rendering.py:269-276,294)
-    // (27 -> 128 -> 3, fp32, ~35 us on a few dozen workgroups.  Running it on a side stream beside the weight-gradient GEMM was tried
-    //  and bought nothing: every large kernel of the step holds the whole register file of its CUs -- 8 waves x 256 registers -- so
-    //  the small kernel's workgroups only start when the large one's leave)
-    AmbientBwdArgs ag;
-    ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
-    ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
-    HIP_TRY(eo_launch_ambient_bwd(ag, st, ctx->deterministic));
-    return EONERF_OK;
+    return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows, !shadows,
+                           shadows ? &w.sun : nullptr, false, st);
 }
 
 // diagnostics: copies the cycle sums of the last pipelined backward ([n_pipes * 7 roles][2 waves][8] u64) to the host; returns the

@@ -129,7 +129,8 @@ inline RenderWs carve_render(const CarveCfg& cfg, void* base, int n_rays, int fl
         w.det.rad_rays = c.take<float>((size_t)n_rays * 6);
         w.det.emb_rays = c.take<float>((size_t)n_rays * 4);
     }
-    carve_pass(c, w.cam, n_rays, p_cap, !od, train, false, ab);
+    // (a density-only training pass -- render_depth under autograd -- may end in the chain kernel's input-gradient variant: room for d position)
+    carve_pass(c, w.cam, n_rays, p_cap, !od, train, train && od, ab);
     if (shadows && !od) carve_pass(c, w.sun, n_rays, p_cap, false, train, true, ab); else memset(&w.sun, 0, sizeof(w.sun));
     w.bytes = c.off + 256;
     return w;

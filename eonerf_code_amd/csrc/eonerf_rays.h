@@ -72,6 +72,7 @@ struct CompositeBwdArgs {
     float* g_ray;
     float *g_sigma, *g_albedo, *g_ts, *g_tb;   // per-sample outputs
     const float* g_pos;                        // sun pass: [3][p_pad] d sigma / d position
+    int depth_only;                            // camera compositing of a density-only pass (render_depth): no head terms
 };
 
 struct AmbientBwdArgs {
@@ -115,6 +116,9 @@ struct PackedArgs {        // flattened samples handed in by the caller (EONerfM
     float *px, *py, *pz, *tmid, *delta; int* simg;
 };
 struct RenderingOutArgs { const float* ray_rec; int n_rays; float *albedo, *depth, *beta, *ts, *ambient, *entropy; };
+// gradients of EONerfMLP.rendering's per-ray outputs (any may be null = zero) -> gradient of the ray record
+struct RenderingOutBwdArgs { const float* ray_rec; int n_rays; const float *g_albedo, *g_depth, *g_beta, *g_ts, *g_ambient; float* g_ray; };
+hipError_t eo_launch_rendering_out_bwd(const RenderingOutBwdArgs& a, hipStream_t st);
 
 hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st);
 hipError_t eo_launch_from_packed(const PackedArgs& a, hipStream_t st);

@@ -117,6 +117,11 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
         if (i < n) {
             const int p = off + i;
             const float w = rw.w[k];
+            if (a.depth_only) {      // render_depth (radiance_fields/eonerf.py:172-194): depth is the only output
+                gw[k] = g_depth * a.tmid[p];
+                gw_w[k] = gw[k] * w;
+                continue;
+            }
             const float alb0 = a.albedo[p], alb1 = a.albedo[(size_t)a.p_pad + p], alb2 = a.albedo[2 * (size_t)a.p_pad + p];
             gw[k] = g_depth * a.tmid[p] + g_alb[0] * alb0 + g_alb[1] * alb1 + g_alb[2] * alb2 + g_ts * a.ts[p] + g_tb * a.tb[p] + g_wsum;
             gw_w[k] = gw[k] * w;
@@ -142,6 +147,29 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
             a.g_sigma[p] = a.delta[p] * (gw[k] * rw.T[k] * e - after[k]);
         }
     }
+}
+
+// ---- EONerfMLP.rendering's outputs backwards (radiance_fields/eonerf.py:229-247; forward: k_rendering_out):
+//      ambient_rgb = wsum * head,  beta = sum w tb + beta_min,  entropy = ones (no gradient) ----
+__global__ void k_rendering_out_bwd(RenderingOutBwdArgs a) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= a.n_rays) return;
+    const float* r = a.ray_rec + (size_t)ray * RAY_REC;
+    float* g = a.g_ray + (size_t)ray * RAY_REC;
+    float g_wsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float ga = a.g_ambient ? a.g_ambient[3 * (size_t)ray + c] : 0.f;
+        g[RR_ALB + c] = a.g_albedo ? a.g_albedo[3 * (size_t)ray + c] : 0.f;
+        g[RR_AMB + c] = ga * r[RR_WSUM];
+        g_wsum += ga * r[RR_AMB + c];
+    }
+    g[RR_DEPTH] = a.g_depth ? a.g_depth[ray] : 0.f;
+    g[RR_TS] = a.g_ts ? a.g_ts[ray] : 0.f;
+    g[RR_TB] = a.g_beta ? a.g_beta[ray] : 0.f;
+    g[RR_WSUM] = g_wsum;
+    g[RR_GEO] = 0.f;
+    g[RR_GEO + 1] = 0.f;
 }
 
 // ---- ambient head backward (radiance_fields/eonerf.py:132-139): thread = (hidden unit j, ray stream q).  A block owns a contiguous
@@ -488,6 +516,10 @@ __global__ void k_grad_seal(float* tail, const int* status) {
 
 hipError_t eo_launch_shade_bwd(const ShadeBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_shade_bwd, dim3((a.n_rays + 255) / 256), dim3(256), (size_t)a.lds_images * 6 * sizeof(float), st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_rendering_out_bwd(const RenderingOutBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_rendering_out_bwd, dim3((a.n_rays + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {

@@ -66,6 +66,59 @@ class _FieldFn(torch.autograd.Function):
         return (None, None, d_x, None, None) + tuple(field.grad_views(d_flat))
 
 
+class _RenderingFn(torch.autograd.Function):
+    """EONerfMLP.rendering / render_depth on caller-provided samples as ONE differentiable op (the reference's methods are ordinary
+    autograd code: gather, field forward, nerfacc compositing -- radiance_fields/eonerf.py:172-248): forward = eonerf_rendering_train
+    (training-mode chain kernel + per-ray compositing; everything the backward needs stays in the op's workspace), backward =
+    eonerf_rendering_backward (compositing backward, heads chain, pipelined trunk, weight-gradient GEMM, embedding / ambient head).
+    Gradients flow to the parameters; t_starts / t_ends come from samplers that run under no_grad in the reference and carry none."""
+
+    @staticmethod
+    def forward(ctx, field, depth_only, table, img, ts_, te_, ri, n_rays, *params):
+        L = _lib.lib()
+        flat = field._ensure_packed()
+        dev, n = table.device, ts_.shape[0]
+        flags = _lib.F_TRAIN | (_lib.F_ONLY_DEPTH if depth_only else 0)
+        nb = L.eonerf_render_workspace_bytes(field._ctx, n_rays, flags)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)        # lives until backward
+        depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+        if depth_only:
+            albedo = beta = tsc = ambient = entropy = None
+        else:
+            albedo, ambient = (torch.empty(n_rays, 3, dtype=torch.float32, device=dev) for _ in range(2))
+            beta, tsc, entropy = (torch.empty(n_rays, 1, dtype=torch.float32, device=dev) for _ in range(3))
+        _lib.check(L.eonerf_rendering_train(field._ctx, _ptr(flat), _ptr(table), _ptr(img), _ptr(ts_), _ptr(te_), _ptr(ri), n, n_rays,
+                                            1 if depth_only else 0, _ptr(albedo), _ptr(depth), _ptr(beta), _ptr(tsc), _ptr(ambient),
+                                            _ptr(entropy), _ptr(ws), ws.numel(), _stream()))
+        ctx.field, ctx.depth_only, ctx.ws, ctx.n_rays = field, depth_only, ws, n_rays
+        ctx.save_for_backward(table, img)
+        if depth_only:
+            return depth
+        ctx.mark_non_differentiable(entropy)
+        return albedo, depth, beta, tsc, ambient, entropy
+
+    @staticmethod
+    def backward(ctx, *g):
+        field, ws = ctx.field, ctx.ws
+        if ws is None:
+            raise RuntimeError("EONerfMLP.rendering: backward through the same call twice (the op's workspace is released after the first)")
+        table, img = ctx.saved_tensors
+        L = _lib.lib()
+        flat = field.flat_params()
+        d_flat = torch.zeros_like(flat)
+        gs = [None if t is None else t.contiguous().float() for t in g]
+        if ctx.depth_only:
+            g_alb = g_beta = g_ts = g_amb = None
+            g_depth = gs[0]
+        else:
+            g_alb, g_depth, g_beta, g_ts, g_amb = gs[:5]
+        _lib.check(L.eonerf_rendering_backward(field._ctx, _ptr(flat), _ptr(table), _ptr(img), ctx.n_rays, 1 if ctx.depth_only else 0,
+                                               _ptr(g_alb), _ptr(g_depth), _ptr(g_beta), _ptr(g_ts), _ptr(g_amb),
+                                               _ptr(d_flat), _ptr(ws), ws.numel(), _stream()))
+        ctx.ws = None
+        return (None,) * 8 + tuple(field.grad_views(d_flat))
+
+
 class EONerfMLP(nn.Module):
     def __init__(self, n_input_images: int, net_depth: int = 8, net_width: int = 256, skip_layer: int = 4,
                  radiometric_normalization: bool = False, precision: str = None, eval_precision: str = None):
@@ -272,13 +325,28 @@ class EONerfMLP(nn.Module):
         return sigma.view(n, 1), albedo, ambient, ts.view(n, 1), tb.view(n, 1)
 
     def _rendering(self, chunk_rays, t_starts, t_ends, ray_indices, depth_only):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # the reference's rendering()/render_depth() build an autograd graph; this entry point cannot (the fused, differentiable
-            # path is sat_rendering.render_image).  Fail loudly rather than hand back graph-less tensors to a loss.
-            raise RuntimeError("EONerfMLP.rendering/render_depth on caller-provided samples is an inference entry point: call it under "
-                               "torch.no_grad(), or differentiate through sat_rendering.render_image (same result, fused autograd)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and t_starts.shape[0] > 0:
+            # the reference's rendering() / render_depth() build an autograd graph (radiance_fields/eonerf.py:172-248): one differentiable op
+            from ..datasets.satellite import satrays_to_table
+            self._ensure_packed()
+            table, img = satrays_to_table(chunk_rays)
+            ts_, te_ = t_starts.detach().float().contiguous(), t_ends.detach().float().contiguous()
+            ri = ray_indices.to(torch.int64).contiguous()
+            out = _RenderingFn.apply(self, depth_only, table, img, ts_, te_, ri, table.shape[0], *self.parameters())
+            self._patch_t_ends(t_ends, ri)
+            return (None, out, None, None, None, None) if depth_only else out
         with torch.no_grad():
             return self._rendering_impl(chunk_rays, t_starts, t_ends, ray_indices, depth_only)
+
+    @staticmethod
+    def _patch_t_ends(t_ends, ri):
+        """the reference patches the caller's t_ends in place (eonerf.py:218-220): last interval of every ray -> 1e10"""
+        n = t_ends.shape[0]
+        if n > 0:
+            with torch.no_grad():
+                last = torch.ones(n, dtype=torch.bool, device=t_ends.device)
+                last[:-1] = ri[1:] != ri[:-1]
+                t_ends[last] = 1e10
 
     def _rendering_impl(self, chunk_rays, t_starts, t_ends, ray_indices, depth_only):
         from ..datasets.satellite import satrays_to_table
@@ -300,19 +368,16 @@ class EONerfMLP(nn.Module):
         _lib.check(L.eonerf_rendering(self._ctx, _ptr(flat), _ptr(table), _ptr(img), _ptr(ts_), _ptr(te_), _ptr(ri), n, n_rays,
                                       1 if depth_only else 0, _ptr(albedo), _ptr(depth), _ptr(beta), _ptr(tsc), _ptr(ambient),
                                       _ptr(entropy), _ptr(ws), ws.numel(), _stream()))
-        # the reference patches the caller's t_ends in place (eonerf.py:218-220): last interval of every ray -> 1e10
-        if n > 0:
-            last = torch.ones(n, dtype=torch.bool, device=dev)
-            last[:-1] = ri[1:] != ri[:-1]
-            t_ends[last] = 1e10
+        self._patch_t_ends(t_ends, ri)
         return albedo, depth, beta, tsc, ambient, entropy
 
     def render_depth(self, chunk_rays, t_starts, t_ends, ray_indices):
-        """radiance_fields/eonerf.py:172-194: flattened samples -> depth [n_rays, 1]."""
+        """radiance_fields/eonerf.py:172-194: flattened samples -> depth [n_rays, 1] (differentiable w.r.t. the parameters)."""
         return self._rendering(chunk_rays, t_starts, t_ends, ray_indices, True)[1]
 
     def rendering(self, chunk_rays, t_starts, t_ends, ray_indices, epoch_idx=100):
         """radiance_fields/eonerf.py:196-248: -> (albedo_rgb_, depth_, transient_beta_, transient_scalar_, ambient_rgb_, entropy_).
-        Inference entry point (raises under a recording autograd with trainable parameters); render_image fuses this with
-        sampling, the shadow pass and autograd."""
+        Differentiable w.r.t. the parameters when autograd is recording, as the reference method is (round 4); render_image fuses this
+        with sampling, the shadow pass and autograd and is what the training loop calls.  At most 127 samples per ray, ray_indices
+        sorted (what satnerf_sampling produces)."""
         return self._rendering(chunk_rays, t_starts, t_ends, ray_indices, False)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EONERF_VERSION 301
+#define EONERF_VERSION 400
 
 enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4, EONERF_E_DEVICE = -5 };
 
@@ -134,6 +134,20 @@ int eonerf_rendering(eonerf_ctx* ctx, const float* flat_params, const float* ray
                      const float* t_starts, const float* t_ends, const int64_t* ray_indices, int n, int n_rays, int depth_only,
                      float* albedo, float* depth, float* beta, float* transient_s, float* ambient, float* entropy,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same two entry points under autograd (the reference's methods are ordinary autograd code, radiance_fields/eonerf.py:172-248):
+ *   eonerf_rendering_train: as eonerf_rendering, with the chain kernel in training mode; `workspace` (eonerf_render_workspace_bytes with
+ *     EONERF_F_TRAIN [| EONERF_F_ONLY_DEPTH]) keeps the saved activations and compositing inputs and must stay untouched until
+ *   eonerf_rendering_backward: gradients of the per-ray outputs ([n_rays, c] row-major, NULL = zero; entropy is a constant) -> gradient of
+ *     every parameter, ACCUMULATED into d_flat_params.  t_starts / t_ends themselves carry no gradient (the reference's samplers run
+ *     under no_grad, sat_rendering.py:56). */
+int eonerf_rendering_train(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
+                           const float* t_starts, const float* t_ends, const int64_t* ray_indices, int n, int n_rays, int depth_only,
+                           float* albedo, float* depth, float* beta, float* transient_s, float* ambient, float* entropy,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int eonerf_rendering_backward(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx, int n_rays, int depth_only,
+                              const float* g_albedo, const float* g_depth, const float* g_beta, const float* g_transient_s, const float* g_ambient,
+                              float* d_flat_params, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One chunk of sat_rendering.render_image (sat_rendering.py:252-312) = satnerf_sampling + EONerfMLP.rendering +
  * compute_geometric_shadows + irradiance/radiometric model + output packing.

@@ -1,6 +1,6 @@
 # per-kernel stats + one step's kernel timeline (gaps) of the full workload
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/trace_r03; rm -rf $O; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${OUT:-trace_r04}; rm -rf $O; mkdir -p $O; cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- python3 bench.py --steps 10 --warmup 3 --workload ${WL:-full} --no-cpu-baseline --no-kernel-pass > $O/bench.json 2> $O/err.txt
 python3 - <<PY
 import csv, collections
