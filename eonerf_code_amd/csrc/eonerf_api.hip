@@ -123,37 +123,42 @@ int pack(const eonerf_ctx* ctx, const std::vector<const DevStream*>& streams, co
 }
 
 // The heads' first layers folded with the bottleneck layer (eonerf_pack.h): fold[o][i] = sum_k W_AT[o][k] W_b[k][i], b_f[o] = sum_k
-// W_AT[o][k] b_b[k] + b_AT[o], with W_AT = [W_A1; W_T1[:, :256]].  fp32 FMAs in k order (deterministic).  Block = 4 output rows,
-// thread = column i (thread 0..255) -- 16.8 M MACs on 64 workgroups, a few microseconds in front of every re-pack.
+// W_AT[o][k] b_b[k] + b_AT[o], with W_AT = [W_A1; W_T1[:, :256]].  fp32 FMAs in a fixed order (four interleaved partial sums over k:
+// deterministic).  Block = 2 output rows, thread = column i: 16.8 M MACs on 128 workgroups in front of every re-pack; the k loop is
+// unrolled so that 16 loads of a W_b column are in flight (one dependent L2 round trip per k took 16 us).
 struct FoldArgs { const float *w_a1, *b_a1, *w_t1, *b_t1, *w_b, *b_b; float* fold; };
 __global__ __launch_bounds__(256) void k_fold(FoldArgs a) {
-    __shared__ float wat[4][256];
-    const int o0 = blockIdx.x * 4, i = threadIdx.x;
-    for (int r = 0; r < 4; ++r) {
+    __shared__ float wat[2][256];
+    const int o0 = blockIdx.x * 2, i = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
         const int o = o0 + r;
         wat[r][i] = o < 128 ? a.w_a1[(size_t)o * 256 + i] : a.w_t1[(size_t)(o - 128) * 260 + i];
     }
     __syncthreads();
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < 256; ++k) {
-        const float wb = a.w_b[(size_t)k * 256 + i];
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+    for (int k = 0; k < 256; k += 4) {
+        float wb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = fmaf(wat[r][k], wb, acc[r]);
+        for (int u = 0; u < 4; ++u) wb[u] = a.w_b[(size_t)(k + u) * 256 + i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[0][u] = fmaf(wat[0][k + u], wb[u], acc[0][u]); acc[1][u] = fmaf(wat[1][k + u], wb[u], acc[1][u]); }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a.fold[(size_t)(o0 + r) * 256 + i] = acc[r];
-    if (i < 4) {
+    for (int r = 0; r < 2; ++r) a.fold[(size_t)(o0 + r) * 256 + i] = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
+    if (i < 2) {
         const int o = o0 + i;
-        float b = 0.f;
-        for (int k = 0; k < 256; ++k) b = fmaf(wat[i][k], a.b_b[k], b);
-        a.fold[256 * 256 + o] = b + (o < 128 ? a.b_a1[o] : a.b_t1[o - 128]);
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 256; ++k) b4[k & 3] = fmaf(wat[i][k], a.b_b[k], b4[k & 3]);
+        a.fold[256 * 256 + o] = ((b4[0] + b4[1]) + (b4[2] + b4[3])) + (o < 128 ? a.b_a1[o] : a.b_t1[o - 128]);
     }
 }
 int fold_heads(const eonerf_ctx* ctx, const float* flat, hipStream_t st) {
     const ParamLayout& pl = ctx->pl;
     FoldArgs a{flat + pl.t[pl.a1_w].offset, flat + pl.t[pl.a1_b].offset, flat + pl.t[pl.t_w[0]].offset, flat + pl.t[pl.t_b[0]].offset,
                flat + pl.t[pl.bot_w].offset, flat + pl.t[pl.bot_b].offset, ctx->fold};
-    hipLaunchKernelGGL(k_fold, dim3(64), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_fold, dim3(128), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -253,7 +258,9 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
 //   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
                          const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false,
-                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false) {
+                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false, BottWgradArgs* defer_bott = nullptr) {
+    // defer_bott != nullptr: the products that follow from the bottleneck factors are NOT launched here; their arguments are handed back
+    // (the render path runs them in one launch with the embedding and ambient-head gradients, eo_launch_step_tail)
     const ParamLayout& pl = ctx->pl;
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
@@ -365,7 +372,8 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         bw.d_w = dptr(pl.bot_w); bw.d_b = dptr(pl.bot_b);
         bw.d_w_a1 = dptr(pl.a1_w); bw.d_b_a1 = dptr(pl.a1_b);
         bw.d_w_t1 = transient ? dptr(pl.t_w[0]) : nullptr; bw.d_b_t1 = transient ? dptr(pl.t_b[0]) : nullptr;
-        HIP_TRY(eo_launch_bott_wgrad(bw, st));
+        if (defer_bott) *defer_bott = bw;
+        else HIP_TRY(eo_launch_bott_wgrad(bw, st));
     }
     return 0;
 }
@@ -724,13 +732,25 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
       HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, !density_only, density_only, transient && !density_only, grid, st, pipe ? 1 : 0)); }
     if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, first_pipe); if (rcp) return rcp; }
 
+    BottWgradArgs bott;
     {
         const PassBuffers* full = density_only ? nullptr : &w.cam;
         const PassBuffers* dens = density_only ? &w.cam : sun;
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, full, transient, dens, p_cap, w.m_bott, w.queue, st, pipe, pipe && dens, w.det.wgrad_part, pipe);
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, full, transient, dens, p_cap, w.m_bott, w.queue, st, pipe, pipe && dens, w.det.wgrad_part, pipe,
+                                             (full && !ctx->deterministic) ? &bott : nullptr);
         if (rcw) return rcw;
     }
     if (density_only) return EONERF_OK;
+    if (!ctx->deterministic) {
+        // the three independent tails of the backward -- bottleneck-factor products, embedding table, per-ray ambient head -- in ONE launch
+        EmbGradArgs eg;
+        eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays;
+        eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0; eg.d_emb_rays = nullptr;
+        AmbientBwdArgs ag;
+        ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
+        ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
+        return (int)eo_launch_step_tail(&bott, transient ? &eg : nullptr, ambient ? &ag : nullptr, st);
+    }
 
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
     if (transient) {

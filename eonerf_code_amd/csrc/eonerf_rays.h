@@ -118,6 +118,8 @@ struct PackedArgs {        // flattened samples handed in by the caller (EONerfM
 struct RenderingOutArgs { const float* ray_rec; int n_rays; float *albedo, *depth, *beta, *ts, *ambient, *entropy; };
 // gradients of EONerfMLP.rendering's per-ray outputs (any may be null = zero) -> gradient of the ray record
 struct RenderingOutBwdArgs { const float* ray_rec; int n_rays; const float *g_albedo, *g_depth, *g_beta, *g_ts, *g_ambient; float* g_ray; };
+// bottleneck-factor products | embedding gradient | ambient-head backward in one launch (any of the three may be null)
+hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb, const AmbientBwdArgs* amb, hipStream_t st);
 hipError_t eo_launch_rendering_out_bwd(const RenderingOutBwdArgs& a, hipStream_t st);
 
 hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st);

@@ -1,6 +1,7 @@
 // Backward of the per-ray kernels (H10 of SURVEY.md 8a: autograd of sat_rendering.py:264-306 and of the nerfacc
 // compositing calls at radiance_fields/eonerf.py:229-243, sat_rendering.py:106-116), plus the fused Adam update.
 #include <stdlib.h>
+#include <string.h>
 #include "eonerf_common.h"
 #include "eonerf_rays.h"
 #include "eonerf_rays_dev.h"
@@ -180,15 +181,16 @@ __global__ void k_rendering_out_bwd(RenderingOutBwdArgs a) {
 //      The streams' partial sums meet in LDS before ONE set of atomics per block (every block adds into the same 3.9k addresses:
 //      ~0.7 us per block, hence few blocks) ----
 constexpr int AMB_STREAMS = 4, AMB_BATCH = 64, AMB_REC = 168;       // per staged ray: 160 saved floats, 3 outputs, 3 gradients, pad
-__global__ __launch_bounds__(128 * AMB_STREAMS) void k_ambient_bwd(AmbientBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[AMB_BATCH * AMB_REC > (AMB_STREAMS - 1) * 128 * 32 ? AMB_BATCH * AMB_REC : (AMB_STREAMS - 1) * 128 * 32];
+constexpr int AMB_LDS_F = AMB_BATCH * AMB_REC > (AMB_STREAMS - 1) * 128 * 32 ? AMB_BATCH * AMB_REC : (AMB_STREAMS - 1) * 128 * 32;
+// body of one ambient block: blk of nblk blocks of 128 * AMB_STREAMS threads; lds: AMB_LDS_F floats, 16-byte aligned
+EO_DEV void ambient_bwd_body(const AmbientBwdArgs& a, int blk, int nblk, float* lds) {
     const int j = threadIdx.x & 127, q = threadIdx.x >> 7;
     float dw1[27], dw2[3] = {0.f, 0.f, 0.f}, db1 = 0.f, db2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 27; ++i) dw1[i] = 0.f;
     const float w2[3] = {a.w.w2[j], a.w.w2[128 + j], a.w.w2[256 + j]};
-    const int per = (a.n_rays + gridDim.x - 1) / gridDim.x;
-    const int r_lo = blockIdx.x * per, r_hi = r_lo + per < a.n_rays ? r_lo + per : a.n_rays;
+    const int per = (a.n_rays + nblk - 1) / nblk;
+    const int r_lo = blk * per, r_hi = r_lo + per < a.n_rays ? r_lo + per : a.n_rays;
     // software pipeline: the loads of batch b + 1 (20 + 1 per thread) are in flight while batch b is consumed out of LDS -- one batch
     // at a time would expose a full memory round trip (~2-3 us with so few workgroups on the chip) per 64 rays
     constexpr int NT = 128 * AMB_STREAMS, NL = AMB_BATCH * 160 / NT;
@@ -267,6 +269,10 @@ __global__ __launch_bounds__(128 * AMB_STREAMS) void k_ambient_bwd(AmbientBwdArg
     if (db1 != 0.f) atomicAdd(a.d_b1 + j, db1);
 #pragma unroll
     for (int o = 0; o < 3; ++o) if (dw2[o] != 0.f) atomicAdd(a.d_w2 + o * 128 + j, dw2[o]);
+}
+__global__ __launch_bounds__(128 * AMB_STREAMS) void k_ambient_bwd(AmbientBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[AMB_LDS_F];
+    ambient_bwd_body(a, blockIdx.x, gridDim.x, lds);
 }
 
 // ---- differentiable EONerfMLP.forward on caller-provided points (radiance_fields/eonerf.py:154-170): glue around the chains ----
@@ -356,12 +362,12 @@ __global__ void k_table_reduce(const float* contrib, const int64_t* idx, int n_r
 // ---- weight gradients that follow from the bottleneck factors (fp32, see BottWgradArgs).
 //      blocks 0..255: bottleneck layer, block = input feature i of the heads' first layers = output feature (row) of the bottleneck
 //      layer, thread = column j;  blocks 256..: one row m of [W_A1; W_T1] each, thread = bottleneck feature i ----
-__global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
-    __shared__ float s_w[256];
-    __shared__ float s_t[256][17];
-    const int j = threadIdx.x;
-    if (blockIdx.x < 256) {
-        const int i = blockIdx.x;
+constexpr int BOTT_LDS_F = 256 + 256 * 17;
+// body of one (virtual) block of 256 threads: vblk = block index, j = thread; s_w [256], s_t [256][17].  Every barrier is executed by
+// all threads of the REAL block (two virtual blocks of the same branch share one in the merged tail kernel).
+EO_DEV void bott_wgrad_body(const BottWgradArgs& a, int vblk, int j, float* s_w, float (*s_t)[17]) {
+    if (vblk < 256) {
+        const int i = vblk;
         float acc = 0.f, accb = 0.f;
         if (j < 128) s_w[j] = a.w_a1[j * 256 + i];
         else s_w[j] = a.w_t1 ? a.w_t1[(j - 128) * 260 + i] : 0.f;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
         return;
     }
     // first layer of a head, row m:  dW[m][i] += sum_j M[m][j] W_bott[i][j] + db[m] b_bott[i]
-    const int mm = blockIdx.x - 256, m = mm & 127;
+    const int mm = vblk - 256, m = mm & 127;
     const bool tr = mm >= 128;
     const float* M = (tr ? a.m_t : a.m_a) + m * 256;
     s_w[j] = M[j];
@@ -405,14 +411,19 @@ __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
     dw[j] += acc;                                       // the only writer of this row in this launch
     if (j == 0) (tr ? a.d_b_t1 : a.d_b_a1)[m] += dbm;
 }
+__global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
+    __shared__ float s_w[256];
+    __shared__ float s_t[256][17];
+    bott_wgrad_body(a, blockIdx.x, threadIdx.x, s_w, s_t);
+}
 
 // ---- transient embedding gradient: per-sample d emb (from the backward chain) summed per ray, added per image ---
-__global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
-    extern __shared__ float s_de[];                     // [n_img][4] block-local accumulation (0 floats if unused)
-    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK * 8 + (threadIdx.x >> 6);
+// body of one (virtual) block of 256 threads; s_de: [n_img][4] block-local accumulation (unused when lds_images == 0)
+EO_DEV void emb_grad_body(const EmbGradArgs& a, int vblk, int tid, float* s_de) {
+    const int lane = tid & 63, ray = vblk * RAYS_PER_BLOCK * 8 + (tid >> 6);
     const bool lds_acc = a.lds_images > 0 && !a.d_emb_rays;
     if (lds_acc) {
-        for (int i = threadIdx.x; i < a.lds_images * 4; i += 256) s_de[i] = 0.f;
+        for (int i = tid; i < a.lds_images * 4; i += 256) s_de[i] = 0.f;
         __syncthreads();
     }
     // 32 rays per block, 8 per wave.  Two passes without early exits, so that the eight (offset, count) loads and then the sixteen
@@ -448,8 +459,35 @@ __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
     }
     if (lds_acc) {
         __syncthreads();
-        for (int i = threadIdx.x; i < a.lds_images * 4; i += 256) { const float v = s_de[i]; if (v != 0.f) atomicAdd(a.d_emb + i, v); }
+        for (int i = tid; i < a.lds_images * 4; i += 256) { const float v = s_de[i]; if (v != 0.f) atomicAdd(a.d_emb + i, v); }
     }
+}
+__global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
+    extern __shared__ float s_de[];
+    emb_grad_body(a, blockIdx.x, threadIdx.x, s_de);
+}
+
+// ---- the tail of a training backward in ONE launch: the three kernels above are independent of each other (bottleneck-factor
+//      products | embedding table | ambient head), each a few dozen workgroups of 10-35 us -- run one after the other they cost their
+//      sum (~70 us of a 3.4 ms step), in one grid the longest.  Blocks of 512 threads: [0, n_amb) ambient head; then pairs of 256-thread
+//      virtual blocks of the bottleneck products (a pair never straddles the kernel's two branches: 256 is even) and of the embedding
+//      gradient.  n_bott / n_emb / n_amb = 0: that part is absent. ----
+struct StepTailArgs { BottWgradArgs bott; EmbGradArgs emb; AmbientBwdArgs amb; int n_amb, n_bott, n_emb; };
+__global__ __launch_bounds__(512) void k_step_tail(StepTailArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[AMB_LDS_F];
+    static_assert(2 * BOTT_LDS_F <= AMB_LDS_F, "two virtual blocks of the bottleneck products share the ambient staging area");
+    int blk = blockIdx.x;
+    if (blk < a.n_amb) { ambient_bwd_body(a.amb, blk, a.n_amb, lds); return; }
+    blk -= a.n_amb;
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    if (blk < a.n_bott / 2) {
+        float* base = lds + half * BOTT_LDS_F;
+        bott_wgrad_body(a.bott, 2 * blk + half, tid, base, reinterpret_cast<float (*)[17]>(base + 256));
+        return;
+    }
+    blk -= a.n_bott / 2;
+    // (an odd last virtual block runs with an idle partner: rays beyond n_rays are skipped inside)
+    emb_grad_body(a.emb, 2 * blk + half, tid, lds + half * (AMB_LDS_F / 2));
 }
 
 // ---- training loss and its gradient on the packed outputs (train_eonerf.py:139-143) ------------------------------
@@ -559,6 +597,25 @@ hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st, bool d
     // deterministic mode: ONE block -- every address is then added by exactly one thread, its rays in a fixed order
     const int want = deterministic ? 1 : (a.n_rays + AMB_BATCH - 1) / AMB_BATCH;
     hipLaunchKernelGGL(k_ambient_bwd, dim3(want < blocks ? want : blocks), dim3(128 * AMB_STREAMS), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb, const AmbientBwdArgs* amb, hipStream_t st) {
+    StepTailArgs a;
+    memset(&a, 0, sizeof(a));
+    if (bott) { a.bott = *bott; a.n_bott = 256 + 128 + (bott->w_t1 ? 128 : 0); }
+    if (emb) {
+        a.emb = *emb;
+        a.n_emb = (emb->n_rays + 31) / 32;
+        if (a.emb.lds_images * 4 > AMB_LDS_F / 2) a.emb.lds_images = 0;      // table too large for the shared staging area: direct atomics
+    }
+    if (amb) {
+        a.amb = *amb;
+        const int want = (amb->n_rays + AMB_BATCH - 1) / AMB_BATCH;
+        a.n_amb = want < 32 ? want : 32;                                      // (block count: see eo_launch_ambient_bwd)
+    }
+    const int grid = a.n_amb + a.n_bott / 2 + (a.n_emb + 1) / 2;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_step_tail, dim3(grid), dim3(512), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_table_reduce(const float* contrib, const int64_t* idx, int n_rays, int width, int stride, int n_rows, int eval_first,
