@@ -35,6 +35,7 @@ struct eonerf_ctx {
     DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig, pipe_wt, bwd_full_heads, bwd_rgb_heads, bwd_dens_heads, ig_tail_wt;
     bool pipe = false;               // layer-pipelined trunk backward (bf16 camera pass; EONERF_PIPE=0 switches back to chain + GEMM)
     int n_pipes = 0;
+    float* loss_scratch = nullptr;   // [LOSS_MAX_BLOCKS] per-block partial sums of k_loss + its arrival counter (self-resetting: no memset per step)
     float* fold = nullptr;           // [FOLD_FLOATS] fp32: the heads' first layers folded with the bottleneck layer (eonerf_pack.h), re-computed
                                      // by k_fold in front of every re-pack
     int pipe_fault_stage = -1;       // test hook (EONERF_PIPE_FAULT)
@@ -433,6 +434,8 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
           if (!rc && ctx->pipe && f && atoi(f)) rc = (int)hipMalloc(&ctx->pipe_stamps, (size_t)ctx->n_pipes * PIPE_STAGES * 128 * sizeof(unsigned long long)); }
     }
     if (!rc) rc = (int)hipMalloc(&ctx->fold, FOLD_FLOATS * sizeof(float));
+    if (!rc) rc = (int)hipMalloc(&ctx->loss_scratch, (LOSS_MAX_BLOCKS + 4) * sizeof(float));
+    if (!rc) rc = (int)hipMemset(ctx->loss_scratch, 0, (LOSS_MAX_BLOCKS + 4) * sizeof(float));
     if (!rc) rc = (int)hipMalloc(&ctx->dev_status, 64 * sizeof(int));
     if (!rc) rc = (int)hipMemset(ctx->dev_status, 0, 64 * sizeof(int));
     if (!rc) {
@@ -484,6 +487,7 @@ int eonerf_destroy(eonerf_ctx* ctx) {
     for (int k = 0; k < EONERF_PROF_KERNELS; ++k) for (int s = 0; s < 2; ++s) for (hipEvent_t e : ctx->prof_ev[k][s]) (void)hipEventDestroy(e);
     release(ctx->fwd_full); release(ctx->fwd_dens); release(ctx->bwd_full); release(ctx->bwd_dens); release(ctx->bwd_rgb); release(ctx->bwd_full_ig); release(ctx->pipe_wt); release(ctx->bwd_full_heads); release(ctx->bwd_rgb_heads); release(ctx->bwd_dens_heads); release(ctx->ig_tail_wt);
     if (ctx->fold) (void)hipFree(ctx->fold);
+    if (ctx->loss_scratch) (void)hipFree(ctx->loss_scratch);
     if (ctx->enc_colmap) (void)hipFree(ctx->enc_colmap);
     if (ctx->pipe_stamps) (void)hipFree(ctx->pipe_stamps);
     if (ctx->dev_status) (void)hipFree(ctx->dev_status);
@@ -785,7 +789,6 @@ int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, 
     if (!ctx || !rays || !zsteps || !ray_indices || !t_starts || !t_ends || n_rays < 0 || !ws) return EONERF_E_ARG;
     RenderWs w = carve_render(ctx, ws, n_rays, EONERF_F_ONLY_DEPTH);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
-    HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * sizeof(int), st));
     SampleArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.rays = rays; sa.zsteps = zsteps; sa.u = u; sa.n_rays = n_rays; sa.perturb = perturb ? 1 : 0;
@@ -902,7 +905,6 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     const int p_cap = p_cap_of(n_rays);
-    HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * sizeof(int), st));
 
     // ---- camera pass: sample -> field -> composite -------------------------------------------------------
     SampleArgs sa;
@@ -1054,7 +1056,7 @@ int eonerf_grad_seal(eonerf_ctx* ctx, float* d_flat, void* stream) {
 
 int eonerf_train_loss(eonerf_ctx* ctx, const float* out, const float* pixels, int n_rays, int kind, float* d_out, float* loss, void* stream) {
     if (!ctx || !out || !pixels || !d_out || !loss || n_rays < 1 || (kind != 0 && kind != 1)) return EONERF_E_ARG;
-    return (int)eo_launch_loss(out, pixels, n_rays, kind, d_out, loss, (hipStream_t)stream);
+    return (int)eo_launch_loss(out, pixels, n_rays, kind, d_out, loss, ctx->loss_scratch, (hipStream_t)stream);
 }
 
 static int adam_common(eonerf_ctx* ctx, float* flat, float* d_flat, bool zero_grad, float* exp_avg, float* exp_avg_sq,

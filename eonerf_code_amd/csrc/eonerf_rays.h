@@ -141,7 +141,8 @@ hipError_t eo_launch_emb_grad_points(const float* g_emb, const int* simg, int n,
 hipError_t eo_launch_ambient_points_bwd(const AmbientW& w, const float* sun, const float* g_amb, int n,
                                         float* d_w1, float* d_b1, float* d_w2, float* d_b2, hipStream_t st);
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st);
-hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st);
+constexpr int LOSS_MAX_BLOCKS = 256;      // k_loss: grid-stride over the rays, one partial sum per block in the context's scratch
+hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, float* scratch, hipStream_t st);
 // status: the context's sticky device status word; fault_flag: reduced fault flag of the gradient message or nullptr (see k_adam)
 hipError_t eo_launch_adam(float* p, float* g, bool zero_grad, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
                           float gscale, int* status, const float* fault_flag, hipStream_t st);

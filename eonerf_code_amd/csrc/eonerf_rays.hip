@@ -94,7 +94,7 @@ EO_DEV RayGeom ray_geom(const SampleArgs& a, int ray) {
     return g;
 }
 
-// ---- kernel 1: count samples per ray (for both the first draw and the "retry" draw) -----------------------
+// ---- kernel 1: count samples per ray (for both the first draw and the "retry" draw; k_scan decides which one counts) ----
 __global__ __launch_bounds__(256) void k_count(SampleArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
@@ -113,7 +113,6 @@ __global__ __launch_bounds__(256) void k_count(SampleArgs a) {
     if (lane == 0) {
         a.cnt_first[ray] = cnt;
         a.cnt_retry[ray] = cnt_retry;
-        if (cnt == 0 && a.retry) atomicOr(a.flags, 1);
     }
 }
 
@@ -122,7 +121,15 @@ __global__ __launch_bounds__(1024) void k_scan(SampleArgs a) {
     __shared__ int wsum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool retry = a.retry && (*a.flags & 1);
+    // "resample if any ray is empty" (sat_rendering.py:260-262): decided here, from the counts of the first draw, and left in flags[0]
+    // for k_emit (a plain store: nothing has to be zeroed before the sampler runs)
+    bool retry = false;
+    if (a.retry) {
+        int any = 0;
+        for (int i = tid; i < a.n_rays; i += 1024) any |= a.cnt_first[i] == 0 ? 1 : 0;
+        retry = __syncthreads_or(any) != 0;
+        if (tid == 0) a.flags[0] = retry ? 1 : 0;
+    }
     const int* cnt = retry ? a.cnt_retry : a.cnt_first;
     if (tid == 0) carry = 0;
     __syncthreads();

@@ -492,10 +492,14 @@ __global__ __launch_bounds__(512) void k_step_tail(StepTailArgs a) {
 
 // ---- training loss and its gradient on the packed outputs (train_eonerf.py:139-143) ------------------------------
 //   kind 0: F.mse_loss(rgb, gt)                          kind 1: metrics.uncertainty_aware_loss (metrics.py:17-22)
-__global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss) {
-    const int ray = blockIdx.x * 256 + threadIdx.x;
+//   The mean is summed in a FIXED order without a zeroed accumulator: every block leaves its partial sum in scratch[block], takes a
+//   ticket, and the last block to arrive adds the partials in block order, writes the scalar and resets the ticket counter
+//   (scratch[LOSS_MAX_BLOCKS], as int) for the next call.
+__global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, float* scratch) {
+    __shared__ float s_part[4];
+    __shared__ int s_last;
     float part = 0.f;
-    if (ray < n) {
+    for (int ray = blockIdx.x * 256 + threadIdx.x; ray < n; ray += gridDim.x * 256) {
         const float* o = out + (size_t)ray * 21;
         float* d = d_out + (size_t)ray * 21;
 #pragma unroll
@@ -509,13 +513,26 @@ __global__ __launch_bounds__(256) void k_loss(const float* out, const float* gt,
             float sq = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) { const float df = o[c] - gt[(size_t)ray * 3 + c]; sq += df * df; d[c] = df * ib2 * inv; }
-            part = 0.5f * sq * ib2 * inv + 0.5f * logf(beta) / n;
+            part += 0.5f * sq * ib2 * inv + 0.5f * logf(beta) / n;
             d[12] = -sq * ib2 / beta * inv + 0.5f / (n * beta);
         }
     }
     part = wave_sum(part);
-    if (kind == 1 && blockIdx.x == 0 && threadIdx.x == 0) part += 1.5f;      // the constant 3/2 of the beta term (metrics.py:20)
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss, part);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        __threadfence();
+        int* ticket = reinterpret_cast<int*>(scratch + LOSS_MAX_BLOCKS);
+        s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    float total = kind == 1 ? 1.5f : 0.f;                 // the constant 3/2 of the beta term (metrics.py:20)
+    for (unsigned b = 0; b < gridDim.x; ++b) total += __hip_atomic_load(scratch + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *loss = total;
+    *reinterpret_cast<int*>(scratch + LOSS_MAX_BLOCKS) = 0;
 }
 // ---- torch.optim.Adam (no weight decay, no amsgrad) on the flat buffers --------------------------------------
 // ONE step count for every parameter: while epoch_idx < 2 the reference's graph still reaches the transient / ambient heads through
@@ -627,10 +644,9 @@ hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_emb_grad, dim3((a.n_rays + 31) / 32), dim3(256), (size_t)a.lds_images * 4 * sizeof(float), st, a);
     return hipGetLastError();
 }
-hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_loss, dim3((n + 255) / 256), dim3(256), 0, st, out, gt, n, kind, d_out, loss);
+hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, float* scratch, hipStream_t st) {
+    const int blocks = (n + 255) / 256 < LOSS_MAX_BLOCKS ? (n + 255) / 256 : LOSS_MAX_BLOCKS;
+    hipLaunchKernelGGL(k_loss, dim3(blocks), dim3(256), 0, st, out, gt, n, kind, d_out, loss, scratch);
     return hipGetLastError();
 }
 hipError_t eo_launch_adam(float* p, float* g, bool zero_grad, float* m, float* v, size_t n, int step, float lr, float b1, float b2, float eps,
