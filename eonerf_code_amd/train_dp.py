@@ -75,7 +75,12 @@ def main():
                 el = time.time() - tic
                 print(f"epoch={epoch} | elapsed_time={el:.2f}s | step={step} | loss={float(loss):.5f} | "
                       f"rays/s={(step + 1) * args.batch_size * world / max(el, 1e-9):.0f}", flush=True)
-            if step > 0 and step % (4 * steps_per_epoch) == 0 and rank == 0:  # save_freq, :180-191
+            save_now = step > 0 and step % (4 * steps_per_epoch) == 0         # save_freq, :180-191 (the same decision on every rank)
+            if save_now and step % args.check_every != 0:
+                # a checkpoint must not hold updates that were skipped: after a device-side fault the Adam kernel leaves the weights alone
+                # while the host's step count keeps running -- every rank checks (and raises together) BEFORE rank 0 writes
+                trainer.check_device_status()
+            if save_now and rank == 0:
                 save_checkpoint(os.path.join(args.logs_dir, args.exp_name, f"ckpts/epoch={epoch}.ckpt"), epoch, field, trainer, loss)
             if step == args.max_train_steps:
                 trainer.check_device_status()

@@ -115,10 +115,55 @@ def test_fp32_outputs_and_gradients_match_the_oracle_at_the_bench_size(batch, ep
     print(f"[fullsize fp32 epoch {epoch}] worst err / bound = {worst:.3f}")
 
 
+_BF16_ORACLE = {}
+
+
+def oracle_bf16(batch, epoch):
+    """ONE run of the oracle's bf16 arithmetic model per epoch (outputs AND gradients; ~40 s of host time), shared by the forward and
+    the backward test."""
+    if epoch not in _BF16_ORACLE:
+        sd, rays, ts, rgbs, u_cam, u_sun = batch
+        _BF16_ORACLE[epoch] = oracle_chunked(sd, rays, ts, rgbs, u_cam, u_sun, epoch, torch.float32, emulate_bf16=True, grads=True)
+    return _BF16_ORACLE[epoch]
+
+
+# per-tensor relative L2 bound of the bf16 HIP gradient against the bf16 arithmetic model's autograd at the bench size: measured values
+# x 2 (printed by the test; VERDICT r3 #6), by tensor family.  What is left between the two is the order of the fp32 sums, where a
+# gradient is rounded to bf16 (the model rounds dX behind every product, the kernels round dY in front of the next one -- the same
+# tensor, except at the heads' outputs) and __sinf / __cosf.
+BF16_GRAD_BOUNDS = {"default": 6e-2}
+
+
+@pytest.mark.parametrize("epoch", [0, 3])
+def test_bf16_backward_matches_the_bf16_arithmetic_model_at_the_bench_size(batch, epoch):
+    sd, rays, ts, rgbs, u_cam, u_sun = batch
+    _, _, loss_ref, g_ref = oracle_bf16(batch, epoch)
+    f = make_field(sd, "bf16")
+    f.zero_grad()
+    res, n = hip_render(f, rays, ts, noise_for(u_cam, u_sun, R), epoch, R)
+    loss = hip_loss(res, rgbs.cuda(), epoch)
+    loss.backward()
+    assert abs(float(loss) - loss_ref) < 2e-3 * max(1.0, abs(loss_ref)), (float(loss), loss_ref)
+    rows = []
+    for name, p in f.named_parameters():
+        r = g_ref[name]
+        if r is None or r.norm().item() == 0.0:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, name
+            continue
+        got = p.grad.cpu()
+        rel = ((got - r).norm() / r.norm()).item()
+        cos = ((got * r).sum() / (got.norm() * r.norm())).item()
+        rows.append((rel, cos, name))
+        bound = next((v for k, v in BF16_GRAD_BOUNDS.items() if k != "default" and name.startswith(k)), BF16_GRAD_BOUNDS["default"])
+        assert rel < bound and cos > 0.998, (epoch, name, rel, cos)
+    rows.sort(reverse=True)
+    print(f"[fullsize bf16 backward epoch {epoch}] worst per-tensor rel L2 / cosine: " + ", ".join(f"{n} {r:.2e}/{c:.5f}" for r, c, n in rows[:6]))
+
+
 @pytest.mark.parametrize("epoch", [0, 3])
 def test_bf16_forward_matches_the_bf16_emulating_oracle_at_the_bench_size(batch, epoch):
     sd, rays, ts, rgbs, u_cam, u_sun = batch
-    ref, n_ref, _, _ = oracle_chunked(sd, rays, ts, rgbs, u_cam, u_sun, epoch, torch.float32, emulate_bf16=True, grads=False)
+    ref, n_ref, _, _ = oracle_bf16(batch, epoch)
     f = make_field(sd, "bf16")
     with torch.no_grad():
         res, n = hip_render(f, rays, ts, noise_for(u_cam, u_sun, R), epoch, R)
