@@ -38,6 +38,8 @@ struct eonerf_ctx {
     float* loss_scratch = nullptr;   // [LOSS_MAX_BLOCKS] per-block partial sums of k_loss + its arrival counter (self-resetting: no memset per step)
     float* fold = nullptr;           // [FOLD_FLOATS] fp32: the heads' first layers folded with the bottleneck layer (eonerf_pack.h), re-computed
                                      // by k_fold in front of every re-pack
+    bool pipe_fallback = true;       // after a REPORTED watchdog fault the context leaves the pipelined path for good (EONERF_PIPE_FALLBACK=0: stay)
+    bool need_repack = false;        // ... and the chain + GEMM path's weight streams have to be packed before the next call
     int pipe_fault_stage = -1;       // test hook (EONERF_PIPE_FAULT)
     bool deterministic = false;      // EONERF_DETERMINISTIC=1: every atomic flush of the backward is replaced by partials + a fixed-order sum
     bool pipe_partials = false;      // the pipelined launches flush their stationary dW through partial buffers + a reduction kernel (always
@@ -424,6 +426,14 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
         const char* e = getenv("EONERF_PIPE");
         ctx->n_pipes = ctx->n_cu / PIPE_STAGES;
         ctx->pipe = ctx->bf16 && ctx->n_pipes >= 1 && !(e && atoi(e) == 0);
+        // Residency: the pipelined launch needs its 7 x n_pipes workgroups on the chip AT THE SAME TIME (one per CU: 128 KB of LDS, the
+        // whole register file).  Where that cannot hold by construction -- the kernel does not fit a CU of this device, or the process
+        // was given a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK: the runtime still reports every CU) -- the chain + GEMM path is used
+        // from the start instead of timing out in the first step.  A co-tenant on the card cannot be seen from here: see eonerf_device_status.
+        if (ctx->pipe && !(e && atoi(e) == 1)) {
+            if (!eo_bwd_pipe_fits_a_cu() || getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) ctx->pipe = false;
+        }
+        { const char* fb = getenv("EONERF_PIPE_FALLBACK"); ctx->pipe_fallback = !(fb && atoi(fb) == 0); }
         if (!rc && ctx->pipe) rc = upload(ctx->pipe_wt, build_pipe_stream(ctx->pl));
         if (!rc && ctx->pipe) rc = upload(ctx->bwd_full_heads, build_bwd_stream(ctx->pl, true, true, false, true, 1));
         if (!rc && ctx->pipe) rc = upload(ctx->bwd_rgb_heads, build_bwd_stream(ctx->pl, true, true, false, false, 1));
@@ -522,6 +532,7 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
         v.push_back(&ctx->fwd_dens); v.push_back(&ctx->bwd_dens);
         if (ctx->pipe) { v.push_back(&ctx->bwd_dens_heads); v.push_back(&ctx->ig_tail_wt); }
     }
+    ctx->need_repack = false;
     int rc = fold_heads(ctx, flat, st);      // the folded head weights are a gather source of the streams below
     if (!rc) rc = pack(ctx, v, flat, st);
     if (!rc) { ctx->weights_set = true; ctx->dens_dirty = !with_dens; ctx->full_ig_dirty = true; ctx->dens_used = false; }
@@ -896,6 +907,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     if (!ctx || !flat || !rays || !img_idx || !zsteps || !out || n_rays < 0 || !ws) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n_rays == 0) return EONERF_OK;
+    if (ctx->need_repack) { const int rcr = eonerf_set_weights(ctx, flat, stream); if (rcr) return rcr; }
     const bool shadows = (flags & EONERF_F_SHADOWS) && !(flags & EONERF_F_ONLY_DEPTH);
     const bool train = flags & EONERF_F_TRAIN, od = flags & EONERF_F_ONLY_DEPTH;
     const bool philox = u_cam == nullptr;       // production: no noise buffers, the sampler draws its own jitter
@@ -1039,6 +1051,11 @@ int eonerf_device_status(eonerf_ctx* ctx, void* stream) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (!err) return EONERF_OK;
     HIP_TRY(hipMemsetAsync(ctx->dev_status, 0, sizeof(int), (hipStream_t)stream));
+    // A hand-off timed out: the launch did not have the card's CUs to itself (a co-tenant, a partitioned or CU-masked GPU) or a stage
+    // stalled.  The fault is reported (the caller decides: the launcher ends the job) and THIS context leaves the pipelined path: a
+    // caller that carries on trains through the chain + GEMM backward instead of paying a 0.3-s timeout in every step.  Data-parallel
+    // ranks all see the fault (flag in the gradient message) and all switch.
+    if (ctx->pipe && ctx->pipe_fallback) { ctx->pipe = false; ctx->need_repack = true; }
     return EONERF_E_DEVICE;
 }
 

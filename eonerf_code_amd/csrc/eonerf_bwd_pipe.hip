@@ -599,6 +599,14 @@ hipError_t eo_launch_pipe_reduce(const BwdPipeArgs& a, hipStream_t st) {
 
 size_t eo_bwd_pipe_lds_bytes() { return SMEM_B; }
 
+// can ONE workgroup of the pipelined kernel be resident on a CU of the current device at all (LDS, registers)?
+bool eo_bwd_pipe_fits_a_cu() {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B) != hipSuccess) return false;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bwd_pipe, NT, SMEM_B) != hipSuccess) return false;
+    return nb >= 1;
+}
+
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st) {
     if (a.n_stages != PIPE_STAGES) return hipErrorInvalidValue;
     static EoAttrOnce attr;

@@ -155,6 +155,7 @@ struct IgTailArgs {
 };
 hipError_t eo_launch_ig_tail(const IgTailArgs& a, int n_wg, hipStream_t st);
 size_t eo_bwd_pipe_lds_bytes();
+bool eo_bwd_pipe_fits_a_cu();
 
 hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);
 // pipe: 0 = the whole dX chain; 1 = stop at dY_7 (the trunk is pipelined)

@@ -181,6 +181,10 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat_params, const floa
  *   eonerf_device_status: SYNCHRONISES `stream`, returns EONERF_E_DEVICE if a fault was recorded since the last call (0 otherwise)
  *   and clears the word.  Call it where the host synchronises anyway (the reference's loop reads the loss every 1000 steps,
  *   train_eonerf.py:173-178) -- on EVERY data-parallel rank.
+ *     After a reported fault the context leaves the pipelined path for the rest of its life (its hand-offs need the card's CUs to
+ *     themselves: a co-tenant, a partitioned or CU-masked GPU): later steps run the chain + GEMM backward (EONERF_PIPE=0's path) instead
+ *     of timing out again; EONERF_PIPE_FALLBACK=0 keeps the pipeline.  eonerf_create makes the same choice up front when the kernel
+ *     cannot be resident at all or the process runs under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK), unless EONERF_PIPE=1 insists.
  *   eonerf_render_status: the same check, kept with the workspace arguments of version 2 of this ABI (they are ignored). */
 int eonerf_device_status(eonerf_ctx* ctx, void* stream);
 int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* workspace, size_t workspace_bytes, void* stream);

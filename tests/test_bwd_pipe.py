@@ -101,7 +101,15 @@ def test_watchdog_drains_the_launch_quickly_reports_and_gates_the_update():
     assert tr.d_flat[tr.n_params].item() == 1.0          # and the gradient message carries the fault flag for the other ranks
     with pytest.raises(RuntimeError, match="hand-off timed out"):
         tr.check_device_status()
-    # the context stays usable: a healthy field next to it still trains
+    # the context has left the pipelined path with the reported fault (eonerf_device_status): the next step runs through the chain + GEMM
+    # backward -- no timeout, clean status, update applied -- although the stalled stage is still armed
+    t0 = time.time()
+    tr.step(rays, img, rgbs, 0)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 0.25
+    tr.check_device_status()
+    assert not torch.equal(tr.flat.detach(), p0)
+    # a healthy field next to it still trains on the pipelined path
     l, g, _ = _grads(_field(True), 512, 0)
     assert torch.isfinite(g).all()
 
