@@ -131,7 +131,8 @@ def oracle_bf16(batch, epoch):
 # x 2 (printed by the test), by tensor family.  What is left between the two is the order of the fp32 sums, where a
 # gradient is rounded to bf16 (the model rounds dX behind every product, the kernels round dY in front of the next one -- the same
 # tensor, except at the heads' outputs) and __sinf / __cosf.
-BF16_GRAD_BOUNDS = {"default": 6e-2}
+BF16_GRAD_BOUNDS = {"base_mlp.hidden_layers.0.weight": 3e-2,       # measured 1.3e-2 (epoch 0) / 4.9e-3 (epoch 3)
+                    "default": 1.3e-2}                               # measured <= 6.2e-3 (hidden_layers.1.weight, epoch 0); round 3's gate: 6e-2
 
 
 @pytest.mark.parametrize("epoch", [0, 3])
@@ -155,7 +156,7 @@ def test_bf16_backward_matches_the_bf16_arithmetic_model_at_the_bench_size(batch
         cos = ((got * r).sum() / (got.norm() * r.norm())).item()
         rows.append((rel, cos, name))
         bound = next((v for k, v in BF16_GRAD_BOUNDS.items() if k != "default" and name.startswith(k)), BF16_GRAD_BOUNDS["default"])
-        assert rel < bound and cos > 0.998, (epoch, name, rel, cos)
+        assert rel < bound and cos > 0.9995, (epoch, name, rel, cos)
     rows.sort(reverse=True)
     print(f"[fullsize bf16 backward epoch {epoch}] worst per-tensor rel L2 / cosine: " + ", ".join(f"{n} {r:.2e}/{c:.5f}" for r, c, n in rows[:6]))
 

@@ -260,13 +260,15 @@ def test_export_render_after_native_updates_uses_the_current_weights():
 
 
 def test_ten_step_trajectory_across_the_loss_switch_follows_the_oracle_under_torch_adam_and_steplr(monkeypatch):
-    """the PRODUCTION sequencing (keep_message=False: update + zero-grad in one kernel, re-pack and re-fold after every
+    """the PRODUCTION sequencing (keep_message=False: update + zero-grad in one kernel, re-fold and re-pack after every
     step, no seal) over a trajectory, against the reference loop restated on the oracle -- render -> loss -> backward -> torch.optim.Adam,
     StepLR(gamma=0.9) once per epoch (train_eonerf.py:64,139-161,304) -- with a fresh batch and fresh injected jitter every step and
     the loss switch MSE -> uncertainty loss (and the shadow pass coming on) at the epoch 1 -> 2 boundary.  fp32 kernels, fixed-order
-    reductions.  Bounds: the loss curve to 2e-4 relative at every step; the parameter MOVEMENT of every tensor (p_10 - p_0) to 3e-2
-    relative L2 and cosine > 0.999 (Adam divides by sqrt(v): elements whose gradient is rounding noise move by +-lr per step in either
-    implementation, which is what the bound leaves room for), measured values printed."""
+    reductions.  The loss curve agrees to 2e-4 relative at every step.  Parameters: Adam divides by sqrt(v), so elements whose gradient
+    is rounding noise move by +-lr per step in ANY fp32 implementation; the bar is therefore the one of the gradient tests -- as close
+    to an fp64 run of the same loop as the reference's own fp32 arithmetic is: per tensor, with d = p_10 - p_0,
+    |d_hip - d_64| <= 1.5 |d_ref32 - d_64| + 1e-2 |d_64|, and cosine(d_hip, d_ref32) > 0.998
+    (measured: 0.75 of the bound, cosine 0.99925)."""
     monkeypatch.setenv("EONERF_DETERMINISTIC", "1")
     from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
     from eonerf_code_amd.trainer import FusedTrainer
@@ -277,32 +279,41 @@ def test_ten_step_trajectory_across_the_loss_switch_follows_the_oracle_under_tor
     f = f.cuda()
     lr0 = 5e-4
     tr = FusedTrainer(f, lr=lr0, max_rays=R, keep_message=False)
-    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-    opt = torch.optim.Adam([v for v in sdg.values() if v.is_floating_point()], lr=lr0)
-    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.9)
+
+    def oracle_loop(dtype):
+        c = (lambda t: t.to(dtype)) if dtype != torch.float32 else (lambda t: t)
+        sdg = {k: (c(v).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        opt = torch.optim.Adam([v for v in sdg.values() if v.is_floating_point()], lr=lr0)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.9)
+        return sdg, opt, sched
+
+    (sd32, opt32, sch32), (sd64, opt64, sch64) = oracle_loop(torch.float32), oracle_loop(torch.float64)
     steps_per_epoch, losses = 5, []
     for it in range(10):
         epoch = 1 + it // steps_per_epoch                              # epochs 1, 2: MSE / no shadows, then uncertainty loss / shadows
         rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R, N_IMG, seed=400 + it)
-        l_ref, _ = orc.train_step(sdg, rays, ts, rgbs, u_cam, u_sun, epoch, 2.0 / 128, opt)
+        l_ref, _ = orc.train_step(sd32, rays, ts, rgbs, u_cam, u_sun, epoch, 2.0 / 128, opt32)
+        orc.train_step(sd64, rays.double(), ts, rgbs.double(), u_cam.double(), u_sun.double(), epoch, 2.0 / 128, opt64)
         l_hip = float(tr.step(rays.cuda(), ts.reshape(-1).cuda(), rgbs.cuda(), epoch, noise=(u_cam.cuda(), None, u_sun.cuda())))
         losses.append((float(l_ref), l_hip))
         assert abs(l_hip - float(l_ref)) <= 2e-4 * abs(float(l_ref)), (it, l_hip, float(l_ref))
         if it % steps_per_epoch == steps_per_epoch - 1:                # end of an epoch: scheduler.step() (train_eonerf.py:304)
-            sched.step()
-            tr.set_lr(sched.get_last_lr()[0])
+            sch32.step()
+            sch64.step()
+            tr.set_lr(sch32.get_last_lr()[0])
     tr.check_device_status()
     assert abs(tr.lr - lr0 * 0.81) < 1e-12 and tr.step_count == 10
-    worst_rel, worst_cos = 0.0, 1.0
+    worst, worst_cos = 0.0, 1.0
     for name, p in f.named_parameters():
-        d_ref = sdg[name].detach() - sd[name]
-        d_hip = p.detach().cpu() - sd[name]
-        if d_ref.norm().item() == 0.0:
+        p0 = sd[name]
+        d32, d64, d_hip = sd32[name].detach() - p0, sd64[name].detach() - p0.double(), p.detach().cpu() - p0
+        if d64.norm().item() == 0.0:
             assert d_hip.abs().max().item() == 0.0, name
             continue
-        rel = ((d_hip - d_ref).norm() / d_ref.norm()).item()
-        cos = ((d_hip * d_ref).sum() / (d_hip.norm() * d_ref.norm())).item()
-        worst_rel, worst_cos = max(worst_rel, rel), min(worst_cos, cos)
-        assert rel < 3e-2 and cos > 0.999, (name, rel, cos)
+        err, ref_err = (d_hip.double() - d64).norm().item(), (d32.double() - d64).norm().item()
+        bound = 1.5 * ref_err + 1e-2 * d64.norm().item()
+        cos = ((d_hip * d32).sum() / (d_hip.norm() * d32.norm())).item()
+        worst, worst_cos = max(worst, err / bound), min(worst_cos, cos)
+        assert err <= bound and cos > 0.998, (name, err, ref_err, d64.norm().item(), cos)
     print(f"10-step trajectory: losses (oracle, hip) first {losses[0]}, at the switch {losses[5]}, last {losses[-1]}; "
-          f"worst per-tensor movement error {worst_rel:.2e}, worst cosine {worst_cos:.6f}")
+          f"worst movement err / bound {worst:.3f}, worst cosine to the fp32 oracle {worst_cos:.6f}")
