@@ -2,7 +2,7 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-RT=${RT:-r03}
+RT=${RT:-r04}
 O=$R/gpurun_out/prof_$RT
 rm -rf $O; mkdir -p $O
 cd $R
@@ -14,6 +14,5 @@ for WL in rgb full; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$WL -o prof -- python3 bench.py --steps 4 --warmup 2 --workload $WL --no-cpu-baseline --no-kernel-pass > /dev/null 2> $O/pmc_mfma_$WL.err
 done
 EONERF_PIPE=0 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_chain_gemm_path.json 2> /dev/null
-EONERF_HEADS_PIPE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_heads_pipe.json 2> /dev/null
 python3 bench.py --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline > $O/bench_fp32.json 2> /dev/null
 du -sh $O

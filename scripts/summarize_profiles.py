@@ -10,13 +10,13 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RT = os.environ.get("RT", "r03")
+RT = os.environ.get("RT", "r04")
 SRC = os.path.join(REPO, "gpurun_out", "prof_" + RT)
 DST = os.path.join(REPO, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else RT + "_a"
 SHORT = {"k_mlp_fwd<PBf16, true, 2": "fwd_chain_camera", "k_mlp_fwd<PBf16, true, 1": "fwd_chain_camera", "k_mlp_fwd<PBf16, false, 1": "fwd_chain_sun",
          "k_mlp_bwd<PBf16, true, false, false,": "bwd_chain_camera", "k_mlp_bwd<PBf16, true, false, true,": "bwd_chain_camera",
-         "k_mlp_bwd<PBf16, false, true, false,": "bwd_chain_sun", "k_bwd_pipe": "bwd_pipe", "k_heads_pipe": "heads_pipe_camera", "k_wgrad<PBf16>": "wgrad_gemm", "k_ig_tail": "ig_tail_sun"}
+         "k_mlp_bwd<PBf16, false, true, false,": "bwd_chain_sun", "k_bwd_pipe": "bwd_pipe", "k_wgrad<PBf16>": "wgrad_gemm", "k_ig_tail": "ig_tail_sun"}
 
 
 def short(name):
@@ -99,7 +99,7 @@ for wl in ("rgb", "full"):
         out.append([name, f"{t:.4f}", f"{b / (a_ / 8 * 1024):.4f}", f"{a_ / 8 / (t * 1e-3) / 1e9:.3f}"])
     with open(os.path.join(DST, f"{TAG}_pmc_mfma_busy_{wl}.csv"), "w", newline="") as fh:
         csv.writer(fh).writerows(out)
-for name in ("bench.json", "bench_chain_gemm_path.json", "bench_fp32.json", "bench_heads_pipe.json"):
+for name in ("bench.json", "bench_chain_gemm_path.json", "bench_fp32.json"):
     shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_{name}"))
 traffic["_note"] = ("bytes per launch (per step for kernels launched twice a step) = (2*FETCH_SIZE + WRITE_SIZE)*1024: the L2's fabric-side "
                     "request counters (gfx950: FETCH_SIZE reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section; Infinity-Cache "
