@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("EONERF_LIB") or os.path.join(CSRC, "libeonerf_hip.so")   # EONERF_LIB: A/B builds of the same ABI
 
-EONERF_FP32, EONERF_BF16 = 0, 1
+EONERF_FP32, EONERF_BF16, EONERF_F16X3 = 0, 1, 2
+PRECISIONS = {"fp32": EONERF_FP32, "bf16": EONERF_BF16, "fp16x3": EONERF_F16X3}
 F_SHADOWS, F_EVAL, F_TRAIN, F_ONLY_DEPTH, F_RGB_LOSS = 1, 2, 4, 8, 16
 
 SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy", "eonerf_param_tensors",

@@ -20,13 +20,14 @@ namespace {
 struct DevStream {
     uint8_t* data = nullptr; size_t bytes = 0;
     ChunkDesc* chunks = nullptr; int n_chunks = 0;
-    PackEntry *e16 = nullptr, *e32 = nullptr; int n16 = 0, n32 = 0;
+    PackEntry *e16 = nullptr, *e32 = nullptr, *e16lo = nullptr; int n16 = 0, n32 = 0, n16lo = 0;      // e16lo: lo halves of an fp16 x 3 stream
 };
 
 }  // namespace
 
 struct eonerf_ctx {
     eonerf_config cfg;
+    int prec;             // cfg.precision: EONERF_FP32 / EONERF_BF16 / EONERF_F16X3 (inference only)
     bool bf16;
     int n_cu;
     int wgrad_riders = 1;   // EONERF_WGRAD_RIDERS=0: the sigma row and the embedding columns as jobs of their own (A/B switch)
@@ -69,7 +70,7 @@ CarveCfg carve_cfg(const eonerf_ctx* ctx) {
 }
 
 int upload(DevStream& d, const PackedStream& s) {
-    d.bytes = s.bytes; d.n_chunks = (int)s.chunks.size(); d.n16 = (int)s.e16.size(); d.n32 = (int)s.e32.size();
+    d.bytes = s.bytes; d.n_chunks = (int)s.chunks.size(); d.n16 = (int)s.e16.size(); d.n32 = (int)s.e32.size(); d.n16lo = (int)s.e16lo.size();
     HIP_TRY(hipMalloc(&d.data, s.bytes + 1024));      // + slack: the chain kernels copy whole 1-KiB pieces (WStream::round)
     HIP_TRY(hipMemset(d.data, 0, s.bytes + 1024));
     HIP_TRY(hipMalloc(&d.chunks, s.chunks.size() * sizeof(ChunkDesc)));
@@ -82,6 +83,10 @@ int upload(DevStream& d, const PackedStream& s) {
         HIP_TRY(hipMalloc(&d.e32, s.e32.size() * sizeof(PackEntry)));
         HIP_TRY(hipMemcpy(d.e32, s.e32.data(), s.e32.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
     }
+    if (d.n16lo) {
+        HIP_TRY(hipMalloc(&d.e16lo, s.e16lo.size() * sizeof(PackEntry)));
+        HIP_TRY(hipMemcpy(d.e16lo, s.e16lo.data(), s.e16lo.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 void release(DevStream& d) {
@@ -89,13 +94,14 @@ void release(DevStream& d) {
     if (d.chunks) (void)hipFree(d.chunks);
     if (d.e16) (void)hipFree(d.e16);
     if (d.e32) (void)hipFree(d.e32);
+    if (d.e16lo) (void)hipFree(d.e16lo);
     d = DevStream();
 }
 
 // (re)packs the fp32 master weights into up to PACK_MAX_JOBS packed streams in ONE launch (blockIdx.y = job): after every
 // optimizer step three streams x {bf16, fp32} entries are rewritten, and six ~5 us launches cost more than the copies
 constexpr int PACK_MAX_JOBS = 16;
-struct PackJob { const PackEntry* e; int n; uint8_t* data; int is16; };
+struct PackJob { const PackEntry* e; int n; uint8_t* data; int kind; };      // kind: 0 fp32, 1 bf16, 2 fp16 (hi half of a split value), 3 its lo half
 struct PackJobs { PackJob j[PACK_MAX_JOBS]; };
 // sources >= fold_base come from the fold buffer (ParamLayout::fold_w / fold_b)
 __global__ void k_pack(const float* flat, const float* fold, int fold_base, PackJobs jobs) {
@@ -103,8 +109,12 @@ __global__ void k_pack(const float* flat, const float* fold, int fold_base, Pack
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
         const PackEntry pe = jb.e[i];
         const float v = pe.src < 0 ? 0.f : (pe.src >= fold_base ? fold[pe.src - fold_base] : flat[pe.src]);
-        if (jb.is16) *reinterpret_cast<__bf16*>(jb.data + pe.dst) = (__bf16)v;
-        else *reinterpret_cast<float*>(jb.data + pe.dst) = v;
+        if (jb.kind == 1) *reinterpret_cast<__bf16*>(jb.data + pe.dst) = (__bf16)v;
+        else if (jb.kind == 0) *reinterpret_cast<float*>(jb.data + pe.dst) = v;
+        else {
+            const _Float16 hi = (_Float16)v;
+            *reinterpret_cast<_Float16*>(jb.data + pe.dst) = jb.kind == 2 ? hi : (_Float16)(v - (float)hi);
+        }
     }
 }
 // (a stream set that needs more than PACK_MAX_JOBS jobs goes out in several launches: today's largest set is 9 streams, 13 jobs)
@@ -116,8 +126,9 @@ int pack(const eonerf_ctx* ctx, const std::vector<const DevStream*>& streams, co
         n = 0; most = 1;
     };
     for (const DevStream* d : streams) {
-        if (n + 2 > PACK_MAX_JOBS) flush();
-        if (d->n16) jobs.j[n++] = PackJob{d->e16, d->n16, d->data, 1};
+        if (n + 3 > PACK_MAX_JOBS) flush();
+        if (d->n16) jobs.j[n++] = PackJob{d->e16, d->n16, d->data, d->n16lo ? 2 : 1};
+        if (d->n16lo) jobs.j[n++] = PackJob{d->e16lo, d->n16lo, d->data, 3};
         if (d->n32) jobs.j[n++] = PackJob{d->e32, d->n32, d->data, 0};
         most = std::max(most, std::max(d->n16, d->n32));
     }
@@ -186,7 +197,8 @@ AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
 int ensure_density_streams(eonerf_ctx* ctx, const float* flat, hipStream_t st) {
     ctx->dens_used = true;
     if (!ctx->dens_dirty) return 0;
-    const int rc = ctx->pipe ? pack(ctx, {&ctx->fwd_dens, &ctx->bwd_dens, &ctx->bwd_dens_heads, &ctx->ig_tail_wt}, flat, st)
+    const int rc = ctx->prec == EONERF_F16X3 ? pack(ctx, {&ctx->fwd_dens}, flat, st)
+                 : ctx->pipe ? pack(ctx, {&ctx->fwd_dens, &ctx->bwd_dens, &ctx->bwd_dens_heads, &ctx->ig_tail_wt}, flat, st)
                              : pack(ctx, {&ctx->fwd_dens, &ctx->bwd_dens}, flat, st);
     if (!rc) ctx->dens_dirty = false;
     return rc;
@@ -207,9 +219,10 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     a.mask_from = (render_train && ctx->pipe) ? 7 : 0;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
-    if (prof_id < 0) return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, mode, grid, st);
+    if (ctx->prec == EONERF_F16X3 && mode != 0) return EONERF_E_UNSUPPORTED;      // the split precision is an inference precision
+    if (prof_id < 0) return (int)eo_launch_mlp_fwd(a, ctx->prec, full, mode, grid, st);
     ProfScope ps(ctx, prof_id, st);
-    return (int)eo_launch_mlp_fwd(a, ctx->bf16, full, mode, grid, st);
+    return (int)eo_launch_mlp_fwd(a, ctx->prec, full, mode, grid, st);
 }
 
 
@@ -402,11 +415,13 @@ const char* eonerf_strerror(int code) {
 int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     if (!out || !cfg || cfg->n_images < 1) return EONERF_E_ARG;
     if (cfg->n_samples != 128) return EONERF_E_UNSUPPORTED;
-    if (cfg->precision != EONERF_FP32 && cfg->precision != EONERF_BF16) return EONERF_E_ARG;
+    if (cfg->precision != EONERF_FP32 && cfg->precision != EONERF_BF16 && cfg->precision != EONERF_F16X3) return EONERF_E_ARG;
     eonerf_ctx* ctx = new (std::nothrow) eonerf_ctx();
     if (!ctx) return EONERF_E_ARG;
     ctx->cfg = *cfg;
+    ctx->prec = cfg->precision;
     ctx->bf16 = cfg->precision == EONERF_BF16;
+    const bool infer_only = cfg->precision == EONERF_F16X3;      // forward streams only
     { const char* e = getenv("EONERF_DETERMINISTIC"); ctx->deterministic = e && atoi(e) != 0; }
     { const char* e = getenv("EONERF_PIPE_PARTIALS"); ctx->pipe_partials = ctx->deterministic || (e && atoi(e) != 0); }
     int dev = 0;
@@ -416,12 +431,12 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     { const char* e = getenv("EONERF_WGRAD_ITEMS"); ctx->wgrad_items = e && atoi(e) > 0 ? atoi(e) : 0; }
     { const char* e = getenv("EONERF_WGRAD_RIDERS"); if (e) ctx->wgrad_riders = atoi(e); }
     ctx->pl.build(cfg->n_images);
-    int rc = upload(ctx->fwd_full, build_fwd_stream(ctx->pl, ctx->bf16, true));
-    if (!rc) rc = upload(ctx->fwd_dens, build_fwd_stream(ctx->pl, ctx->bf16, false));
-    if (!rc) rc = upload(ctx->bwd_full, build_bwd_stream(ctx->pl, ctx->bf16, true, false));
-    if (!rc) rc = upload(ctx->bwd_dens, build_bwd_stream(ctx->pl, ctx->bf16, false, true));
-    if (!rc) rc = upload(ctx->bwd_rgb, build_bwd_stream(ctx->pl, ctx->bf16, true, false, false));
-    if (!rc) rc = upload(ctx->bwd_full_ig, build_bwd_stream(ctx->pl, ctx->bf16, true, true, true));
+    int rc = upload(ctx->fwd_full, build_fwd_stream(ctx->pl, ctx->prec, true));
+    if (!rc) rc = upload(ctx->fwd_dens, build_fwd_stream(ctx->pl, ctx->prec, false));
+    if (!rc && !infer_only) rc = upload(ctx->bwd_full, build_bwd_stream(ctx->pl, ctx->bf16, true, false));
+    if (!rc && !infer_only) rc = upload(ctx->bwd_dens, build_bwd_stream(ctx->pl, ctx->bf16, false, true));
+    if (!rc && !infer_only) rc = upload(ctx->bwd_rgb, build_bwd_stream(ctx->pl, ctx->bf16, true, false, false));
+    if (!rc && !infer_only) rc = upload(ctx->bwd_full_ig, build_bwd_stream(ctx->pl, ctx->bf16, true, true, true));
     {
         const char* e = getenv("EONERF_PIPE");
         ctx->n_pipes = ctx->n_cu / PIPE_STAGES;
@@ -524,12 +539,14 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     // ride along when something has read them since the last re-pack (shadow pass on: they would be re-packed a few kernels later anyway)
     std::vector<const DevStream*> v;
     v.push_back(&ctx->fwd_full);
-    if (ctx->pipe) { v.push_back(&ctx->bwd_full_heads); v.push_back(&ctx->bwd_rgb_heads); }
+    if (ctx->prec == EONERF_F16X3) {}      // forward streams only
+    else if (ctx->pipe) { v.push_back(&ctx->bwd_full_heads); v.push_back(&ctx->bwd_rgb_heads); }
     else { v.push_back(&ctx->bwd_full); v.push_back(&ctx->bwd_rgb); }
     if (ctx->pipe) v.push_back(&ctx->pipe_wt);
     const bool with_dens = ctx->dens_used;
     if (with_dens) {      // the same set ensure_density_streams packs
-        v.push_back(&ctx->fwd_dens); v.push_back(&ctx->bwd_dens);
+        v.push_back(&ctx->fwd_dens);
+        if (ctx->prec != EONERF_F16X3) v.push_back(&ctx->bwd_dens);
         if (ctx->pipe) { v.push_back(&ctx->bwd_dens_heads); v.push_back(&ctx->ig_tail_wt); }
     }
     ctx->need_repack = false;
@@ -640,6 +657,7 @@ int eonerf_field_backward(eonerf_ctx* ctx, const float* flat, const float* sun, 
                           float* d_flat, float* d_xyz, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!ctx || !flat || !d_flat || n < 0 || !ws) return EONERF_E_ARG;
+    if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
     if (!density_only && g_ambient && !sun) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n == 0) return EONERF_OK;
@@ -887,6 +905,7 @@ int eonerf_rendering_backward(eonerf_ctx* ctx, const float* flat, const float* r
                               float* d_flat, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!ctx || !flat || !rays || !d_flat || n_rays < 1 || !ws) return EONERF_E_ARG;
+    if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
     if (!depth_only && !img_idx) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
     const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
@@ -973,6 +992,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     hipStream_t st = (hipStream_t)stream;
     if (!ctx || !flat || !rays || !img_idx || !d_out || !d_flat || n_rays < 0 || !ws) return EONERF_E_ARG;
     if (!(flags & EONERF_F_TRAIN) || (flags & EONERF_F_ONLY_DEPTH)) return EONERF_E_STATE;
+    if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n_rays == 0) return EONERF_OK;
     const bool shadows = flags & EONERF_F_SHADOWS;

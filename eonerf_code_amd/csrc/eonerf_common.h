@@ -41,7 +41,8 @@ EO_DEV constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 *
 // Precision policies
 // ------------------------------------------------------------------------------------------------
 struct PBf16 {
-    static constexpr bool IS_BF16 = true;
+    static constexpr bool IS_BF16 = true, IS_SPLIT = false;
+    static constexpr int UNIT_B = 1024;      // one A-operand unit (a k-group of one m-tile) in the packed streams and in LDS
     static constexpr int WAVES = 8, NT = 512, TILE = 256;
     static constexpr int KF = 16;            // features per k-group
     static constexpr int KG32 = 2;           // k-groups per 32 features
@@ -57,7 +58,8 @@ struct PBf16 {
 };
 
 struct PF32 {
-    static constexpr bool IS_BF16 = false;
+    static constexpr bool IS_BF16 = false, IS_SPLIT = false;
+    static constexpr int UNIT_B = 1024;
     static constexpr int WAVES = 4, NT = 256, TILE = 128;
     static constexpr int KF = 8;
     static constexpr int KG32 = 4;
@@ -75,6 +77,39 @@ struct PF32 {
     }
     EO_DEV static U zero() { U u = {0.f, 0.f, 0.f, 0.f}; return u; }
 };
+
+// Split precision for EXPORT renders (round 4): every operand is carried as hi + lo, two fp16 numbers (11 + 11 significant bits, lo in
+// fp16's subnormal range where it has to be: ~2^-21 relative, against 2^-24 for fp32 and 2^-17 for a bf16 pair), and a product is
+// three v_mfma_f32_32x32x16_f16 -- hi x hi + hi x lo + lo x hi, fp32 accumulate; lo x lo (2^-22 of the product) is dropped.  3/16 of
+// the matrix time of the fp32 path (v_mfma_f32_32x32x2_f32) at fp32-level accuracy on this network (measured against the fp32 oracle:
+// tests/test_bf16_fullsize.py).  Inference only: 4 waves x 512 registers like the fp32 policy (an activation costs 32 bits either way).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+struct F16Pair { f16x8 hi, lo; };
+struct PH3 {
+    static constexpr bool IS_BF16 = false, IS_SPLIT = true;
+    static constexpr int UNIT_B = 2048;      // [hi 1 KiB][lo 1 KiB]
+    static constexpr int WAVES = 4, NT = 256, TILE = 128;
+    static constexpr int KF = 16;
+    static constexpr int KG32 = 2;
+    static constexpr int NE = 8;
+    typedef F16Pair U;
+    typedef float act_t;                     // (never saved: no training in this precision)
+    static constexpr int ACT_BYTES = 4;
+    __host__ __device__ static constexpr int feat(int kg, int h, int e) { return 16 * kg + 8 * (e >> 2) + 4 * h + (e & 3); }      // as PBf16
+    EO_DEV static f32x16 mma(const U& a, const U& b, f32x16 c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);      // the small terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    EO_DEV static U zero() { U u; for (int i = 0; i < 8; ++i) { u.hi[i] = (_Float16)0.0f; u.lo[i] = (_Float16)0.0f; } return u; }
+};
+// element e of a unit := v (rounded to the policy's operand type)
+EO_DEV void set_elem(PBf16::U& u, int e, float v) { u[e] = (__bf16)v; }
+EO_DEV void set_elem(PF32::U& u, int e, float v) { u[e] = v; }
+EO_DEV void set_elem(PH3::U& u, int e, float v) { const _Float16 hv = (_Float16)v; u.hi[e] = hv; u.lo[e] = (_Float16)(v - (float)hv); }
+EO_DEV float get_elem(const PBf16::U& u, int e) { return (float)u[e]; }
+EO_DEV float get_elem(const PF32::U& u, int e) { return u[e]; }
+EO_DEV float get_elem(const PH3::U& u, int e) { return (float)u.hi[e] + (float)u.lo[e]; }
 
 // accumulator tile -> the KG32 B-operand units of the next layer (same feature order, no permutation)
 template <class P> struct Units32 { typename P::U u[P::KG32]; };
@@ -235,7 +270,14 @@ template <class P> struct TileSched {
 };
 
 template <class P> EO_DEV typename P::U lds_unit(const uint8_t* p) {
-    return *reinterpret_cast<const typename P::U*>(p);   // 16 B per lane -> ds_read_b128
+    if constexpr (P::IS_SPLIT) {      // hi and lo halves of the unit: two ds_read_b128
+        typename P::U u;
+        u.hi = *reinterpret_cast<const f16x8*>(p);
+        u.lo = *reinterpret_cast<const f16x8*>(p + 1024);
+        return u;
+    } else {
+        return *reinterpret_cast<const typename P::U*>(p);   // 16 B per lane -> ds_read_b128
+    }
 }
 
 // acc tile initialised with the 32 bias values of its m-tile (bias region of the chunk, fp32)
@@ -265,18 +307,23 @@ EO_DEV f32x16 zero_acc() { f32x16 a; for (int i = 0; i < 16; ++i) a[i] = 0.f; re
 // Chunk grouping of a layer (shared with the packer, eonerf_pack.cpp): its MT m-tiles are cut into the fewest chunks of at most
 // CHUNK_KG_TARGET k-group units (and 8 m-tiles), as even as possible -- e.g. a 256 x 256 layer (KG = 16, MT = 8) into 3 + 3 + 2
 // m-tiles.  Every chunk costs a workgroup barrier, so fewer, larger chunks; two chunk slots + the slab staging fill the LDS.
-constexpr int CHUNK_KG_TARGET = 48;
-__host__ __device__ constexpr int group_max(int kg, int mt) {
-    int g = CHUNK_KG_TARGET / kg;
+// (`target` = units a slot holds: 48 of 1 KiB for the bf16 / fp32 policies, whose kernels share the LDS with the slab staging; 32 of
+//  2 KiB for the split policy, inference only)
+constexpr int CHUNK_KG_TARGET = 48, CHUNK_KG_TARGET_SPLIT = 32;
+template <class P> constexpr int chunk_target() { return P::IS_SPLIT ? CHUNK_KG_TARGET_SPLIT : CHUNK_KG_TARGET; }
+__host__ __device__ constexpr int group_max(int kg, int mt, int target = CHUNK_KG_TARGET) {
+    int g = target / kg;
     g = g > 8 ? 8 : g;
     g = g > mt ? mt : g;
     return g < 1 ? 1 : g;
 }
-__host__ __device__ constexpr int n_groups(int kg, int mt) { return (mt + group_max(kg, mt) - 1) / group_max(kg, mt); }
-__host__ __device__ constexpr int group_size(int kg, int mt, int c) { return mt / n_groups(kg, mt) + (c < mt % n_groups(kg, mt) ? 1 : 0); }
-__host__ __device__ constexpr int group_start(int kg, int mt, int c) {
+__host__ __device__ constexpr int n_groups(int kg, int mt, int target = CHUNK_KG_TARGET) { return (mt + group_max(kg, mt, target) - 1) / group_max(kg, mt, target); }
+__host__ __device__ constexpr int group_size(int kg, int mt, int c, int target = CHUNK_KG_TARGET) {
+    return mt / n_groups(kg, mt, target) + (c < mt % n_groups(kg, mt, target) ? 1 : 0);
+}
+__host__ __device__ constexpr int group_start(int kg, int mt, int c, int target = CHUNK_KG_TARGET) {
     int s = 0;
-    for (int k = 0; k < c; ++k) s += group_size(kg, mt, k);
+    for (int k = 0; k < c; ++k) s += group_size(kg, mt, k, target);
     return s;
 }
 constexpr int EPI_SLICES = 8;
@@ -292,12 +339,12 @@ EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& 
     constexpr int MID0 = PLAST > MIDK ? PLAST : MIDK; // ... in the first m-tile: after the last prefetch round (the flush's stores
                                                       // must stay YOUNGER than the copy, see WStream::advance)
     constexpr int NF = G * KG;
-    constexpr int PF = NF < 4 ? NF : 4;
+    constexpr int PF = NF < 4 ? NF : (P::IS_SPLIT ? 3 : 4);      // (a split unit is two 16-byte reads and eight registers)
     const uint8_t* a = chunk + lane * 16;
     typename P::U fr[PF];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) fr[d] = lds_unit<P>(a + d * 1024);
-    f32x16 acc = BIAS ? bias_init(chunk + NF * 1024, h) : zero_acc();
+    for (int d = 0; d < PF; ++d) fr[d] = lds_unit<P>(a + d * P::UNIT_B);
+    f32x16 acc = BIAS ? bias_init(chunk + NF * P::UNIT_B, h) : zero_acc();
     f32x16 pend = zero_acc();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -308,9 +355,9 @@ EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& 
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             const int f = g * KG + kg;
-            if (BIAS && g + 1 < G && kg == BPOS) nxt = bias_init(chunk + NF * 1024 + (g + 1) * 128, h);
+            if (BIAS && g + 1 < G && kg == BPOS) nxt = bias_init(chunk + NF * P::UNIT_B + (g + 1) * 128, h);
             acc = P::mma(fr[f % PF], B(kg), acc);
-            if (!(EO_ABL & 2) && f + PF < NF) fr[f % PF] = lds_unit<P>(a + (f + PF) * 1024);
+            if (!(EO_ABL & 2) && f + PF < NF) fr[f % PF] = lds_unit<P>(a + (f + PF) * P::UNIT_B);
             if (g == 0) {
                 if (kg == PLAST) ws.pump_rest();
                 else if (kg < PLAST) ws.pump();
@@ -355,9 +402,10 @@ EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& 
 // `mid` provides the slab-flush hooks called a few MFMAs into every m-tile (or no-ops).
 template <class P, int SLOT, int KG, int MT, bool BIAS, int NST = 0, int C = 0, class Mid, class BArr, class Epi>
 EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BArr& B, Epi&& epi) {
-    if constexpr (C < n_groups(KG, MT)) {
-        constexpr int G = group_size(KG, MT, C), M0 = group_start(KG, MT, C);
-        static_assert(G * (KG * 1024 + 128) <= SLOT, "chunk does not fit the LDS slot");
+    constexpr int TG = chunk_target<P>();
+    if constexpr (C < n_groups(KG, MT, TG)) {
+        constexpr int G = group_size(KG, MT, C, TG), M0 = group_start(KG, MT, C, TG);
+        static_assert(G * (KG * P::UNIT_B + 128) <= SLOT, "chunk does not fit the LDS slot");
         ws.prefetch_next();
         chunk_compute<P, KG, G, BIAS>(ws, lane, h, B, M0, epi, mid);
         // stores younger than the copy (LOWER bound, see WStream::advance).  bf16: one flush (NST = 2 stores) per m-tile once the
@@ -381,6 +429,7 @@ typedef __attribute__((ext_vector_type(2))) short s16x2;
 template <class P> struct Sl;
 template <> struct Sl<PBf16> { uint32_t w; };
 template <> struct Sl<PF32> { float v0, v1; };
+template <> struct Sl<PH3> { uint32_t hi, lo; };      // packed fp16 pairs
 
 // forward: ReLU + mask bits of slice s; `bits` collects the tile's flags (reset by slice 0)
 EO_DEV Sl<PBf16> relu_slice(PBf16, const f32x16& acc, int s, uint32_t& bits) {
@@ -400,6 +449,30 @@ EO_DEV Sl<PF32> relu_slice(PF32, const f32x16& acc, int s, uint32_t& bits) {
     const uint32_t t = (p0 ? (1u << (2 * s)) : 0u) | (p1 ? (2u << (2 * s)) : 0u);
     bits = s == 0 ? t : (bits | t);
     return Sl<PF32>{p0 ? a0 : 0.f, p1 ? a1 : 0.f};
+}
+// split policy: two fp32 -> (hi, lo) packed fp16 pairs, round to nearest even
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+EO_DEV Sl<PH3> split_pair(float a0, float a1) {
+    const f32x2 p = {a0, a1};
+    const f16x2 hi = __builtin_convertvector(p, f16x2);
+    const f32x2 back = __builtin_convertvector(hi, f32x2);
+    const f32x2 rem = {a0 - back[0], a1 - back[1]};
+    const f16x2 lo = __builtin_convertvector(rem, f16x2);
+    return Sl<PH3>{__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo)};
+}
+EO_DEV Sl<PH3> relu_slice(PH3, const f32x16& acc, int s, uint32_t& bits) {      // (no masks in this precision: inference only)
+    const float a0 = acc[2 * s], a1 = acc[2 * s + 1];
+    bits = 0;
+    return split_pair(a0 > 0.f ? a0 : 0.f, a1 > 0.f ? a1 : 0.f);
+}
+EO_DEV Sl<PH3> relu_only_slice(PH3, const f32x16& acc, int s) { uint32_t b; return relu_slice(PH3(), acc, s, b); }
+EO_DEV void mask_commit(PH3, int, uint32_t, uint32_t&) {}
+EO_DEV Sl<PH3> pack_slice(PH3, const f32x16& acc, int s) { return split_pair(acc[2 * s], acc[2 * s + 1]); }
+EO_DEV void put_slice(PH3, F16Pair* arr, int mt, int s, const Sl<PH3>& v) {      // same place as the bf16 policy, in both halves
+    u32x4 th = __builtin_bit_cast(u32x4, arr[2 * mt + (s >> 2)].hi), tl = __builtin_bit_cast(u32x4, arr[2 * mt + (s >> 2)].lo);
+    th[s & 3] = v.hi; tl[s & 3] = v.lo;
+    arr[2 * mt + (s >> 2)].hi = __builtin_bit_cast(f16x8, th);
+    arr[2 * mt + (s >> 2)].lo = __builtin_bit_cast(f16x8, tl);
 }
 // forward, ReLU only (nobody reads this layer's mask bits)
 EO_DEV Sl<PBf16> relu_only_slice(PBf16, const f32x16& acc, int s) {
@@ -487,6 +560,15 @@ struct SlabWriterBase {
         return __builtin_amdgcn_make_buffer_rsrc(slab + (size_t)b.s * nt * SEG_B, 0, b.r * nt * SEG_B, 0x00020000);
     }
     EO_DEV uint32_t block_off(SlabBlk b, int row) const { return (((EO_ABL & 16) ? 0 : tile0) * b.r + (row - b.s)) * SEG_B; }   // EO_ABL 16: every wave writes sample tile 0 (stores stay in L2)
+};
+
+template <class Map> struct SlabWriter<PH3, Map> : NoSlab {      // never instantiated for training: the hooks of an inference chain
+    static constexpr int LDS_BYTES = 0;
+    static constexpr int FLUSH_STORES = 0;
+    EO_DEV void init(void*, int, int, int, uint8_t*) {}
+    EO_DEV void stage(int, int, const Sl<PH3>&) {}
+    EO_DEV void elem(int, float) const {}
+    EO_DEV void drain() {}
 };
 
 template <class Map> struct SlabWriter<PF32, Map> : SlabWriterBase {

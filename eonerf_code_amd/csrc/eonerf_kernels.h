@@ -63,7 +63,7 @@ constexpr int MASK_SLOTS_FULL = 13;                 // trunk 0..7, A1, T1..T4
 constexpr int MASK_SLOTS_DENSITY = 8;
 
 // LDS slot (one packed weight chunk; grouping: eonerf_common.h)
-template <class P> struct FwdSlot { static constexpr int BYTES = CHUNK_KG_TARGET * 1024 + 1024; };
+template <class P> struct FwdSlot { static constexpr int BYTES = chunk_target<P>() * P::UNIT_B + 1024; };
 
 struct MlpFwdArgs {
     const float *px, *py, *pz;     // [p_pad] compact sample positions (SoA)
@@ -157,7 +157,7 @@ hipError_t eo_launch_ig_tail(const IgTailArgs& a, int n_wg, hipStream_t st);
 size_t eo_bwd_pipe_lds_bytes();
 bool eo_bwd_pipe_fits_a_cu();
 
-hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st);
+hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, int prec, bool full, int mode, int grid, hipStream_t st);      // prec: 0 fp32, 1 bf16, 2 fp16 x 3 (inference)
 // pipe: 0 = the whole dX chain; 1 = stop at dY_7 (the trunk is pipelined)
 hipError_t eo_launch_mlp_bwd(const MlpBwdArgs& a, bool bf16, bool full, bool input_grad, bool transient, int grid, hipStream_t st, int pipe = 0);
 constexpr int WGRAD_MAX_JOBS = 32;     // <= 31 used (fp32 chain + GEMM path, full model); the table must fit the 4-KiB kernel-argument segment

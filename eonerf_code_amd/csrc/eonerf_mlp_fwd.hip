@@ -37,7 +37,7 @@ EO_DEV EncUnits<P> encode_position(float x, float y, float z, int h) {
             } else {
                 v = h ? 0.0f : y;
             }
-            if constexpr (P::IS_BF16) E.u[kg][e] = (__bf16)v; else E.u[kg][e] = v;
+            set_elem(E.u[kg], e, v);
         }
     return E;
 }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
 #pragma unroll
             for (int kg = 0; kg < EKG; ++kg)      // encoding slots, rows [0,64)
 #pragma unroll
-                for (int e = 0; e < P::NE; ++e) sw.elem(ACT_ROW_ENC + P::feat(kg, 0, e), (float)E.u[kg][e]);
+                for (int e = 0; e < P::NE; ++e) sw.elem(ACT_ROW_ENC + P::feat(kg, 0, e), get_elem(E.u[kg], e));
         }
 
         auto& mid = sw;          // run_layer's slab-flush hooks
@@ -192,11 +192,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                 const int im = live ? a.simg[p] : 0;
                 const f32x4 ev = *reinterpret_cast<const f32x4*>(a.emb + 4 * im);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { if constexpr (P::IS_BF16) EMB[e] = (__bf16)ev[e]; else EMB[e] = ev[e]; }
+                for (int e = 0; e < 4; ++e) set_elem(EMB, e, ev[e]);
             }
             if constexpr (TSAVE) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sw.elem(ACT_ROW_EMB + e, (float)EMB[e]);
+                for (int e = 0; e < 4; ++e) sw.elem(ACT_ROW_EMB + e, get_elem(EMB, e));
             }
             U T1[QKG], T2[QKG];
             run_layer<P, SLOT, HKG + 1, 4, true, NST_T>(ws, mid, lane, h,
@@ -247,7 +247,13 @@ template <class P> hipError_t dispatch(const MlpFwdArgs& a, bool full, int mode,
 }  // namespace
 
 // mode: 0 inference, 1 training, 2 training with the transient head outside the autograd graph (full variant only)
-hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, bool bf16, bool full, int mode, int grid, hipStream_t st) {
+// prec: 0 fp32, 1 bf16, 2 fp16 x 3 split (inference only)
+hipError_t eo_launch_mlp_fwd(const MlpFwdArgs& a, int prec, bool full, int mode, int grid, hipStream_t st) {
+    if (prec == 2) {
+        if (mode != 0) return hipErrorInvalidValue;
+        return full ? launch<PH3, true, 0>(a, grid, st) : launch<PH3, false, 0>(a, grid, st);
+    }
+    const bool bf16 = prec == 1;
     if (bf16 && mode != 0 && a.mask_from >= 7) {      // training pass in front of the pipelined trunk backward: no trunk mask bits
         if (!full) return launch<PBf16, false, 1, false>(a, grid, st);
         return mode == 1 ? launch<PBf16, true, 1, false>(a, grid, st) : launch<PBf16, true, 2, false>(a, grid, st);

@@ -55,12 +55,15 @@ int enc_col_of_slot(bool bf16, int slot) {
     return enc_col_of_hq(h, q);
 }
 
-void append_layer(PackedStream& s, bool bf16, const PackLayer& L) {
-    const int ne = bf16 ? 8 : 4, esz = bf16 ? 2 : 4;
-    for (int mg = 0; mg < n_groups(L.KG, L.MT); ++mg) {          // the chunk grouping run_layer walks (eonerf_common.h)
-        const int G = group_size(L.KG, L.MT, mg), m0 = group_start(L.KG, L.MT, mg);
+// prec: 0 fp32, 1 bf16, 2 the fp16 x 3 split (PH3: 16-feature k-groups in the bf16 fragment order, units of 2 KiB = [hi][lo])
+void append_layer(PackedStream& s, int prec, const PackLayer& L) {
+    const bool f32 = prec == 0, split = prec == 2;
+    const int ne = f32 ? 4 : 8, esz = f32 ? 4 : 2, ub = split ? PH3::UNIT_B : 1024;
+    const int tg = split ? CHUNK_KG_TARGET_SPLIT : CHUNK_KG_TARGET;
+    for (int mg = 0; mg < n_groups(L.KG, L.MT, tg); ++mg) {          // the chunk grouping run_layer walks (eonerf_common.h)
+        const int G = group_size(L.KG, L.MT, mg, tg), m0 = group_start(L.KG, L.MT, mg, tg);
         const uint32_t off = (uint32_t)s.bytes;
-        const uint32_t bytes = (uint32_t)(G * (L.KG * 1024 + 128));
+        const uint32_t bytes = (uint32_t)(G * (L.KG * ub + 128));
         s.chunks.push_back(ChunkDesc{off, bytes});
         for (int g = 0; g < G; ++g) {
             const int mt = m0 + g;
@@ -68,13 +71,14 @@ void append_layer(PackedStream& s, bool bf16, const PackLayer& L) {
                 for (int lane = 0; lane < 64; ++lane) {
                     const int r = lane & 31, h = lane >> 5;
                     for (int e = 0; e < ne; ++e) {
-                        const int slot = bf16 ? PBf16::feat(kg, h, e) : PF32::feat(kg, h, e);
-                        PackEntry pe{off + (uint32_t)((g * L.KG + kg) * 1024 + lane * 16 + e * esz), L.w(32 * mt + r, slot)};
-                        (bf16 ? s.e16 : s.e32).push_back(pe);
+                        const int slot = f32 ? PF32::feat(kg, h, e) : PBf16::feat(kg, h, e);
+                        PackEntry pe{off + (uint32_t)((g * L.KG + kg) * ub + lane * 16 + e * esz), L.w(32 * mt + r, slot)};
+                        (f32 ? s.e32 : s.e16).push_back(pe);
+                        if (split) { pe.dst += 1024; s.e16lo.push_back(pe); }
                     }
                 }
             for (int i = 0; i < 32; ++i) {
-                PackEntry pe{off + (uint32_t)(G * L.KG * 1024 + g * 128 + i * 4), L.bias ? L.b(32 * mt + i) : -1};
+                PackEntry pe{off + (uint32_t)(G * L.KG * ub + g * 128 + i * 4), L.bias ? L.b(32 * mt + i) : -1};
                 s.e32.push_back(pe);
             }
         }
@@ -82,23 +86,24 @@ void append_layer(PackedStream& s, bool bf16, const PackLayer& L) {
     }
 }
 
-PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full) {
+PackedStream build_fwd_stream(const ParamLayout& pl, int prec, bool full) {
     PackedStream s;
+    const bool bf16 = prec != 0;             // fragment order and k-group width of the 16-bit policies (bf16, fp16 x 3)
     const int KF = bf16 ? 16 : 8;
     const int HKG = 256 / KF, QKG = 128 / KF, EKG = 64 / KF;
     auto dense = [&](int wi, int bi, int out_rows, int in_cols, int KG, int MT) {
         PackLayer L{KG, MT, true,
             [=, &pl](int row, int slot) { return (row < out_rows && slot < in_cols) ? pl.at(wi, row, slot) : -1; },
             [=, &pl](int row) { return row < out_rows ? pl.at(bi, 0, row) : -1; }};
-        append_layer(s, bf16, L);
+        append_layer(s, prec, L);
     };
     // trunk layer 0: encoding slots -> columns of W0
-    append_layer(s, bf16, PackLayer{EKG, 8, true,
+    append_layer(s, prec, PackLayer{EKG, 8, true,
         [&, bf16](int row, int slot) { const int c = enc_col_of_slot(bf16, slot); return c >= 0 ? pl.at(pl.trunk_w[0], row, c) : -1; },
         [&](int row) { return pl.at(pl.trunk_b[0], 0, row); }});
     for (int l = 1; l < 8; ++l) {
         if (l == 5) {   // [h(256), enc slots(64)] -> columns [0,256) and 256 + enc column (mlp.py:92-97)
-            append_layer(s, bf16, PackLayer{HKG + EKG, 8, true,
+            append_layer(s, prec, PackLayer{HKG + EKG, 8, true,
                 [&, bf16](int row, int slot) {
                     if (slot < 256) return pl.at(pl.trunk_w[5], row, slot);
                     const int c = enc_col_of_slot(bf16, slot - 256);
@@ -110,7 +115,7 @@ PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full) {
         }
     }
     if (!full) {      // one m-tile: the sigma row (sigma_layer)
-        append_layer(s, bf16, PackLayer{HKG, 1, true,
+        append_layer(s, prec, PackLayer{HKG, 1, true,
             [&](int row, int slot) { return row == 0 ? pl.at(pl.sig_w, 0, slot) : -1; },
             [&](int row) { return row == 0 ? pl.at(pl.sig_b, 0, 0) : -1; }});
         return s;
@@ -118,16 +123,16 @@ PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full) {
     // m-tiles 0..3 = the albedo head's first layer FOLDED with the bottleneck layer (eonerf_pack.h: the kernels never evaluate the
     // bottleneck itself), m-tile 4 = sigma row.  (The sigma tile comes LAST: it saves nothing, and the counted wait of a chunk barrier
     // -- run_layer / WStream::advance -- relies on a slab flush from a layer's third m-tile on.)
-    append_layer(s, bf16, PackLayer{HKG, 5, true,
+    append_layer(s, prec, PackLayer{HKG, 5, true,
         [&](int row, int slot) { return row < 128 ? pl.fold_w(row, slot) : (row == 128 ? pl.at(pl.sig_w, 0, slot) : -1); },
         [&](int row) { return row < 128 ? pl.fold_b(row) : (row == 128 ? pl.at(pl.sig_b, 0, 0) : -1); }});
     dense(pl.a2_w, pl.a2_b, 3, 128, QKG, 1);
     // transient head's first layer on [X_8 (folded with the bottleneck), emb(img)]: slots 256..259 = embedding columns
-    append_layer(s, bf16, PackLayer{HKG + 1, 4, true,
+    append_layer(s, prec, PackLayer{HKG + 1, 4, true,
         [&](int row, int slot) { return slot < 256 ? pl.fold_w(128 + row, slot) : (slot < 260 ? pl.at(pl.t_w[0], row, slot) : -1); },
         [&](int row) { return pl.fold_b(128 + row); }});
     for (int l = 1; l < 4; ++l) dense(pl.t_w[l], pl.t_b[l], 128, 128, QKG, 4);
-    append_layer(s, bf16, PackLayer{QKG, 1, true,
+    append_layer(s, prec, PackLayer{QKG, 1, true,
         [&](int row, int slot) { return row == 0 ? pl.at(pl.tsc_w, 0, slot) : (row == 1 ? pl.at(pl.tbe_w, 0, slot) : -1); },
         [&](int row) { return row == 0 ? pl.at(pl.tsc_b, 0, 0) : (row == 1 ? pl.at(pl.tbe_b, 0, 0) : -1); }});
     return s;

@@ -40,7 +40,8 @@ struct PackEntry { uint32_t dst; int32_t src; };     // dst: byte offset into th
 
 struct PackedStream {
     std::vector<ChunkDesc> chunks;
-    std::vector<PackEntry> e16;     // bf16 destinations
+    std::vector<PackEntry> e16;     // 16-bit destinations (bf16; fp16 x 3 split: the hi halves)
+    std::vector<PackEntry> e16lo;   // fp16 x 3 split: the lo halves (value - float(fp16(value)), rounded to fp16)
     std::vector<PackEntry> e32;     // fp32 destinations
     size_t bytes = 0;
 };
@@ -52,8 +53,8 @@ struct PackLayer {
     std::function<int(int row)> b;               // flat index of the bias of output row `row`
 };
 
-void append_layer(PackedStream& s, bool bf16, const PackLayer& L);
-PackedStream build_fwd_stream(const ParamLayout& pl, bool bf16, bool full);
+void append_layer(PackedStream& s, int prec, const PackLayer& L);      // prec: 0 fp32, 1 bf16, 2 fp16 x 3 split (forward streams only)
+PackedStream build_fwd_stream(const ParamLayout& pl, int prec, bool full);
 // heads: 0 = the whole chain; 1 = the stream ends behind the [dY_A1, dY_T1, d sigma_pre] -> dX8 layer (the chain kernel's PIPE 1 variant
 // leaves the trunk to eonerf_bwd_pipe.hip).  The stream is consumed cyclically, so it must hold exactly the layers one tile walks.
 PackedStream build_bwd_stream(const ParamLayout& pl, bool bf16, bool full, bool input_grad, bool transient = true, int heads = 0);

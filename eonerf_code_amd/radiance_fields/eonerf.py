@@ -144,16 +144,19 @@ class EONerfMLP(nn.Module):
         self.transient_beta = DenseLayer(self.transient_mlp.output_dim, 1)
         self.ambient_mlp = MLP(self.view_encoder.latent_dim, 3, 1, net_width // 2, None)
 
+        # "fp16x3": an INFERENCE precision (every operand as hi + lo fp16, three fp16 MFMAs per product: fp32-level accuracy at a fraction
+        # of the fp32 path's time); a module created with it renders and evaluates, training calls raise (EONERF_E_UNSUPPORTED)
         self.precision = (precision or os.environ.get("EONERF_PRECISION", "bf16")).lower()
-        if self.precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be 'bf16', 'fp32' or 'fp16x3' (inference only)")
         # EXPORT renders (render_image(eval=True), or a module in .eval() mode under no_grad: eval_eonerf.py:311-324, the validation
-        # of train_eonerf.py:197-226 -- where DSMs and their MAE come from) run in fp32 whatever the training precision: on identical
-        # weights the fp32 kernels match the reference arithmetic to 1e-4 (altitude well inside 1 cm), while the bf16 kernels move
-        # the rendered surface of a trained field by ~1 cm per ray (weight rounding of the trunk).  "same": no switch.
-        self.eval_precision = (eval_precision or os.environ.get("EONERF_EVAL_PRECISION", "fp32")).lower()
-        if self.eval_precision not in ("fp32", "same"):
-            raise ValueError("eval_precision must be 'fp32' or 'same'")
+        # of train_eonerf.py:197-226 -- where DSMs and their MAE come from) do not run in bf16 whatever the training precision: on
+        # identical weights the fp32-accurate kernels match the reference arithmetic to 1e-4 (altitude well inside 1 cm), while the bf16
+        # kernels move the rendered surface of a trained field by ~1 cm per ray (weight rounding of the trunk).
+        # "fp16x3" (default since round 4): the split precision above, ~5x faster than "fp32" (exact fp32 FMA chains); "same": no switch.
+        self.eval_precision = (eval_precision or os.environ.get("EONERF_EVAL_PRECISION", "fp16x3")).lower()
+        if self.eval_precision not in ("fp32", "fp16x3", "same"):
+            raise ValueError("eval_precision must be 'fp16x3', 'fp32' or 'same'")
         self._ctx = None          # eonerf_ctx*
         self._ctx_eval = None     # second native context (fp32) for export renders of a bf16 field, created on first use
         self._packed_version_eval = None
@@ -169,8 +172,7 @@ class EONerfMLP(nn.Module):
     def _context(self):
         if self._ctx is None:
             L = _lib.lib()
-            cfg = _lib.EonerfConfig(self.n_input_images, _lib.EONERF_BF16 if self.precision == "bf16" else _lib.EONERF_FP32,
-                                    128, 1 if self.radiometric_normalization else 0)
+            cfg = _lib.EonerfConfig(self.n_input_images, _lib.PRECISIONS[self.precision], 128, 1 if self.radiometric_normalization else 0)
             ctx = C.c_void_p()
             _lib.check(L.eonerf_create(C.byref(ctx), C.byref(cfg)))
             self._ctx = ctx
@@ -189,13 +191,13 @@ class EONerfMLP(nn.Module):
 
     def _native(self, export=False):
         """(context, flat parameters) to run a call on, packed weights up to date.  export=True on a bf16 module with
-        eval_precision="fp32": the module's second, fp32 context over the SAME flat parameter buffer."""
-        if not (export and self.precision == "bf16" and self.eval_precision == "fp32"):
+        eval_precision "fp16x3" / "fp32": the module's second context, of that precision, over the SAME flat parameter buffer."""
+        if not (export and self.precision == "bf16" and self.eval_precision != "same"):
             return self._context(), self._ensure_packed()
         flat = self.flat_params()
         L = _lib.lib()
         if self._ctx_eval is None:
-            cfg = _lib.EonerfConfig(self.n_input_images, _lib.EONERF_FP32, 128, 1 if self.radiometric_normalization else 0)
+            cfg = _lib.EonerfConfig(self.n_input_images, _lib.PRECISIONS[self.eval_precision], 128, 1 if self.radiometric_normalization else 0)
             ctx = C.c_void_p()
             _lib.check(L.eonerf_create(C.byref(ctx), C.byref(cfg)))
             self._ctx_eval = ctx

@@ -28,7 +28,10 @@ enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE
 
 /* arithmetic of the MLP GEMMs */
 enum { EONERF_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (parity mode, 1e-4 vs the reference) */
-       EONERF_BF16 = 1 }; /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (throughput mode) */
+       EONERF_BF16 = 1,   /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (throughput mode) */
+       EONERF_F16X3 = 2 }; /* INFERENCE only (export renders): every operand as hi + lo fp16, three v_mfma_f32_32x32x16_f16 per product, fp32
+                            * accumulate: fp32-level accuracy at 3/16 of the fp32 path's matrix time.  Training entry points (EONERF_F_TRAIN,
+                            * *_train, *_backward) return EONERF_E_UNSUPPORTED */
 
 /* flags of eonerf_render_forward */
 enum { EONERF_F_SHADOWS = 1,     /* epoch_idx >= 2: shadow-ray pass + s = geo_shadow * transient_s (sat_rendering.py:269-276) */
@@ -44,7 +47,7 @@ typedef struct eonerf_ctx eonerf_ctx;
 
 typedef struct {
     int n_images;        /* EONerfMLP(n_input_images), radiance_fields/eonerf.py:70-77 */
-    int precision;       /* EONERF_FP32 | EONERF_BF16 */
+    int precision;       /* EONERF_FP32 | EONERF_BF16 | EONERF_F16X3 */
     int n_samples;       /* int(2/render_step_size); only 128 is supported (run_JAX_RGB.sh:11, sat_rendering.py:64) */
     int radiometric;     /* radiometric_normalization (opt.py:98-99 forces 1 for eo-nerf) */
 } eonerf_config;

@@ -30,6 +30,7 @@ static void check_stream(const char* name, const PackedStream& s, const ParamLay
         }
     };
     walk(s.e16, 2);
+    walk(s.e16lo, 2);
     walk(s.e32, 4);
     size_t covered = 0;
     for (uint8_t h : hit) covered += h;
@@ -38,7 +39,8 @@ static void check_stream(const char* name, const PackedStream& s, const ParamLay
         size_t off = 0;
         for (const ChunkDesc& c : s.chunks) {
             CHECK(c.off == off, "%s: chunk table not contiguous", name);
-            CHECK(c.bytes <= (uint32_t)(CHUNK_KG_TARGET * 1024 + 1024), "%s: chunk of %u bytes exceeds the LDS slot", name, c.bytes);
+            const uint32_t slot = s.e16lo.empty() ? (uint32_t)(CHUNK_KG_TARGET * 1024 + 1024) : (uint32_t)(CHUNK_KG_TARGET_SPLIT * PH3::UNIT_B + 1024);
+            CHECK(c.bytes <= slot, "%s: chunk of %u bytes exceeds the LDS slot", name, c.bytes);
             CHECK(c.bytes % 128 == 0, "%s: chunk size %u", name, c.bytes);
             off += c.bytes;
         }
@@ -65,6 +67,13 @@ static void check_layout(int n_img) {
         check_stream(("bwd full ig " + tag).c_str(), build_bwd_stream(pl, bf16, true, true, true), pl, true);
         check_stream(("bwd rgb " + tag).c_str(), build_bwd_stream(pl, bf16, true, false, false), pl, true);
         check_stream(("bwd dens " + tag).c_str(), build_bwd_stream(pl, bf16, false, true), pl, true);
+    }
+    {   // fp16 x 3 split (inference): hi and lo halves of every unit, same sources
+        const PackedStream sf = build_fwd_stream(pl, 2, true), sd = build_fwd_stream(pl, 2, false);
+        check_stream("fwd full fp16x3", sf, pl, true);
+        check_stream("fwd dens fp16x3", sd, pl, true);
+        CHECK(sf.e16.size() == sf.e16lo.size() && sf.e16.size() == build_fwd_stream(pl, 1, true).e16.size(), "split stream: one hi and one lo entry per bf16-stream element");
+        for (size_t k = 0; k < sf.e16.size(); ++k) CHECK(sf.e16lo[k].dst == sf.e16[k].dst + 1024 && sf.e16lo[k].src == sf.e16[k].src, "lo entry %zu", k);
     }
     check_stream("bwd full heads", build_bwd_stream(pl, true, true, false, true, 1), pl, true);
     check_stream("bwd rgb heads", build_bwd_stream(pl, true, true, false, false, 1), pl, true);
