@@ -291,12 +291,13 @@ class EONerfMLP(nn.Module):
             self._ensure_packed()
             return _FieldFn.apply(self, True, xs, None, None, *self.parameters()).view(*shape, 1)
         with torch.no_grad():
-            flat = self._ensure_packed()
+            # a module in .eval() mode evaluates on the export context, like its renders do (one checkpoint, one arithmetic)
+            native, flat = self._native(export=not self.training)
             sigma = torch.empty(n, dtype=torch.float32, device=xs.device)
             L = _lib.lib()
-            nb = L.eonerf_field_workspace_bytes(self._ctx, n)
+            nb = L.eonerf_field_workspace_bytes(native, n)
             ws = self._workspace("field", nb)
-            _lib.check(L.eonerf_query_density(self._ctx, _ptr(flat), _ptr(xs), n, _ptr(sigma), _ptr(ws), ws.numel(), _stream()))
+            _lib.check(L.eonerf_query_density(native, _ptr(flat), _ptr(xs), n, _ptr(sigma), _ptr(ws), ws.numel(), _stream()))
         return sigma.view(*shape, 1)
 
     def query_opacity(self, x, step_size):
@@ -315,14 +316,14 @@ class EONerfMLP(nn.Module):
             self._ensure_packed()
             return _FieldFn.apply(self, False, xs, sun, img, *self.parameters())
         with torch.no_grad():
-            flat = self._ensure_packed()
+            native, flat = self._native(export=not self.training)
             dev = xs.device
             sigma, ts, tb = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
             albedo, ambient = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(2))
             L = _lib.lib()
-            nb = L.eonerf_field_workspace_bytes(self._ctx, n)
+            nb = L.eonerf_field_workspace_bytes(native, n)
             ws = self._workspace("field", nb)
-            _lib.check(L.eonerf_field_forward(self._ctx, _ptr(flat), _ptr(xs), _ptr(sun), _ptr(img), n, _ptr(sigma), _ptr(albedo),
+            _lib.check(L.eonerf_field_forward(native, _ptr(flat), _ptr(xs), _ptr(sun), _ptr(img), n, _ptr(sigma), _ptr(albedo),
                                               _ptr(ambient), _ptr(ts), _ptr(tb), _ptr(ws), ws.numel(), _stream()))
         return sigma.view(n, 1), albedo, ambient, ts.view(n, 1), tb.view(n, 1)
 
