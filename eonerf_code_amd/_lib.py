@@ -39,10 +39,18 @@ class EonerfConfig(C.Structure):
 
 def build(verbose=False):
     """Compile libeonerf_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile"]
+    # up to date?  Decided by CONTENT (a digest of every source, kept beside the library), not by time stamps: a snapshot copied to the
+    # GPU box may carry arbitrary mtimes, and the object files do not travel -- a current library must never be rebuilt there
+    import hashlib
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile")
     srcs.append(os.path.join(_HERE, "..", "include", "eonerf_hip.h"))
-    if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in srcs):
-        return LIB_PATH         # up to date (the object files do not travel to the GPU box: never rebuild a current library there)
+    h = hashlib.sha1()
+    for f in srcs:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    digest, stamp = h.hexdigest(), os.path.join(CSRC, "libeonerf_hip.digest")
+    if os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest and not os.environ.get("EONERF_LIB"):
+        return LIB_PATH
     cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
@@ -50,6 +58,8 @@ def build(verbose=False):
         print(r.stderr[-8000:])
     if r.returncode:
         raise RuntimeError("building libeonerf_hip.so failed")
+    with open(stamp, "w") as fh:
+        fh.write(digest + "\n")
     return LIB_PATH
 
 
