@@ -641,6 +641,7 @@ int eonerf_field_forward_train(eonerf_ctx* ctx, const float* flat, const float* 
     const bool full = !density_only;
     FieldTrainWs w = carve_field_train(ctx, ws, p_cap, full);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    if (ctx->need_repack) { const int rcr = eonerf_set_weights(ctx, flat, stream); if (rcr) return rcr; }      // (after the fault fallback)
     HIP_TRY(eo_launch_points_to_soa(xyz, full ? img : nullptr, n, p_cap, w.b.px, w.b.py, w.b.pz, w.b.simg, w.b.n_pts, st));
     int rc = run_mlp_fwd(ctx, w.b, flat, p_cap, full, 1, st);
     if (rc) return rc;
@@ -876,6 +877,7 @@ int eonerf_rendering_train(eonerf_ctx* ctx, const float* flat, const float* rays
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n > n_rays * 127) return EONERF_E_UNSUPPORTED;           // at most 127 intervals per ray (n_samples = 128)
     if (n_rays > (1 << 24) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays))) return EONERF_E_UNSUPPORTED;
+    if (ctx->need_repack) { const int rcr = eonerf_set_weights(ctx, flat, stream); if (rcr) return rcr; }      // (after the fault fallback)
     const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;

@@ -85,7 +85,7 @@ struct AmbientBwdArgs {
 // The bottleneck layer has an identity activation: bott = W_bott X8 + b_bott feeds the first layers of the albedo and transient heads.
 // With the factors  M_a = dA1^T X8  (and M_t = dT1^T X8) and the bias gradients db_A1 = sum_p dA1 (db_T1) -- ONE weight-gradient job
 // against X8 -- three weight gradients follow without the d bottleneck tensor and without the bottleneck OUTPUT ever being saved:
-//     dW_bott += W_A1^T M_a (+ W_T1^T M_t)             db_bott += W_A1^T db_A1 (+ W_T1^T db_T1)          (see k_mlp_bwd, bott_epi)
+//     dW_bott += W_A1^T M_a (+ W_T1^T M_t)             db_bott += W_A1^T db_A1 (+ W_T1^T db_T1)          (d bottleneck itself is never formed: eonerf_pack.h)
 //     dW_A1   += M_a W_bott^T + db_A1 (x) b_bott       (since sum_p dA1 bott^T = sum_p dA1 (W_bott X8 + b_bott)^T)     db_A1 -> d_flat
 //     dW_T1[:, :256] += M_t W_bott^T + db_T1 (x) b_bott                                                               db_T1 -> d_flat
 struct BottWgradArgs {
