@@ -106,7 +106,7 @@ def test_watchdog_drains_the_launch_quickly_reports_and_gates_the_update():
     t0 = time.time()
     tr.step(rays, img, rgbs, 0)
     torch.cuda.synchronize()
-    assert time.time() - t0 < 0.25
+    assert time.time() - t0 < 0.29                        # (one watchdog timeout alone is 0.3 s)
     tr.check_device_status()
     assert not torch.equal(tr.flat.detach(), p0)
     # a healthy field next to it still trains on the pipelined path
