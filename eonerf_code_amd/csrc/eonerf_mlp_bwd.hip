@@ -66,6 +66,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             if (nwords == 4) { const u32x4 v = *reinterpret_cast<const u32x4*>(mp); mb[0] = v[0]; mb[1] = v[1]; mb[2] = v[2]; mb[3] = v[3]; }
             else { const u32x2 v = *reinterpret_cast<const u32x2*>(mp); mb[0] = v[0]; mb[1] = v[1]; }
         };
+        // the heads' mask words are fetched at the top of the tile, with the per-sample scalars: several of the head layers have ONE
+        // k-group, so a mask loaded in front of its layer is needed a few dozen cycles later -- a whole memory latency exposed per layer
+        // in a kernel that is HBM-bound since the bottleneck fold (round 4)
+        auto fetch2 = [&](int slot) { return *reinterpret_cast<const u32x2*>(a.masks + ((size_t)slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4); };
+        auto use2 = [&](const u32x2& v) { mb[0] = v[0]; mb[1] = v[1]; };
         // dX tile -> (optional ReLU mask) -> units of the next backward layer + feature-major save for the wgrad GEMM
         // (slice s of the epilogue of m-tile mt, see chunk_compute)
         auto grad_epi = [&](U* dst, int grd_row, bool masked, int mt, const f32x16& accv, int s) {
@@ -81,6 +86,10 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
 
         U D[HKG], N[HKG];
         if constexpr (FULL) {
+            u32x2 pm12 = {0, 0}, pm11 = {0, 0}, pm10 = {0, 0}, pm9 = {0, 0};
+            if constexpr (TRANS) { pm12 = fetch2(12); pm11 = fetch2(11); pm10 = fetch2(10); pm9 = fetch2(9); }
+            const u32x2 pm8 = fetch2(8);
+            const u32x4 pm7 = *reinterpret_cast<const u32x4*>(a.masks + ((size_t)7 * a.p_pad * 2 + (size_t)p * 2 + h) * 4);
             float dalb[4] = {0.f, 0.f, 0.f, 0.f}, dtr[4] = {0.f, 0.f, 0.f, 0.f};
             if (live) {
 #pragma unroll
@@ -104,22 +113,22 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             if constexpr (TRANS) {
                 // ---- transient head backwards: {ts,tb}_pre -> T4 -> T3 -> T2 -> T1 ----
                 const U u_tr = small_unit<P>(dtr, h);
-                load_mask(12, 2);
+                use2(pm12);
                 run_layer<P, SLOT, 1, 4, false, NST>(ws, mid, lane, h, [&](int) { return u_tr; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TA, GRD_ROW_T1 + 384, true, mt, v, s); });
-                load_mask(11, 2);
+                use2(pm11);
                 run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TB, GRD_ROW_T1 + 256, true, mt, v, s); });
-                load_mask(10, 2);
+                use2(pm10);
                 run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TB[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TA, GRD_ROW_T1 + 128, true, mt, v, s); });
-                load_mask(9, 2);
+                use2(pm9);
                 run_layer<P, SLOT, QKG, 4, false, NST>(ws, mid, lane, h, [&](int kg) { return TA[kg]; },
                     [&](int mt, const f32x16& v, int s) { grad_epi(TB, GRD_ROW_T1, true, mt, v, s); });        // TB = dY_T1
             }
             // ---- albedo head backwards: albedo_pre -> A1 ----
             const U u_al = small_unit<P>(dalb, h);
-            load_mask(8, 2);
+            use2(pm8);
             run_layer<P, SLOT, 1, 4, false, NST>(ws, mid, lane, h, [&](int) { return u_al; },
                 [&](int mt, const f32x16& v, int s) { grad_epi(DA1, GRD_ROW_A1, true, mt, v, s); });
             if constexpr (TRANS) {
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
             //      layers folded with the bottleneck layer ----
             constexpr int AKG = TRANS ? 2 * QKG : QKG;
             const U u_sg = small_unit<P>(dsig, h);
-            load_mask(7, 4);
+            mb[0] = pm7[0]; mb[1] = pm7[1]; mb[2] = pm7[2]; mb[3] = pm7[3];
             auto src = [&](int kg) {
                 if (kg < QKG) return DA1[kg < QKG ? kg : 0];
                 if constexpr (TRANS) { if (kg < AKG) return TB[(kg >= QKG && kg < AKG) ? kg - QKG : 0]; }
