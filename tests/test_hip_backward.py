@@ -129,6 +129,36 @@ def test_backward_fp32_random_batch_all_parameters():
             assert (got - rg).abs().max().item() <= 1e-2 * rg.abs().max().item() + 1e-7, (epoch, name)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config4_twenty_dates_learned_radiometric_correction_step(precision):
+    """BASELINE.json configs[4] on one GPU: 20 acquisition dates, every date with its own learned radiometric affine (A, b rows away
+    from the identity: opt.py:98-99, sat_rendering.py:288-306) and transient embedding, full EO-NeRF step (shadow pass + uncertainty
+    loss), every image index present in the batch.  fp32: outputs 1e-4, every parameter gradient -- the 20 x 9 radiometric table and
+    the 20 x 4 embedding included -- 2e-3 relative L2 of torch autograd on the oracle ("RPC bundle-adjust parameters" do not exist in
+    the shipped reference).  bf16: against the oracle's bf16 arithmetic model, 3e-2 / cosine 0.999."""
+    n_img, R = 20, 320
+    sd = orc.random_state_dict(n_img, seed=131, bias_scale=0.05, radiometric_jitter=0.1)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    rays, ts, rgbs, u_cam, u_sun = orc.synthetic_batch(R, n_img, seed=132)
+    ts[:n_img, 0] = torch.arange(n_img)                                   # every date is in the batch (a ray carries its own sun direction)
+    f = make_field(sd, n_img, precision)
+    loss, res = hip_step(f, rays, ts, rgbs, (u_cam, None, u_sun), 3)
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ref_loss, ref_out = orc.train_step(sdg, rays, ts, rgbs, u_cam, u_sun, 3, STEP, emulate_bf16=(precision == "bf16"))
+    assert abs(loss.item() - ref_loss.item()) < (1e-5 if precision == "fp32" else 2e-3)
+    if precision == "fp32":
+        assert (res["rgb"].cpu() - ref_out[:, 0:3]).abs().max().item() < 1e-4 and (res["shadowless_rgb"].cpu() - ref_out[:, 18:21]).abs().max().item() < 1e-4
+    for name, p in f.named_parameters():
+        rg = sdg[name].grad
+        assert rg is not None and rg.norm() > 0, name                     # everything is in the graph in this configuration
+        got = p.grad.cpu()
+        rel = ((got - rg).norm() / rg.norm()).item()
+        cos = ((got * rg).sum() / (got.norm() * rg.norm())).item()
+        assert (rel < 2e-3) if precision == "fp32" else (rel < 3e-2 and cos > 0.999), (name, rel, cos)
+    rad = dict(f.named_parameters())["radiometricT_enc.weight"].grad
+    assert (rad[:, :6].abs().sum(dim=1) > 0).all() and rad[:, 6:].abs().max().item() == 0.0      # all 20 rows of A | b, the 3 unused columns untouched
+
+
 def test_backward_bf16_close_to_fp32_autograd():
     n_img, R = 5, 256
     sd = orc.random_state_dict(n_img, seed=61, bias_scale=0.05)
