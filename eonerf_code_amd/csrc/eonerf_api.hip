@@ -748,6 +748,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
     cb.albedo = w.cam.albedo; cb.ts = w.cam.ts; cb.tb = w.cam.tb;
     cb.g_sigma = w.cam.g_sigma; cb.g_albedo = w.cam.g_albedo; cb.g_ts = w.cam.g_ts; cb.g_tb = w.cam.g_tb;
     cb.depth_only = density_only ? 1 : 0;
+    if (sun && !density_only) { cb.sun_offsets = sun->offsets; cb.sun_counts = sun->counts; cb.sun_g_pos = sun->g_pos; }      // d depth of the shadow rays' origins
     HIP_TRY(eo_launch_cam_composite_bwd(cb, st));
     MlpBwdArgs mc;
     memset(&mc, 0, sizeof(mc));
@@ -959,32 +960,33 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     ca.sigma = w.cam.sigma; ca.delta = w.cam.delta; ca.tmid = w.cam.tmid; ca.albedo = w.cam.albedo; ca.ts = w.cam.ts; ca.tb = w.cam.tb;
     ca.p_pad = p_cap; ca.n_rays = n_rays; ca.shadow_only = 0; ca.depth_only = od ? 1 : 0;
     ca.amb = ambient_w(ctx, flat); ca.ray_out = w.ray_rec; ca.amb_save = w.amb_save;
-    HIP_TRY(eo_launch_composite_fwd(ca, st));
-
-    // ---- sun pass: shadow rays from the rendered surface toward the sun -----------------------------------
-    if (shadows) {
-        SampleArgs ss = sa;
-        ss.img_idx = nullptr; ss.u = u_sun; ss.u_retry = nullptr; ss.retry = 0;
-        ss.depth = w.ray_rec + RR_DEPTH; ss.depth_stride = RAY_REC; ss.sun_pass = 1; ss.patch_last = 0;
-        ss.cnt_first = w.sun.counts; ss.cnt_retry = w.cnt_retry; ss.counts = w.sun.counts; ss.offsets = w.sun.offsets;
-        ss.n_pts = w.sun.n_pts; ss.n_pts_copy = nullptr;
-        ss.px = w.sun.px; ss.py = w.sun.py; ss.pz = w.sun.pz; ss.tmid = w.sun.tmid; ss.delta = w.sun.delta; ss.simg = w.sun.simg;
-        HIP_TRY(eo_launch_sampler(ss, st));
-        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train ? 1 : 0, st, EONERF_PROF_FWD_CHAIN_SUN, train);
-        if (rc) return rc;
-        CompositeArgs cs = ca;
-        cs.offsets = w.sun.offsets; cs.counts = w.sun.counts; cs.sigma = w.sun.sigma; cs.delta = w.sun.delta; cs.tmid = w.sun.tmid;
-        cs.shadow_only = 1; cs.depth_only = 0;
-        HIP_TRY(eo_launch_composite_fwd(cs, st));
-    }
-
-    // ---- irradiance model + radiometric affine + packing ---------------------------------------------------
+    // irradiance model + radiometric affine + packing (sat_rendering.py:265-312): done by the chunk's LAST compositing launch, ray by ray
     ShadeArgs sh;
     sh.ray_rec = w.ray_rec; sh.img_idx = img_idx;
     sh.radiometric = ctx->cfg.radiometric ? flat + ctx->pl.t[ctx->pl.rad].offset : nullptr;
     sh.pts_first = w.cnt_first; sh.sc_counts = shadows ? w.sun.counts : w.cnt_first;
     sh.n_rays = n_rays; sh.use_shadow = shadows ? 1 : 0; sh.eval = (flags & EONERF_F_EVAL) ? 1 : 0; sh.out = out;
-    HIP_TRY(eo_launch_shade_fwd(sh, st));
+    ca.shade = sh; ca.do_shade = shadows ? 0 : 1;
+    // sun pass: shadow rays from the rendered surface toward the sun; the camera compositing counts their samples
+    SampleArgs ss = sa;
+    ss.img_idx = nullptr; ss.u = u_sun; ss.u_retry = nullptr; ss.retry = 0;
+    ss.depth = w.ray_rec + RR_DEPTH; ss.depth_stride = RAY_REC; ss.sun_pass = 1; ss.patch_last = 0;
+    ss.cnt_first = w.sun.counts; ss.cnt_retry = w.cnt_retry; ss.counts = w.sun.counts; ss.offsets = w.sun.offsets;
+    ss.n_pts = w.sun.n_pts; ss.n_pts_copy = nullptr;
+    ss.px = w.sun.px; ss.py = w.sun.py; ss.pz = w.sun.pz; ss.tmid = w.sun.tmid; ss.delta = w.sun.delta; ss.simg = w.sun.simg;
+    if (shadows) { ca.count_sun = 1; ca.sun = ss; }
+    HIP_TRY(eo_launch_composite_fwd(ca, st));
+
+    // ---- sun pass ---------------------------------------------------------------------------------------------
+    if (shadows) {
+        HIP_TRY(eo_launch_sampler(ss, st, true));
+        rc = run_mlp_fwd(ctx, w.sun, flat, p_cap, false, train ? 1 : 0, st, EONERF_PROF_FWD_CHAIN_SUN, train);
+        if (rc) return rc;
+        CompositeArgs cs = ca;
+        cs.offsets = w.sun.offsets; cs.counts = w.sun.counts; cs.sigma = w.sun.sigma; cs.delta = w.sun.delta; cs.tmid = w.sun.tmid;
+        cs.shadow_only = 1; cs.depth_only = 0; cs.count_sun = 0; cs.do_shade = 1;
+        HIP_TRY(eo_launch_composite_fwd(cs, st));
+    }
     return EONERF_OK;
 }
 
@@ -1048,7 +1050,6 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
             ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_SUN, st);
             HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, false, grid, st));
         }
-        HIP_TRY(eo_launch_sun_depth_grad(cs, st));
     }
 
     return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows, !shadows,

@@ -32,6 +32,15 @@ struct SampleArgs {
     int64_t* o_ray; float *o_ts, *o_te;
 };
 
+struct ShadeArgs {
+    const float* ray_rec;
+    const int64_t* img_idx;
+    const float* radiometric;   // [n_img][9] or nullptr
+    const int *pts_first, *sc_counts;
+    int n_rays, use_shadow, eval;
+    float* out;                 // [R][21]
+};
+
 struct CompositeArgs {
     const float* rays;
     const int *offsets, *counts;
@@ -41,15 +50,14 @@ struct CompositeArgs {
     AmbientW amb;
     float* ray_out;           // [R][RAY_REC]
     float* amb_save;          // training: [R][160] = sun encoding (27, padded to 32) + hidden activations (128) of the ambient head
-};
-
-struct ShadeArgs {
-    const float* ray_rec;
-    const int64_t* img_idx;
-    const float* radiometric;   // [n_img][9] or nullptr
-    const int *pts_first, *sc_counts;
-    int n_rays, use_shadow, eval;
-    float* out;                 // [R][21]
+    // render_image's last compositing launch of a chunk also shades its ray and packs the 21 output columns (the ray record is
+    // complete then: one launch fewer); do_shade = 0: EONerfMLP.rendering / render_depth, and the camera pass when a sun pass follows
+    int do_shade;
+    ShadeArgs shade;
+    // the camera pass of a chunk with the shadow pass on also COUNTS the samples of the ray's shadow ray (its origin needs only this
+    // ray's depth): the sun sampler then starts at its scan kernel.  count_sun = 0: no sun pass follows
+    int count_sun;
+    SampleArgs sun;
 };
 
 struct ShadeBwdArgs {
@@ -73,6 +81,10 @@ struct CompositeBwdArgs {
     float *g_sigma, *g_albedo, *g_ts, *g_tb;   // per-sample outputs
     const float* g_pos;                        // sun pass: [3][p_pad] d sigma / d position
     int depth_only;                            // camera compositing of a density-only pass (render_depth): no head terms
+    // camera compositing backward with the shadow pass on: d depth first collects <d position, viewdir> over the ray's shadow samples
+    // (origin = o + depth * d, sat_rendering.py:90) -- formerly a launch of its own (k_sun_depth_grad)
+    const int *sun_offsets, *sun_counts;
+    const float* sun_g_pos;                    // [3][p_pad] or nullptr
 };
 
 struct AmbientBwdArgs {
@@ -122,13 +134,12 @@ struct RenderingOutBwdArgs { const float* ray_rec; int n_rays; const float *g_al
 hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb, const AmbientBwdArgs* amb, hipStream_t st);
 hipError_t eo_launch_rendering_out_bwd(const RenderingOutBwdArgs& a, hipStream_t st);
 
-hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st);
+hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st, bool counted = false);      // counted: cnt_first is filled already (CompositeArgs::count_sun)
 hipError_t eo_launch_from_packed(const PackedArgs& a, hipStream_t st);
 hipError_t eo_launch_rendering_out(const RenderingOutArgs& a, hipStream_t st);
 hipError_t eo_launch_int_to_float(const int* src, int n, float* dst, hipStream_t st);
 hipError_t eo_launch_shade_bwd(const ShadeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
-hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st);
 hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st, bool deterministic = false);
 // out[idx[r] * stride + w] += contrib[r * width + w], summed over the rays in ray order by ONE thread per (table row, w)

@@ -77,16 +77,20 @@ struct RayGeom { float ox, oy, oz, dx, dy, dz, near; };
 
 // camera rays come from the [R,11] table; sun rays start at the rendered surface point and look at the sun
 // (sat_rendering.py:90-91: origin = o + depth*d, dir = -sundir, near = 0)
+EO_DEV RayGeom sun_geom(const float* r, float depth) {
+    RayGeom g;
+    g.ox = __fadd_rn(r[0], __fmul_rn(depth, r[3]));
+    g.oy = __fadd_rn(r[1], __fmul_rn(depth, r[4]));
+    g.oz = __fadd_rn(r[2], __fmul_rn(depth, r[5]));
+    g.dx = -r[8]; g.dy = -r[9]; g.dz = -r[10];
+    g.near = 0.f;
+    return g;
+}
 EO_DEV RayGeom ray_geom(const SampleArgs& a, int ray) {
     const float* r = a.rays + (size_t)ray * 11;
     RayGeom g;
     if (a.sun_pass) {
-        const float depth = a.depth[(size_t)ray * a.depth_stride];
-        g.ox = __fadd_rn(r[0], __fmul_rn(depth, r[3]));
-        g.oy = __fadd_rn(r[1], __fmul_rn(depth, r[4]));
-        g.oz = __fadd_rn(r[2], __fmul_rn(depth, r[5]));
-        g.dx = -r[8]; g.dy = -r[9]; g.dz = -r[10];
-        g.near = 0.f;
+        g = sun_geom(r, a.depth[(size_t)ray * a.depth_stride]);
     } else {
         g.ox = r[0]; g.oy = r[1]; g.oz = r[2]; g.dx = r[3]; g.dy = r[4]; g.dz = r[5];
         g.near = r[6];
@@ -95,10 +99,7 @@ EO_DEV RayGeom ray_geom(const SampleArgs& a, int ray) {
 }
 
 // ---- kernel 1: count samples per ray (for both the first draw and the "retry" draw; k_scan decides which one counts) ----
-__global__ __launch_bounds__(256) void k_count(SampleArgs a) {
-    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
-    if (ray >= a.n_rays) return;
-    const RayGeom g = ray_geom(a, ray);
+EO_DEV void count_ray(const SampleArgs& a, int ray, int lane, const RayGeom& g) {
     float ua, ub;
     jitter2(a, a.u, a.sun_pass ? 2 : 0, ray, lane, ua, ub);
     RaySamples s = sample_ray(a.zsteps, a.perturb, ua, ub, g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
@@ -114,6 +115,11 @@ __global__ __launch_bounds__(256) void k_count(SampleArgs a) {
         a.cnt_first[ray] = cnt;
         a.cnt_retry[ray] = cnt_retry;
     }
+}
+__global__ __launch_bounds__(256) void k_count(SampleArgs a) {
+    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= a.n_rays) return;
+    count_ray(a, ray, lane, ray_geom(a, ray));
 }
 
 // ---- kernel 2: exclusive scan of the chosen counts -> offsets[R+1]; n_pts; pts_per_ray (first draw) ---------
@@ -184,6 +190,42 @@ __global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
     }
 }
 
+// ---- shading + output packing (sat_rendering.py:265-312) of one ray; `r` = its complete ray record -----------------------
+EO_DEV void shade_ray(const ShadeArgs& a, int ray, const float* r) {
+    float* o = a.out + (size_t)ray * 21;
+    const float wsum = r[RR_WSUM];
+    const float geo = a.use_shadow ? r[RR_GEO] : 1.0f;
+    const float ts = r[RR_TS];
+    const float s = a.use_shadow ? geo * ts : 1.0f;                       // :269-276
+    const long img = a.eval ? a.img_idx[0] : a.img_idx[ray];               // :288-291
+    const float* T = a.radiometric ? a.radiometric + img * 9 : nullptr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float alb = r[RR_ALB + c];
+        const float amb = (wsum * r[RR_AMB + c]) * 0.2f;                   // accumulate (eonerf.py:240) then *0.2 (:265)
+        float rgb = alb * s + (1.f - s) * (amb * alb);                     // :294
+        const float A = T ? T[c] : 1.f, b = T ? T[3 + c] : 0.f;
+        rgb = A * rgb + b;
+        o[c] = fminf(fmaxf(rgb, 0.f), 1.f);                                // :304-305
+        o[4 + c] = alb;
+        o[7 + c] = amb;
+        o[18 + c] = A * alb + b;                                           // :306
+    }
+    o[3] = r[RR_DEPTH];
+    o[10] = geo;
+    o[11] = ts;
+    o[12] = r[RR_TB];
+    o[13] = 1.0f;                                                          // entropy, eonerf.py:246
+    o[14] = (float)a.pts_first[ray];                                       // counts of the FIRST draw (:259, stale on retry)
+    o[15] = a.use_shadow ? (float)a.sc_counts[ray] : 1.0f;                 // :272 / :96
+    o[16] = 1.0f; o[17] = 1.0f;                                            // opacity_after_surface, :283
+}
+__global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
+    const int ray = blockIdx.x * 256 + threadIdx.x;
+    if (ray >= a.n_rays) return;
+    shade_ray(a, ray, a.ray_rec + (size_t)ray * RAY_REC);
+}
+
 __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
@@ -193,7 +235,17 @@ __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
         // geo_shadow = T at the LAST valid sample (exclusive), 1 for an empty ray (sat_rendering.py:112-116)
         const int last = n - 1;
         const float Tl = __shfl(last >= 64 ? rw.T[1] : rw.T[0], last & 63, 64);
-        if (lane == 0) a.ray_out[(size_t)ray * RAY_REC + RR_GEO] = n > 0 ? Tl : 1.0f;
+        if (lane == 0) {
+            float* o = a.ray_out + (size_t)ray * RAY_REC;
+            o[RR_GEO] = n > 0 ? Tl : 1.0f;
+            if (a.do_shade) {      // the record is complete: the camera pass' fields were written by an earlier launch
+                float rec[RAY_REC];
+#pragma unroll
+                for (int i = 0; i < RAY_REC; ++i) rec[i] = o[i];
+                rec[RR_GEO] = n > 0 ? Tl : 1.0f;
+                shade_ray(a.shade, ray, rec);
+            }
+        }
         return;
     }
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // depth, albedo3, ts, tb, wsum
@@ -240,41 +292,16 @@ __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
         o[RR_WSUM] = acc[6];
         o[RR_AMB + 0] = amb[0]; o[RR_AMB + 1] = amb[1]; o[RR_AMB + 2] = amb[2];   // sigmoid output of the head
         o[RR_GEO] = 1.0f;
+        if (a.do_shade) {
+            float rec[RAY_REC] = {};
+            rec[RR_DEPTH] = acc[0]; rec[RR_ALB] = acc[1]; rec[RR_ALB + 1] = acc[2]; rec[RR_ALB + 2] = acc[3]; rec[RR_TS] = acc[4];
+            rec[RR_TB] = acc[5] + 0.05f; rec[RR_WSUM] = acc[6]; rec[RR_AMB] = amb[0]; rec[RR_AMB + 1] = amb[1]; rec[RR_AMB + 2] = amb[2];
+            rec[RR_GEO] = 1.0f;
+            shade_ray(a.shade, ray, rec);
+        }
     }
-}
-
-// ---- shading + output packing (sat_rendering.py:265-312) -----------------------------------------------------
-__global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
-    const int ray = blockIdx.x * 256 + threadIdx.x;
-    if (ray >= a.n_rays) return;
-    const float* r = a.ray_rec + (size_t)ray * RAY_REC;
-    float* o = a.out + (size_t)ray * 21;
-    const float wsum = r[RR_WSUM];
-    const float geo = a.use_shadow ? r[RR_GEO] : 1.0f;
-    const float ts = r[RR_TS];
-    const float s = a.use_shadow ? geo * ts : 1.0f;                       // :269-276
-    const long img = a.eval ? a.img_idx[0] : a.img_idx[ray];               // :288-291
-    const float* T = a.radiometric ? a.radiometric + img * 9 : nullptr;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float alb = r[RR_ALB + c];
-        const float amb = (wsum * r[RR_AMB + c]) * 0.2f;                   // accumulate (eonerf.py:240) then *0.2 (:265)
-        float rgb = alb * s + (1.f - s) * (amb * alb);                     // :294
-        const float A = T ? T[c] : 1.f, b = T ? T[3 + c] : 0.f;
-        rgb = A * rgb + b;
-        o[c] = fminf(fmaxf(rgb, 0.f), 1.f);                                // :304-305
-        o[4 + c] = alb;
-        o[7 + c] = amb;
-        o[18 + c] = A * alb + b;                                           // :306
-    }
-    o[3] = r[RR_DEPTH];
-    o[10] = geo;
-    o[11] = ts;
-    o[12] = r[RR_TB];
-    o[13] = 1.0f;                                                          // entropy, eonerf.py:246
-    o[14] = (float)a.pts_first[ray];                                       // counts of the FIRST draw (:259, stale on retry)
-    o[15] = a.use_shadow ? (float)a.sc_counts[ray] : 1.0f;                 // :272 / :96
-    o[16] = 1.0f; o[17] = 1.0f;                                            // opacity_after_surface, :283
+    // the shadow ray of this ray starts at the surface point it has just rendered: count its samples here (acc[0] = depth on every lane)
+    if (a.count_sun) count_ray(a.sun, ray, lane, sun_geom(a.rays + (size_t)ray * 11, acc[0]));
 }
 
 // ---- caller-provided flattened samples (radiance_fields/eonerf.py:196-220: gather, mid points, last t_end := 1e10) ----
@@ -349,9 +376,9 @@ __global__ void k_soa3_to_aos(const float* soa, int p_pad, int n, float* aos) {
 
 }  // namespace
 
-hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st) {
+hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st, bool counted) {
     const int blocks = (a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
-    hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, st, a);
+    if (!counted) hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, st, a);
     return hipGetLastError();

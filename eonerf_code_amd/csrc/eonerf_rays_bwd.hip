@@ -80,25 +80,6 @@ __global__ __launch_bounds__(256) void k_sun_composite_bwd(CompositeBwdArgs a) {
     }
 }
 
-// ---- d depth += sum over the ray's shadow samples of <d pos, viewdir>  (origin = o + depth*d, sat_rendering.py:90) --
-__global__ __launch_bounds__(256) void k_sun_depth_grad(CompositeBwdArgs a) {
-    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
-    if (ray >= a.n_rays) return;
-    const int off = a.offsets[ray], n = a.counts[ray];
-    const float* r = a.rays + (size_t)ray * 11;
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = lane + 64 * k;
-        if (i < n) {
-            const int p = off + i;
-            acc += a.g_pos[p] * r[3] + a.g_pos[(size_t)a.p_pad + p] * r[4] + a.g_pos[2 * (size_t)a.p_pad + p] * r[5];
-        }
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) a.g_ray[(size_t)ray * RAY_REC + RR_DEPTH] += acc;
-}
-
 // ---- camera compositing backward ---------------------------------------------------------------------------
 //   w_i = T_i (1 - e_i), e_i = exp(-sd_i), T_i = exp(-sum_{j<i} sd_j)
 //   dL/dsd_i = g_w_i T_i e_i - sum_{j>i} g_w_j w_j          dL/dsigma_i = delta_i dL/dsd_i
@@ -107,7 +88,22 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
     if (ray >= a.n_rays) return;
     const int off = a.offsets[ray], n = a.counts[ray];
     const float* g = a.g_ray + (size_t)ray * RAY_REC;
-    const float g_depth = g[RR_DEPTH], g_ts = g[RR_TS], g_tb = g[RR_TB], g_wsum = g[RR_WSUM];
+    float g_depth = g[RR_DEPTH];
+    const float g_ts = g[RR_TS], g_tb = g[RR_TB], g_wsum = g[RR_WSUM];
+    if (a.sun_g_pos) {      // d depth += sum over the ray's shadow samples of <d pos, viewdir>  (origin = o + depth*d, sat_rendering.py:90)
+        const int so = a.sun_offsets[ray], sn = a.sun_counts[ray];
+        const float* r = a.rays + (size_t)ray * 11;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = lane + 64 * k;
+            if (i < sn) {
+                const int p = so + i;
+                acc += a.sun_g_pos[p] * r[3] + a.sun_g_pos[(size_t)a.p_pad + p] * r[4] + a.sun_g_pos[2 * (size_t)a.p_pad + p] * r[5];
+            }
+        }
+        g_depth += wave_sum(acc);
+    }
     const float g_alb[3] = {g[RR_ALB], g[RR_ALB + 1], g[RR_ALB + 2]};
     const RayWeights rw = ray_weights(a.sigma, a.delta, off, n, lane);
     float gw_w[2], gw[2];
@@ -579,10 +575,6 @@ hipError_t eo_launch_rendering_out_bwd(const RenderingOutBwdArgs& a, hipStream_t
 }
 hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_sun_composite_bwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
-    return hipGetLastError();
-}
-hipError_t eo_launch_sun_depth_grad(const CompositeBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_sun_depth_grad, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {
