@@ -139,7 +139,7 @@ int pack(const eonerf_ctx* ctx, const std::vector<const DevStream*>& streams, co
 // The heads' first layers folded with the bottleneck layer (eonerf_pack.h): fold[o][i] = sum_k W_AT[o][k] W_b[k][i], b_f[o] = sum_k
 // W_AT[o][k] b_b[k] + b_AT[o], with W_AT = [W_A1; W_T1[:, :256]].  fp32 FMAs in a fixed order (four interleaved partial sums over k:
 // deterministic).  Block = 2 output rows, thread = column i: 16.8 M MACs on 128 workgroups in front of every re-pack; the k loop is
-// unrolled so that 16 loads of a W_b column are in flight (one dependent L2 round trip per k took 16 us).
+// unrolled so that 64 loads of a W_b column are in flight (a batch of 16 was still a chain of L2 round trips: 14 us).
 struct FoldArgs { const float *w_a1, *b_a1, *w_t1, *b_t1, *w_b, *b_b; float* fold; };
 __global__ __launch_bounds__(256) void k_fold(FoldArgs a) {
     __shared__ float wat[2][256];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_fold(FoldArgs a) {
     }
     __syncthreads();
     float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 4
+#pragma unroll 16
     for (int k = 0; k < 256; k += 4) {
         float wb[4];
 #pragma unroll
