@@ -81,6 +81,28 @@ def test_field_forward_fp32_random_weights_ragged_sizes(precision):
         assert f.query_density(torch.zeros(0, 3).cuda()).shape == (0, 1)
 
 
+def test_eval_mode_field_queries_of_a_bf16_module_run_on_its_export_context():
+    """one checkpoint, one arithmetic -- a bf16 module in .eval() mode answers query_density / forward (no_grad) on the
+    same export context its renders use (fp16x3 by default): equal to a module created in that precision, 1e-4 from the fp32 oracle,
+    and different from the bf16 answer of the same module in training mode."""
+    sd = orc.random_state_dict(5, seed=21, bias_scale=0.1)
+    f16, fx = make_field(sd, 5, "bf16"), make_field(sd, 5, "fp16x3")
+    g = torch.Generator().manual_seed(6)
+    x, sun, img = torch.rand(777, 3, generator=g) * 2 - 1, torch.randn(777, 3, generator=g), torch.randint(0, 5, (777, 1), generator=g)
+    with torch.no_grad():
+        ref = orc.Field(sd).forward(x, sun, img)
+        train_mode = f16(x.cuda(), sun.cuda(), img.cuda())
+        f16.eval()
+        ev = f16(x.cuda(), sun.cuda(), img.cuda())
+        dens = f16.query_density(x.cuda())
+        want = fx(x.cuda(), sun.cuda(), img.cuda())
+    assert f16._ctx_eval is not None
+    for a_, b_, r in zip(ev, want, ref):
+        assert torch.equal(a_, b_) and (a_.cpu() - r).abs().max().item() < 1e-4
+    assert torch.equal(dens, ev[0])
+    assert (train_mode[0] - ev[0]).abs().max().item() > 1e-5           # the bf16 kernels really answer differently
+
+
 def test_field_forward_bf16_vs_bf16_oracle():
     sd = orc.random_state_dict(5, seed=12, bias_scale=0.1)
     f = make_field(sd, 5, "bf16")
