@@ -250,9 +250,16 @@ int pipe_clear(const RenderWs& w, bool first_of_backward, int slot, hipStream_t 
     return 0;
 }
 
+// CUs the pipelined launch leaves without a stage (256 - 7 x 36 = 4): enough of them, and the per-ray ambient-head backward rides there
+inline int pipe_spare_cus(const eonerf_ctx* ctx) {
+    const int spare = ctx->n_cu - ctx->n_pipes * PIPE_STAGES;
+    return (ctx->pipe && !ctx->deterministic && spare >= 2) ? std::min(spare, 8) : 0;
+}
+
 // trunk layers 7..1 of one pass: dX chain + weight gradients.  Reads dY_7 from w.pipe.dy_in (written by the heads chain or the heads
 // pipeline), accumulates dW / db of the trunk into d_flat, saves dY_5 / dY_0 in b.grd.
-int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, int slot, bool first_of_backward) {
+int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, int slot, bool first_of_backward,
+                 const AmbientBwdArgs* amb = nullptr) {
     const ParamLayout& pl = ctx->pl;
     { const int rc = pipe_clear(w, first_of_backward, slot, st); if (rc) return rc; }
     ProfScope ps(ctx, prof_id, st);
@@ -260,6 +267,7 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
     pipe_common(ctx, w, b, p_cap, d_flat, slot, ctx->n_pipes, PIPE_STAGES, pa);
     pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in;
     pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
+    if (amb) { pa.amb = *amb; pa.amb_blocks = pipe_spare_cus(ctx); }
     for (int s = 0; s < PIPE_STAGES; ++s) {
         const int l = 7 - s;
         pa.dw_off[s] = pl.t[pl.trunk_w[l]].offset; pa.db_off[s] = pl.t[pl.trunk_b[l]].offset; pa.dw_ld[s] = l == 5 ? 319 : 256;
@@ -1022,6 +1030,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     CompositeBwdArgs cb;
     memset(&cb, 0, sizeof(cb));
     cb.rays = rays; cb.p_pad = p_cap; cb.n_rays = n_rays; cb.ray_rec = w.ray_rec; cb.g_ray = w.g_ray;
+    bool ambient_done = false;
 
     // ---- shadow pass backwards: d geo -> d sigma_sun -> (chain, input grad) -> d pos -> d depth -----------
     if (shadows) {
@@ -1040,7 +1049,12 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
             ms.stream = ctx->bwd_dens_heads.data; ms.chunks = ctx->bwd_dens_heads.chunks; ms.n_chunks = ctx->bwd_dens_heads.n_chunks;
             ms.dy7_units = w.pipe.dy_in;
             { ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_SUN, st); HIP_TRY(eo_launch_mlp_bwd(ms, true, false, true, false, grid, st, true)); }
-            const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, EONERF_PROF_BWD_PIPE_SUN, st, 0, true);
+            // (the spare CUs of this launch take the ambient-head backward: its inputs -- g_ray, the saved head activations -- are final)
+            AmbientBwdArgs ag;
+            ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
+            ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
+            ambient_done = pipe_spare_cus(ctx) > 0;
+            const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, EONERF_PROF_BWD_PIPE_SUN, st, 0, true, ambient_done ? &ag : nullptr);
             if (rcp) return rcp;
             IgTailArgs ta;
             ta.n_pts = w.sun.n_pts; ta.p_pad = p_cap; ta.grd = w.sun.grd; ta.wt = ctx->ig_tail_wt.data;
@@ -1052,7 +1066,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         }
     }
 
-    return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows, !shadows,
+    return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows && !ambient_done, !shadows,
                            shadows ? &w.sun : nullptr, false, st);
 }
 

@@ -27,6 +27,7 @@
 // that processes samples is complete as soon as its last workgroup is scheduled.
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
+#include "eonerf_ambient_dev.h"
 
 // Diagnostic builds only (scripts/pipe_ablate.sh): EO_PABL bit 0 drops the dW MFMAs, bit 1 the dX MFMAs, bit 2 the B-fragment LDS reads of
 // both products, bit 3 the LDS-DMA refill, bit 4 the ring / slab stores, bit 5 the epilogue's VALU work and the bias sums, bit 6 the final
@@ -542,7 +543,12 @@ EO_DEV bool take_role(const BwdPipeArgs& a, uint8_t* smem, int tid, Stage& S) {
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(ctl[1]);
     S.pipe = role / a.n_stages; S.st = role % a.n_stages;
-    if (S.pipe >= a.n_pipes) return false;
+    if (S.pipe >= a.n_pipes) {      // no stage left for this workgroup: the launch's spare CUs take the ambient-head backward of the step
+        static_assert(NT == 128 * AMB_STREAMS && AMB_LDS_F * 4 <= NSLOT * SLOT_B, "the ambient body runs with a stage workgroup's shape and LDS");
+        if (role - a.n_pipes * a.n_stages < a.amb_blocks)
+            ambient_bwd_body(a.amb, role - a.n_pipes * a.n_stages, a.amb_blocks, reinterpret_cast<float*>(smem));
+        return false;
+    }
     const int n_pts = *a.n_pts;
     // whole 256-sample tiles, as the chain kernels process them (dead samples carry zero gradients): the GEMM jobs that follow read
     // the saved dY_0 / dY_5 rows of every sample tile up to that bound
@@ -614,6 +620,6 @@ hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st) {
         const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B); });
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_bwd_pipe, dim3(a.n_pipes * PIPE_STAGES), dim3(NT), SMEM_B, st, a);
+    hipLaunchKernelGGL(k_bwd_pipe, dim3(a.n_pipes * PIPE_STAGES + a.amb_blocks), dim3(NT), SMEM_B, st, a);
     return hipGetLastError();
 }

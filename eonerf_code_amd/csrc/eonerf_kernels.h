@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "eonerf_common.h"
+#include "eonerf_rays.h"
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of the kernel ON ONE DEVICE (of the code object loaded there): a process
 // that drives several GPUs has to set it once per device, not once per process.
@@ -143,6 +144,10 @@ struct BwdPipeArgs {
     unsigned long long* stamps;   // diagnostics (EONERF_PIPE_STAMPS): [workgroup role][2 waves][8] cycle sums, or nullptr
     float* partials;          // deterministic mode: [pipeline][stage][256 x 256 dW | 256 db] instead of the atomic flush (reduced in pipeline order)
     int fault_stage;          // test hook (EONERF_PIPE_FAULT): this stage never publishes its tiles -> every watchdog downstream must fire; -1 = off
+    // Workgroups beyond the 7 x n_pipes stage roles (256 CUs: 4 of them idle for the whole launch otherwise) run the per-ray ambient-head
+    // backward of the step (eonerf_ambient_dev.h), amb_blocks of them; 0: none.  Independent of the stages: nothing waits for them.
+    int amb_blocks;
+    AmbientBwdArgs amb;
 };
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st);
 // input-gradient tail of a pipelined density pass (eonerf_ig_tail.hip)
