@@ -23,7 +23,7 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering", "eonerf_generate_rays",
            "eonerf_field_train_workspace_bytes", "eonerf_field_forward_train",
            "eonerf_field_backward", "eonerf_set_noise_seed", "eonerf_render_status", "eonerf_device_status", "eonerf_grad_floats",
-           "eonerf_grad_seal", "eonerf_profile_name", "eonerf_adam_step_zero_grad", "eonerf_rendering_train", "eonerf_rendering_backward"]
+           "eonerf_grad_seal", "eonerf_profile_name", "eonerf_adam_step_zero_grad", "eonerf_rendering_train", "eonerf_rendering_backward", "eonerf_clock_probe", "eonerf_range_status"]
 
 
 class EonerfRpc(C.Structure):
@@ -97,6 +97,7 @@ def lib():
     L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp, vp]
     L.eonerf_adam_step_zero_grad.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp, vp]
     L.eonerf_device_status.argtypes = [vp, vp]
+    L.eonerf_range_status.argtypes = [vp, vp]
     L.eonerf_grad_floats.restype = sz
     L.eonerf_grad_floats.argtypes = [vp]
     L.eonerf_grad_seal.argtypes = [vp, vp, vp]
@@ -115,12 +116,16 @@ def lib():
     L.eonerf_rendering_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_profile_enable.argtypes = [vp, i]
     L.eonerf_profile_read.argtypes = [vp, i, C.POINTER(fp), C.POINTER(i)]
+    L.eonerf_clock_probe.argtypes = [vp, vp, vp]
     L.eonerf_profile_name.restype = C.c_char_p
     L.eonerf_profile_name.argtypes = [i]
     for name in SYMBOLS:
         getattr(L, name)
     _lib = L
     return L
+
+
+E_RANGE = -6
 
 
 def check(rc):

@@ -4,6 +4,7 @@
 #include <string.h>
 #include <new>
 #include <vector>
+#include <unordered_map>
 
 #include "../../include/eonerf_hip.h"
 #include "eonerf_kernels.h"
@@ -25,6 +26,8 @@ struct DevStream {
 
 }  // namespace
 
+constexpr int RANGE_WORD = 16;      // ctx->dev_status[RANGE_WORD]: fp16 x 3 range flag (a cache line of its own; eonerf_range_status)
+
 struct eonerf_ctx {
     eonerf_config cfg;
     int prec;             // cfg.precision: EONERF_FP32 / EONERF_BF16 / EONERF_F16X3 (inference only)
@@ -41,6 +44,10 @@ struct eonerf_ctx {
                                      // by k_fold in front of every re-pack
     bool pipe_fallback = true;       // after a REPORTED watchdog fault the context leaves the pipelined path for good (EONERF_PIPE_FALLBACK=0: stay)
     bool need_repack = false;        // ... and the chain + GEMM path's weight streams have to be packed before the next call
+    // Training forwards whose backward is still outstanding: workspace -> the path (pipelined or chain + GEMM) its layout was carved for and
+    // its mask slots were written for.  A backward runs in the mode of ITS forward even if eonerf_device_status switched the context in
+    // between (the autograd paths keep a workspace across arbitrary host code: render_image chunks, EONerfMLP.rendering)
+    std::unordered_map<const void*, bool> ws_pipe;
     int pipe_fault_stage = -1;       // test hook (EONERF_PIPE_FAULT)
     bool deterministic = false;      // EONERF_DETERMINISTIC=1: every atomic flush of the backward is replaced by partials + a fixed-order sum
     bool pipe_partials = false;      // the pipelined launches flush their stationary dW through partial buffers + a reduction kernel (always
@@ -104,7 +111,7 @@ constexpr int PACK_MAX_JOBS = 16;
 struct PackJob { const PackEntry* e; int n; uint8_t* data; int kind; };      // kind: 0 fp32, 1 bf16, 2 fp16 (hi half of a split value), 3 its lo half
 struct PackJobs { PackJob j[PACK_MAX_JOBS]; };
 // sources >= fold_base come from the fold buffer (ParamLayout::fold_w / fold_b)
-__global__ void k_pack(const float* flat, const float* fold, int fold_base, PackJobs jobs) {
+__global__ void k_pack(const float* flat, const float* fold, int fold_base, PackJobs jobs, int* range_flag) {
     const PackJob jb = jobs.j[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
         const PackEntry pe = jb.e[i];
@@ -114,6 +121,7 @@ __global__ void k_pack(const float* flat, const float* fold, int fold_base, Pack
         else {
             const _Float16 hi = (_Float16)v;
             *reinterpret_cast<_Float16*>(jb.data + pe.dst) = jb.kind == 2 ? hi : (_Float16)(v - (float)hi);
+            if (jb.kind == 2 && !(fabsf(v) <= 65504.f)) atomicOr(range_flag, 1);      // a weight (or folded weight) outside fp16's range, or not finite
         }
     }
 }
@@ -122,7 +130,7 @@ int pack(const eonerf_ctx* ctx, const std::vector<const DevStream*>& streams, co
     PackJobs jobs;
     int n = 0, most = 1;
     auto flush = [&]() {
-        if (n) hipLaunchKernelGGL(k_pack, dim3(std::min((most + 255) / 256, 1024), n), dim3(256), 0, st, flat, ctx->fold, (int)ctx->pl.total, jobs);
+        if (n) hipLaunchKernelGGL(k_pack, dim3(std::min((most + 255) / 256, 1024), n), dim3(256), 0, st, flat, ctx->fold, (int)ctx->pl.total, jobs, ctx->dev_status + RANGE_WORD);
         n = 0; most = 1;
     };
     for (const DevStream* d : streams) {
@@ -168,12 +176,87 @@ __global__ __launch_bounds__(256) void k_fold(FoldArgs a) {
         a.fold[256 * 256 + o] = ((b4[0] + b4[1]) + (b4[2] + b4[3])) + (o < 128 ? a.b_a1[o] : a.b_t1[o - 128]);
     }
 }
+// fp16 x 3 contexts, at every re-pack: the weight matrices the split streams are made of must lie where hi + lo fp16 carries them to
+// fp32-level accuracy (include/eonerf_hip.h, eonerf_range_status).  One block per matrix: max |w| over the matrix
+//   > F16X3_W_MAX (or not finite): an absolute operand error of 2^-25 per activation is amplified beyond what "fp32-level" means
+//   < F16X3_W_MIN: the lo halves are fp16 subnormals for the whole matrix, the weights keep < 16 bits relative to the largest one
+// -> the range flag is raised and the Python layer renders on an fp32 context instead.
+constexpr float F16X3_W_MAX = 64.f, F16X3_W_MIN = 1.f / 512.f;
+struct RangeJob { const float* w; int n; int check_min; };
+struct RangeJobs { RangeJob j[24]; };
+__global__ __launch_bounds__(256) void k_weight_range(RangeJobs jobs, int* range_flag) {
+    __shared__ float red[256];
+    __shared__ int bad[1];
+    const RangeJob jb = jobs.j[blockIdx.x];
+    if (threadIdx.x == 0) bad[0] = 0;
+    __syncthreads();
+    float m = 0.f;
+    for (int i = threadIdx.x; i < jb.n; i += 256) {
+        const float v = fabsf(jb.w[i]);
+        if (!(v <= 3.0e38f)) bad[0] = 1;      // inf / NaN
+        else m = fmaxf(m, v);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const float mx = red[0];
+        const float hi_lim = jb.check_min ? F16X3_W_MAX : 65504.f;       // (operands that are not weights -- the embedding rows -- only have to fit)
+        if (bad[0] || mx > hi_lim || (jb.check_min && mx > 0.f && mx < F16X3_W_MIN)) atomicOr(range_flag, 1);
+    }
+}
+int weight_range(const eonerf_ctx* ctx, const float* flat, hipStream_t st) {
+    const ParamLayout& pl = ctx->pl;
+    RangeJobs jobs;
+    int n = 0;
+    auto add = [&](int ti, int check_min) { jobs.j[n++] = RangeJob{flat + pl.t[ti].offset, pl.t[ti].rows * pl.t[ti].cols, check_min}; };
+    for (int l = 0; l < 8; ++l) add(pl.trunk_w[l], 1);
+    add(pl.sig_w, 1); add(pl.a2_w, 1);
+    for (int l = 1; l < 4; ++l) add(pl.t_w[l], 1);
+    add(pl.tsc_w, 1); add(pl.tbe_w, 1);
+    add(pl.t_w[0], 0);      // its embedding columns are packed as they are; its bottleneck columns enter through the fold
+    add(pl.emb, 0);
+    jobs.j[n++] = RangeJob{ctx->fold, 256 * 256, 1};      // [W_A1; W_T1'] W_bott, what the streams hold of the three folded layers
+    hipLaunchKernelGGL(k_weight_range, dim3(n), dim3(256), 0, st, jobs, ctx->dev_status + RANGE_WORD);
+    return (int)hipGetLastError();
+}
+
 int fold_heads(const eonerf_ctx* ctx, const float* flat, hipStream_t st) {
     const ParamLayout& pl = ctx->pl;
     FoldArgs a{flat + pl.t[pl.a1_w].offset, flat + pl.t[pl.a1_b].offset, flat + pl.t[pl.t_w[0]].offset, flat + pl.t[pl.t_b[0]].offset,
                flat + pl.t[pl.bot_w].offset, flat + pl.t[pl.bot_b].offset, ctx->fold};
     hipLaunchKernelGGL(k_fold, dim3(128), dim3(256), 0, st, a);
     return (int)hipGetLastError();
+}
+
+// Measurement hook (eonerf_clock_probe): a FIXED amount of dense bf16 MFMA work on every CU -- 4 waves per workgroup (one per SIMD), each
+// CLOCK_PROBE_MFMAS v_mfma_f32_32x32x16_bf16 on four independent accumulators -- bracketed, in workgroup 0, by the shader-clock counter
+// (s_memtime) and the constant 100-MHz counter (s_memrealtime).  cycles / ticks x 100 = the shader clock in MHz the chip held over the
+// probe; the probe's duration (ticks x 10 ns) is the same statement without trusting s_memtime: fixed work, time ~ 1 / clock.
+constexpr int CLOCK_PROBE_MFMAS = 8192;
+typedef __attribute__((ext_vector_type(8))) __bf16 probe_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float probe_f32x16;
+__global__ __launch_bounds__(256) void k_clock_probe(float* out) {
+    probe_bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (float)(threadIdx.x + e)); b[e] = (__bf16)(0.002f * (float)(threadIdx.x ^ e)); }
+    probe_f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < CLOCK_PROBE_MFMAS / 4; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += (c0[e] + c1[e]) + (c2[e] + c3[e]);
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float cyc = (float)(t1 - t0), ticks = (float)(r1 - r0);
+        out[0] = cyc; out[1] = ticks; out[2] = ticks > 0.f ? cyc / ticks * 100.f : 0.f;
+        out[3] = s == 12345.678f ? 1.f : 0.f;      // keeps the accumulators live
+    }
 }
 
 struct ProfScope {      // brackets one kernel launch with events when profiling is on
@@ -188,6 +271,19 @@ inline bool slabs_addressable(const eonerf_ctx* ctx, size_t p_cap) { return slab
 
 CarveCfg carve_cfg(const eonerf_ctx* ctx);
 RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) { return carve_render(carve_cfg(ctx), base, n_rays, flags); }
+
+void note_train_forward(eonerf_ctx* ctx, const void* ws) {
+    if (ctx->ws_pipe.size() > 1024) ctx->ws_pipe.clear();       // forwards that never saw a backward (caller dropped the graph)
+    ctx->ws_pipe[ws] = ctx->pipe;
+}
+struct PipeModeGuard {      // a backward call runs on the path its forward ran on; the context's own choice is restored on return
+    eonerf_ctx* c; bool keep;
+    PipeModeGuard(eonerf_ctx* ctx, const void* ws) : c(ctx), keep(ctx->pipe) {
+        auto it = c->ws_pipe.find(ws);
+        if (it != c->ws_pipe.end()) c->pipe = it->second;
+    }
+    ~PipeModeGuard() { c->pipe = keep; }
+};
 
 AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
     const ParamLayout& pl = ctx->pl;
@@ -214,6 +310,7 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     a.stream = ds.data; a.chunks = ds.chunks; a.n_chunks = ds.n_chunks;
     a.sigma = b.sigma; a.albedo = b.albedo; a.ts = b.ts; a.tb = b.tb;
     a.act = b.act; a.masks = b.masks;
+    a.range_flag = ctx->dev_status + RANGE_WORD;
     // training passes of the render path with the pipelined backward: the trunk's ReLU' comes from the X images, only the heads chain
     // reads mask bits (slot 7 = X_8 for its last layer)
     a.mask_from = (render_train && ctx->pipe) ? 7 : 0;
@@ -415,6 +512,7 @@ const char* eonerf_strerror(int code) {
         case EONERF_E_WORKSPACE: return "eonerf: workspace too small";
         case EONERF_E_STATE: return "eonerf: call sequence error (set_weights / train forward missing)";
         case EONERF_E_UNSUPPORTED: return "eonerf: unsupported configuration";
+        case EONERF_E_RANGE: return "eonerf: a weight, an activation or a position left fp16's range (|v| > 65504 or not finite) in an fp16 x 3 call since the last check; its outputs are invalid -- render in fp32";
         case EONERF_E_DEVICE: return "eonerf: a device-side hand-off timed out (pipelined backward watchdog) on this or another rank; the gradients of that step are invalid and every optimizer update since has been skipped";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "eonerf: unknown error";
     }
@@ -496,6 +594,12 @@ int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches) {
     return EONERF_OK;
 }
 
+int eonerf_clock_probe(eonerf_ctx* ctx, float* out4, void* stream) {
+    if (!ctx || !out4) return EONERF_E_ARG;
+    hipLaunchKernelGGL(k_clock_probe, dim3(ctx->n_cu), dim3(256), 0, (hipStream_t)stream, out4);
+    return (int)hipGetLastError();
+}
+
 const char* eonerf_profile_name(int kernel) {
     static const char* const names[EONERF_PROF_KERNELS] = {"fwd_chain_camera", "bwd_chain_camera", "wgrad_gemm", "fwd_chain_sun", "bwd_chain_sun",
                                                            "bwd_pipe_camera", "bwd_pipe_sun", "ig_tail_sun"};
@@ -559,6 +663,7 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     }
     ctx->need_repack = false;
     int rc = fold_heads(ctx, flat, st);      // the folded head weights are a gather source of the streams below
+    if (!rc && ctx->prec == EONERF_F16X3) rc = weight_range(ctx, flat, st);
     if (!rc) rc = pack(ctx, v, flat, st);
     if (!rc) { ctx->weights_set = true; ctx->dens_dirty = !with_dens; ctx->full_ig_dirty = true; ctx->dens_used = false; }
     return rc;
@@ -851,7 +956,7 @@ int eonerf_rendering(eonerf_ctx* ctx, const float* flat, const float* rays, cons
     if (n > 0 && (!t_starts || !t_ends || !ray_indices)) return EONERF_E_ARG;
     if (!depth_only && (!albedo || !beta || !transient_s || !ambient || !entropy || !img_idx)) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
-    if (n > n_rays * 127) return EONERF_E_UNSUPPORTED;           // at most 127 intervals per ray (n_samples = 128)
+    if (n_rays > (1 << 24) || (long long)n > (long long)n_rays * 127) return EONERF_E_UNSUPPORTED;      // at most 127 intervals per ray (n_samples = 128)
     const int flags = depth_only ? EONERF_F_ONLY_DEPTH : 0;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
@@ -884,12 +989,13 @@ int eonerf_rendering_train(eonerf_ctx* ctx, const float* flat, const float* rays
     if (n > 0 && (!t_starts || !t_ends || !ray_indices)) return EONERF_E_ARG;
     if (!depth_only && (!albedo || !beta || !transient_s || !ambient || !entropy || !img_idx)) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
-    if (n > n_rays * 127) return EONERF_E_UNSUPPORTED;           // at most 127 intervals per ray (n_samples = 128)
     if (n_rays > (1 << 24) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays))) return EONERF_E_UNSUPPORTED;
+    if ((long long)n > (long long)n_rays * 127) return EONERF_E_UNSUPPORTED;           // at most 127 intervals per ray (n_samples = 128)
     if (ctx->need_repack) { const int rcr = eonerf_set_weights(ctx, flat, stream); if (rcr) return rcr; }      // (after the fault fallback)
     const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    note_train_forward(ctx, ws);
     const int p_cap = p_cap_of(n_rays);
     PackedArgs pa;
     pa.rays = rays; pa.img_idx = img_idx; pa.t_starts = t_starts; pa.t_ends = t_ends; pa.ray_indices = ray_indices;
@@ -919,6 +1025,8 @@ int eonerf_rendering_backward(eonerf_ctx* ctx, const float* flat, const float* r
     if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
     if (!depth_only && !img_idx) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
+    if (n_rays > (1 << 24) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays))) return EONERF_E_UNSUPPORTED;      // (the forward's own bounds)
+    PipeModeGuard mode(ctx, ws);
     const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
@@ -946,6 +1054,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     if (n_rays > (1 << 24) || (train && !slabs_addressable(ctx, (size_t)p_cap_of(n_rays)))) return EONERF_E_UNSUPPORTED;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    if (train) note_train_forward(ctx, ws);
     const int p_cap = p_cap_of(n_rays);
 
     // ---- camera pass: sample -> field -> composite -------------------------------------------------------
@@ -1007,6 +1116,8 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n_rays == 0) return EONERF_OK;
+    if (n_rays > (1 << 24) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays))) return EONERF_E_UNSUPPORTED;
+    PipeModeGuard mode(ctx, ws);
     const bool shadows = flags & EONERF_F_SHADOWS;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
@@ -1091,9 +1202,21 @@ int eonerf_device_status(eonerf_ctx* ctx, void* stream) {
     // A hand-off timed out: the launch did not have the card's CUs to itself (a co-tenant, a partitioned or CU-masked GPU) or a stage
     // stalled.  The fault is reported (the caller decides: the launcher ends the job) and THIS context leaves the pipelined path: a
     // caller that carries on trains through the chain + GEMM backward instead of paying a 0.3-s timeout in every step.  Data-parallel
-    // ranks all see the fault (flag in the gradient message) and all switch.
+    // ranks all see the fault (flag in the gradient message) and all switch.  Backwards of forwards that ran BEFORE this call keep the
+    // pipelined path (ws_pipe / PipeModeGuard: their workspace layout and mask slots are that path's).
     if (ctx->pipe && ctx->pipe_fallback) { ctx->pipe = false; ctx->need_repack = true; }
     return EONERF_E_DEVICE;
+}
+
+int eonerf_range_status(eonerf_ctx* ctx, void* stream) {
+    if (!ctx) return EONERF_E_ARG;
+    if (ctx->prec != EONERF_F16X3) return EONERF_OK;
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, ctx->dev_status + RANGE_WORD, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (!flag) return EONERF_OK;
+    HIP_TRY(hipMemsetAsync(ctx->dev_status + RANGE_WORD, 0, sizeof(int), (hipStream_t)stream));
+    return EONERF_E_RANGE;
 }
 
 int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* ws, size_t ws_bytes, void* stream) {

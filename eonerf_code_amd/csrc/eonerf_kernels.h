@@ -80,6 +80,7 @@ struct MlpFwdArgs {
     uint32_t* masks;               // TRAIN: [MASK_SLOTS][p_pad][2][4] ReLU masks
     int mask_from;                 // TRAIN: first mask slot the backward will read (the pipelined trunk backward derives ReLU' from the saved
                                    // activations themselves: slots below are not written)
+    int* range_flag;               // fp16 x 3 policy: set to 1 when an activation or a position leaves fp16's range (eonerf_range_status)
 };
 
 struct MlpBwdArgs {

@@ -91,6 +91,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         auto& mid = sw;          // run_layer's slab-flush hooks
         U H[HKG], N[HKG];
         uint32_t mbits[4];
+        if constexpr (P::IS_SPLIT) {
+            // split policy: mbits[0] OR-accumulates the range probes of the whole sample tile (f16_range_probe); the raw coordinates are
+            // operands of layer 0 and of the skip layer
+            mbits[0] = __builtin_amdgcn_ballot_w64(!(fabsf(x) <= 65504.f && fabsf(y) <= 65504.f && fabsf(z) <= 65504.f)) != 0ull ? 1u : 0u;
+        }
         uint32_t tbits = 0;      // ReLU flags of the tile whose epilogue is in progress
 
         // ---------------- trunk ----------------
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         auto relu_epi = [&](U* dst, int act_row, int mt, const f32x16& accv, int s) {
             const Sl<P> v = relu_slice(P(), accv, s, tbits);
             put_slice(P(), dst, mt, s, v);
-            if (s == EPI_SLICES - 1) mask_commit(P(), mt, tbits, mbits[mt >> 1]);
+            if (s == EPI_SLICES - 1) mask_commit(P(), mt, tbits, mbits[P::IS_SPLIT ? 0 : mt >> 1]);
             if constexpr (TRAIN) sw.stage(act_row + 32 * mt, s, v);
         };
         auto relu_epi_nomask = [&](U* dst, int act_row, int mt, const f32x16& accv, int s) {      // trunk layers 0..6 with TMASK = false
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         auto relu_epi_t = [&](U* dst, int act_row, int mt, const f32x16& accv, int s) {      // transient head layers
             const Sl<P> v = relu_slice(P(), accv, s, tbits);
             put_slice(P(), dst, mt, s, v);
-            if (s == EPI_SLICES - 1) mask_commit(P(), mt, tbits, mbits[mt >> 1]);
+            if (s == EPI_SLICES - 1) mask_commit(P(), mt, tbits, mbits[P::IS_SPLIT ? 0 : mt >> 1]);
             if constexpr (TSAVE) sw.stage(act_row + 32 * mt, s, v);
         };
         auto save_mask = [&](int mask_slot, int nwords) {
@@ -218,6 +223,10 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
                 });
         }
         if constexpr (TRAIN) sw.drain();
+        if constexpr (P::IS_SPLIT) {
+            // an activation beyond fp16's largest finite value (65504), or a raw coordinate that is
+            if (mbits[0] != 0u && lane == 0) atomicOr(a.range_flag, 1);      // (wave-uniform condition)
+        }
     }
 #ifdef EO_STAMP
     if (lane == 0) {

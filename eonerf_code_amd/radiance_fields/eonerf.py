@@ -209,6 +209,33 @@ class EONerfMLP(nn.Module):
             self._packed_version_eval = ver
         return self._ctx_eval, flat
 
+    def _export_range_ok(self):
+        """Call where an fp16 x 3 call has just been (or may now be) synchronised: False when an operand left the range the split
+        precision carries (eonerf_range_status: a weight matrix, an activation or a position; include/eonerf_hip.h) -- its outputs are
+        invalid.  A bf16 module then switches its export context to "fp32" for good (the caller repeats the call); a module whose OWN
+        precision is fp16x3 has nowhere to go and raises."""
+        if self.precision == "fp16x3":
+            ctx = self._ctx
+        elif self.precision == "bf16" and self.eval_precision == "fp16x3":
+            ctx = self._ctx_eval
+        else:
+            return True
+        if ctx is None:
+            return True
+        L = _lib.lib()
+        rc = L.eonerf_range_status(ctx, _stream())
+        if rc == 0:
+            return True
+        if rc != _lib.E_RANGE or self.precision == "fp16x3":
+            _lib.check(rc)
+        import warnings
+        warnings.warn("EONerfMLP: a weight matrix or an activation is outside the range of the fp16x3 export precision "
+                      "(|v| > 65504, or a layer with max|w| outside [2^-9, 64]); export renders of this module use the fp32 kernels from now on")
+        L.eonerf_destroy(self._ctx_eval)
+        self._ctx_eval, self._packed_version_eval = None, None
+        self.eval_precision = "fp32"
+        return False
+
     def _named(self):
         return dict(self.named_parameters())
 
@@ -291,13 +318,16 @@ class EONerfMLP(nn.Module):
             self._ensure_packed()
             return _FieldFn.apply(self, True, xs, None, None, *self.parameters()).view(*shape, 1)
         with torch.no_grad():
-            # a module in .eval() mode evaluates on the export context, like its renders do (one checkpoint, one arithmetic)
-            native, flat = self._native(export=not self.training)
-            sigma = torch.empty(n, dtype=torch.float32, device=xs.device)
-            L = _lib.lib()
-            nb = L.eonerf_field_workspace_bytes(native, n)
-            ws = self._workspace("field", nb)
-            _lib.check(L.eonerf_query_density(native, _ptr(flat), _ptr(xs), n, _ptr(sigma), _ptr(ws), ws.numel(), _stream()))
+            for _attempt in range(2):
+                # a module in .eval() mode evaluates on the export context, like its renders do (one checkpoint, one arithmetic)
+                native, flat = self._native(export=not self.training)
+                sigma = torch.empty(n, dtype=torch.float32, device=xs.device)
+                L = _lib.lib()
+                nb = L.eonerf_field_workspace_bytes(native, n)
+                ws = self._workspace("field", nb)
+                _lib.check(L.eonerf_query_density(native, _ptr(flat), _ptr(xs), n, _ptr(sigma), _ptr(ws), ws.numel(), _stream()))
+                if self.training or self._export_range_ok():      # (fp16x3 export context: range check, once more in fp32 if it fired)
+                    break
         return sigma.view(*shape, 1)
 
     def query_opacity(self, x, step_size):
@@ -316,15 +346,18 @@ class EONerfMLP(nn.Module):
             self._ensure_packed()
             return _FieldFn.apply(self, False, xs, sun, img, *self.parameters())
         with torch.no_grad():
-            native, flat = self._native(export=not self.training)
-            dev = xs.device
-            sigma, ts, tb = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
-            albedo, ambient = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(2))
-            L = _lib.lib()
-            nb = L.eonerf_field_workspace_bytes(native, n)
-            ws = self._workspace("field", nb)
-            _lib.check(L.eonerf_field_forward(native, _ptr(flat), _ptr(xs), _ptr(sun), _ptr(img), n, _ptr(sigma), _ptr(albedo),
-                                              _ptr(ambient), _ptr(ts), _ptr(tb), _ptr(ws), ws.numel(), _stream()))
+            for _attempt in range(2):
+                native, flat = self._native(export=not self.training)
+                dev = xs.device
+                sigma, ts, tb = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
+                albedo, ambient = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(2))
+                L = _lib.lib()
+                nb = L.eonerf_field_workspace_bytes(native, n)
+                ws = self._workspace("field", nb)
+                _lib.check(L.eonerf_field_forward(native, _ptr(flat), _ptr(xs), _ptr(sun), _ptr(img), n, _ptr(sigma), _ptr(albedo),
+                                                  _ptr(ambient), _ptr(ts), _ptr(tb), _ptr(ws), ws.numel(), _stream()))
+                if self.training or self._export_range_ok():
+                    break
         return sigma.view(n, 1), albedo, ambient, ts.view(n, 1), tb.view(n, 1)
 
     def _rendering(self, chunk_rays, t_starts, t_ends, ray_indices, depth_only):

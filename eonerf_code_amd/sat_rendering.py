@@ -175,15 +175,21 @@ def render_image(
         num_rays, _ = rays_shape
     table, img = satrays_to_table(rays)
 
-    outs, counts = [], []
-    for k, i in enumerate(range(0, num_rays, chunk)):
-        nz = None if noise is None else noise[k]
-        out, n = render_rays_chunk(radiance_field, table[i:i + chunk], img[i:i + chunk], epoch_idx, eval=eval,
-                                   only_depth=only_depth, noise=nz)
-        outs.append(out)
-        counts.append(n)
-    out = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
-    n_rendering_samples = int(torch.stack(counts).sum().item())     # the only host sync of the call
+    export = bool(eval) or (not radiance_field.training and not torch.is_grad_enabled())
+    for _attempt in range(2):
+        outs, counts = [], []
+        for k, i in enumerate(range(0, num_rays, chunk)):
+            nz = None if noise is None else noise[k]
+            out, n = render_rays_chunk(radiance_field, table[i:i + chunk], img[i:i + chunk], epoch_idx, eval=eval,
+                                       only_depth=only_depth, noise=nz)
+            outs.append(out)
+            counts.append(n)
+        out = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+        n_rendering_samples = int(torch.stack(counts).sum().item())     # the only host sync of the call
+        # export renders on the fp16x3 context: its range check rides on that sync; if an operand left the range the split precision
+        # carries, the module has switched to its fp32 export context and the image is rendered once more (EONerfMLP._export_range_ok)
+        if not export or radiance_field._export_range_ok():
+            break
     if torch.is_grad_enabled() and any(p.requires_grad for p in radiance_field.parameters()):
         # training through autograd: the stream is synchronised right here anyway, so this is where a device-side fault of an EARLIER
         # backward (pipelined kernels' watchdog, include/eonerf_hip.h) surfaces -- before another optimizer step builds on it

@@ -128,12 +128,19 @@ class FusedTrainer:
             u_cam = u_retry = u_sun = None
         else:
             u_cam, u_retry, u_sun = noise
-        ws = self._workspace(n, flags)
-        st = _stream()
-        _lib.check(self.L.eonerf_render_forward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), _ptr(self.zsteps),
-                                                _ptr(u_cam), _ptr(u_retry), _ptr(u_sun), n, flags, _ptr(self.out), _ptr(self.n_samples),
-                                                _ptr(ws), ws.numel(), st))
+        self._render_forward(rays, img_idx, n, flags, (u_cam, u_retry, u_sun))
         loss = self.loss_grad(self.out[:n], pixels.contiguous(), epoch_idx, self.d_out)
+        self._render_backward(rays, img_idx, n, flags)
+        return loss
+
+    def _render_forward(self, rays, img_idx, n, flags, noise):
+        ws, st = self._workspace(n, flags), _stream()
+        _lib.check(self.L.eonerf_render_forward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), _ptr(self.zsteps),
+                                                _ptr(noise[0]), _ptr(noise[1]), _ptr(noise[2]), n, flags, _ptr(self.out), _ptr(self.n_samples),
+                                                _ptr(ws), ws.numel(), st))
+
+    def _render_backward(self, rays, img_idx, n, flags):
+        ws, st = self._workspace(n, flags), _stream()
         if not self._grad_clean:      # (the update consumes the message: eonerf_adam_step_zero_grad)
             self.d_flat.zero_()
         self._grad_clean = False
@@ -141,7 +148,6 @@ class FusedTrainer:
                                                  _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
         if self.keep_message or self._exchanges():     # the flag travels with the message; alone, k_adam reads the status word itself
             _lib.check(self.L.eonerf_grad_seal(self.ctx, _ptr(self.d_flat), st))
-        return loss
 
     def _exchanges(self):
         return self.dist_on and (self.world > 1 or os.environ.get("EONERF_FORCE_ALLREDUCE") == "1")
@@ -186,6 +192,15 @@ class FusedTrainer:
         self.field.set_noise_seed(seed)
 
     # ---- measurement hooks ----
+    def clock_probe(self):
+        """One launch of the library's fixed MFMA loop (eonerf_clock_probe), read back: {"mhz": shader clock the chip held over the probe,
+        "us": the probe's duration}.  Synchronises; bench.py calls it outside its timed bracket."""
+        if not hasattr(self, "_probe"):
+            self._probe = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
+        _lib.check(self.L.eonerf_clock_probe(self.ctx, _ptr(self._probe), _stream()))
+        cyc, ticks, mhz, _ = self._probe.tolist()
+        return {"mhz": mhz, "us": ticks * 0.01}
+
     def profile_enable(self, max_launches):
         _lib.check(self.L.eonerf_profile_enable(self.ctx, max_launches))
 

@@ -22,9 +22,9 @@
 extern "C" {
 #endif
 
-#define EONERF_VERSION 400
+#define EONERF_VERSION 500
 
-enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4, EONERF_E_DEVICE = -5 };
+enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4, EONERF_E_DEVICE = -5, EONERF_E_RANGE = -6 };
 
 /* arithmetic of the MLP GEMMs */
 enum { EONERF_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (parity mode, 1e-4 vs the reference) */
@@ -190,6 +190,15 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat_params, const floa
  *     cannot be resident at all or the process runs under a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK), unless EONERF_PIPE=1 insists.
  *   eonerf_render_status: the same check, kept with the workspace arguments of version 2 of this ABI (they are ignored). */
 int eonerf_device_status(eonerf_ctx* ctx, void* stream);
+/* EONERF_F16X3 contexts: the RANGE of the split precision.  An operand is carried as hi + lo fp16: exact to ~2^-21 relative for
+ * 2^-14 <= |v| <= 65504; below 2^-14 the lo half is an fp16 subnormal (ABSOLUTE accuracy 2^-25, still far below what a weight or an
+ * activation of that size contributes to a sum next to O(1) terms); above 65504 hi rounds to infinity and the value is lost (the reference's
+ * fp32 arithmetic has no such limit).  Every fp16 x 3 kernel therefore flags an activation, an embedding value or a position outside
+ * +-65504 (or not finite) in a context-owned word, and every re-pack (eonerf_set_weights) flags a weight matrix whose largest |w| is
+ * not finite, above 64 (absolute operand errors amplified beyond "fp32-level") or below 2^-9 (the whole matrix in the subnormal-lo regime).  eonerf_range_status SYNCHRONISES `stream`, returns EONERF_E_RANGE if the flag was
+ * raised since the last call (0 otherwise, always 0 for the other precisions) and clears it; the Python layer calls it where an export
+ * render synchronises anyway and repeats the call on an EONERF_FP32 context (sat_rendering.render_image, EONerfMLP eval-mode queries). */
+int eonerf_range_status(eonerf_ctx* ctx, void* stream);
 int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The data-parallel gradient MESSAGE (one flat fp32 all-reduce per step) is eonerf_grad_floats() long:
@@ -232,6 +241,11 @@ enum { EONERF_PROF_FWD_CHAIN_CAMERA = 0, EONERF_PROF_BWD_CHAIN_CAMERA = 1, EONER
 int eonerf_profile_enable(eonerf_ctx* ctx, int max_launches_per_kernel);
 int eonerf_profile_read(eonerf_ctx* ctx, int kernel, float* total_ms, int* launches);
 const char* eonerf_profile_name(int kernel);
+/* Clock probe (no reference counterpart; bench.py's attribution of a slow step): one launch of a FIXED dense bf16 MFMA loop on every CU
+ * (8192 v_mfma_f32_32x32x16_bf16 per wave, 4 waves per CU; ~0.13 ms at 2 GHz), read in-kernel against the shader-clock counter (s_memtime)
+ * and the constant 100-MHz counter (s_memrealtime).  out4 (DEVICE, 4 floats): [0] shader cycles, [1] 100-MHz ticks (x 10 ns = the probe's
+ * duration: fixed work, so it is inversely proportional to the clock the chip held), [2] cycles / ticks x 100 = shader clock in MHz. */
+int eonerf_clock_probe(eonerf_ctx* ctx, float* out4, void* stream);
 
 const char* eonerf_strerror(int code);
 int eonerf_version(void);
