@@ -25,7 +25,7 @@ the stream the kernels run on (the timed passes run without them); every scope i
 that launch evaluates (kernel_model), so the scopes' FLOPs add up to the step's useful work.  `roofline` prices the dominant kernel against the bound SURVEY.md 8(d) names (bf16 MFMA peak) from its
 ALGORITHMIC FLOPs (8(d): 2 x MACs of the layers it evaluates x live samples) and also carries the HBM view of the same
 launch (the design's stash bytes; PMC-measured bytes in `traffic`).  `cpu_baseline` is the oracle (CPU port of the reference
-algorithm, torch fp32) timed on this box's host cores per BASELINE.md 3: >= 1024 rays, 1 warm-up + median of 3 steps.
+algorithm, torch fp32) timed on this box's host cores per BASELINE.md 3: the 4096-ray batch, 1 warm-up + median of 3 steps.
 """
 import argparse
 import json
@@ -92,10 +92,11 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(workloads, n_rays=1024, reps=3):
+def cpu_baseline(workloads, n_rays=4096, reps=3):
     """The oracle (CPU restatement of the reference algorithm, torch fp32) timed on the host cores:
-    the same synthetic geometry and weights init as the GPU run, a full train step (render + loss + backward + Adam),
-    1 warm-up + median of `reps` steps per workload."""
+    the same synthetic geometry and weights init as the GPU run AT THE SAME BATCH (4096 rays x 128 samples: ~14 s per full step on 16
+    threads, under the protocol's 2-minute limit), a full train step (render + loss + backward + Adam), 1 warm-up + median of `reps`
+    steps per workload (~1.5 min in all)."""
     from oracle import eonerf_oracle as orc
     torch.set_num_threads(host_cores())
     res = {}

@@ -26,6 +26,7 @@ struct DevStream {
 
 }  // namespace
 
+constexpr int PIPE_STREAM_DEFAULT = 0;      // (A/B: scripts/stream_ab.sh)
 constexpr int RANGE_WORD = 16;      // ctx->dev_status[RANGE_WORD]: fp16 x 3 range flag (a cache line of its own; eonerf_range_status)
 
 struct eonerf_ctx {
@@ -39,6 +40,8 @@ struct eonerf_ctx {
     DevStream fwd_full, fwd_dens, bwd_full, bwd_dens, bwd_rgb, bwd_full_ig, pipe_wt, bwd_full_heads, bwd_rgb_heads, bwd_dens_heads, ig_tail_wt;
     bool pipe = false;               // layer-pipelined trunk backward (bf16 camera pass; EONERF_PIPE=0 switches back to chain + GEMM)
     int n_pipes = 0;
+    int stream_blocks = 0;           // EONERF_PIPE_STREAM: workgroups of the pipelined CAMERA launch that run ready weight-gradient GEMM items
+    int n_pipes_stream = 0;          // ... and the pipelines that launch keeps: (CUs - stream_blocks) / 7
     float* loss_scratch = nullptr;   // [LOSS_MAX_BLOCKS] per-block partial sums of k_loss + its arrival counter (self-resetting: no memset per step)
     float* fold = nullptr;           // [FOLD_FLOATS] fp32: the heads' first layers folded with the bottleneck layer (eonerf_pack.h), re-computed
                                      // by k_fold in front of every re-pack
@@ -355,19 +358,29 @@ inline int pipe_spare_cus(const eonerf_ctx* ctx) {
 
 // trunk layers 7..1 of one pass: dX chain + weight gradients.  Reads dY_7 from w.pipe.dy_in (written by the heads chain or the heads
 // pipeline), accumulates dW / db of the trunk into d_flat, saves dY_5 / dY_0 in b.grd.
+struct WgradPlan;
+int fill_stream_args(const eonerf_ctx* ctx, const WgradPlan& plan, int* queue, int* stop, PipeStreamArgs& sa);
 int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p_cap, float* d_flat, int prof_id, hipStream_t st, int slot, bool first_of_backward,
-                 const AmbientBwdArgs* amb = nullptr) {
+                 const AmbientBwdArgs* amb = nullptr, const WgradPlan* plan = nullptr) {
     const ParamLayout& pl = ctx->pl;
     { const int rc = pipe_clear(w, first_of_backward, slot, st); if (rc) return rc; }
     ProfScope ps(ctx, prof_id, st);
     BwdPipeArgs pa;
-    pipe_common(ctx, w, b, p_cap, d_flat, slot, ctx->n_pipes, PIPE_STAGES, pa);
+    pipe_common(ctx, w, b, p_cap, d_flat, slot, plan ? ctx->n_pipes_stream : ctx->n_pipes, PIPE_STAGES, pa);
     pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in;
     pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
     if (amb) { pa.amb = *amb; pa.amb_blocks = pipe_spare_cus(ctx); }
     for (int s = 0; s < PIPE_STAGES; ++s) {
         const int l = 7 - s;
         pa.dw_off[s] = pl.t[pl.trunk_w[l]].offset; pa.db_off[s] = pl.t[pl.trunk_b[l]].offset; pa.dw_ld[s] = l == 5 ? 319 : 256;
+    }
+    if (plan) {      // streaming roles: ready items of the weight-gradient GEMM under the stages
+        PipeStreamArgs sa;
+        uint32_t* sync = w.pipe.sync + (size_t)slot * (w.pipe.sync_bytes / sizeof(uint32_t));
+        const int rcs = fill_stream_args(ctx, *plan, w.queue, reinterpret_cast<int*>(sync) + 48, sa);      // (word 48 of the launch's zeroed sync header)
+        if (rcs) return rcs;
+        HIP_TRY(eo_launch_bwd_pipe_stream(pa, sa, st));
+        return 0;
     }
     HIP_TRY(eo_launch_bwd_pipe(pa, st));
     if (pa.partials) HIP_TRY(eo_launch_pipe_reduce(pa, st));
@@ -377,14 +390,33 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
 // Weight gradients of up to two MLP passes in ONE split-K launch (eonerf_wgrad.hip) + the bottleneck factor product:
 //   full: a pass through the whole field (camera pass / EONerfMLP.forward), with or without the transient head in the graph;
 //   dens: a density-only pass (shadow pass / query_density).  Either may be null.  Gradients are ACCUMULATED into d_flat.
+// plan != nullptr: the table is only BUILT (into plan->tab; the camera pass' layer-0 / skip-column jobs, whose dY_0 / dY_5 operands the
+// pipelined camera launch is still to write, at the END of the queue: plan->ready_items = the items in front of them) -- the caller
+// launches the pipelined trunk with streaming roles on the ready items and then launch_planned_wgrad() for what is left.
+struct WgradPlan { WgradJobTable tab; int ready_items; };
+int fill_stream_args(const eonerf_ctx* ctx, const WgradPlan& plan, int* queue, int* stop, PipeStreamArgs& sa) {
+    if (plan.tab.n > WGRAD_STREAM_JOBS) return EONERF_E_STATE;
+    memset(&sa, 0, sizeof(sa));
+    sa.blocks = ctx->stream_blocks; sa.ready_items = plan.ready_items; sa.queue = queue; sa.stop = stop;
+    for (int i = 0; i < plan.tab.n; ++i) sa.tab.j[i] = plan.tab.j[i];
+    sa.tab.aux = plan.tab.aux; sa.tab.n = plan.tab.n; sa.tab.items = plan.tab.items;
+    return 0;
+}
+int launch_planned_wgrad(eonerf_ctx* ctx, const WgradPlan& plan, int p_cap, int* queue, hipStream_t st) {
+    ProfScope ps(ctx, EONERF_PROF_WGRAD, st);
+    HIP_TRY(eo_launch_wgrad(plan.tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, nullptr, false));
+    return 0;
+}
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
                          const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false,
-                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false, BottWgradArgs* defer_bott = nullptr) {
+                         bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false, BottWgradArgs* defer_bott = nullptr,
+                         WgradPlan* plan = nullptr) {
     // defer_bott != nullptr: the products that follow from the bottleneck factors are NOT launched here; their arguments are handed back
     // (the render path runs them in one launch with the embedding and ambient-head gradients, eo_launch_step_tail)
     const ParamLayout& pl = ctx->pl;
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     WgradJobTable tab;
+    bool late[WGRAD_MAX_JOBS] = {};      // (plan) jobs whose operands the pipelined camera launch writes
     tab.n = 0;
     memset(&tab.aux, 0, sizeof(tab.aux));
     tab.aux.job = -1;
@@ -411,22 +443,22 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     };
     // pipelined: the 256 x 256 products of layers 1..7 (and their biases) were accumulated by the layer-pipelined trunk backward;
     // what is left are the two 256 x 64 products against the encoding (layer 0, skip columns of layer 5) and the sigma row
-    auto trunk_jobs = [&](const PassBuffers& b, bool pipelined, bool sigma_job) {
+    auto trunk_jobs = [&](const PassBuffers& b, bool pipelined, bool sigma_job, bool written_late) {
         // (pipelined: dY_0 and dY_5 lie in their slab tiles in unit order -- written once by the stages of layers 1 and 6)
         add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
-        tab.j[tab.n - 1].a_units = pipelined;
+        tab.j[tab.n - 1].a_units = pipelined; late[tab.n - 1] = written_late;
         for (int l = 1; l < 8; ++l) {
             const int in_ld = l == 5 ? 319 : 256;
             if (!pipelined)
                 add(b, GRD_ROW_Y0 + 256 * l, 256, ACT_ROW_X1 + 256 * (l - 1), 256, dptr(pl.trunk_w[l]), in_ld, dptr(pl.trunk_b[l]), nullptr, 2, 4, 4, 2);
             if (l == 5)   // skip columns 256..318 <- encoding slots
-                { add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1); tab.j[tab.n - 1].a_units = pipelined; }
+                { add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1); tab.j[tab.n - 1].a_units = pipelined; late[tab.n - 1] = written_late; }
         }
         if (sigma_job) add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
     };
     if (full) {
         const PassBuffers& c = *full;
-        trunk_jobs(c, full_trunk_done, !riders);
+        trunk_jobs(c, full_trunk_done, !riders, plan != nullptr);
         // bottleneck factors M_a = dA1^T X8 (and M_t = dT1^T X8) + the bias gradients db_A1 (db_T1), finished by eo_launch_bott_wgrad
         // below into THREE weight gradients: the bottleneck layer's and the two head layers' that read the bottleneck output (which is
         // therefore never saved by the forward, nor read back here: see BottWgradArgs)
@@ -457,7 +489,16 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
             split_at(1, dptr(pl.tbe_w), 128, dptr(pl.tbe_b));
         }
     }
-    if (dens) trunk_jobs(*dens, dens_trunk_done, true);
+    if (dens) trunk_jobs(*dens, dens_trunk_done, true, false);
+    if (plan) {      // late jobs to the end of the table (stable), the riders' job index follows
+        WgradJob ordered[WGRAD_MAX_JOBS];
+        int k = 0, aux_job = tab.aux.job;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i < tab.n; ++i)
+                if (late[i] == (pass == 1)) { if (i == tab.aux.job) aux_job = k; ordered[k++] = tab.j[i]; }
+        for (int i = 0; i < tab.n; ++i) tab.j[i] = ordered[i];
+        tab.aux.job = aux_job;
+    }
     // every work item = one slice of one job's sample range, equal slices for every job; persistent workgroups pull items from one
     // counter.  Since the K loop is instantiated per tile shape the launch is HBM-bound (5.7 TB/s) and an item's time follows the
     // bytes its job moves per K step.  Measured rules (scripts/wgrad_items_sweep.sh; slices in proportion to the bytes were tried
@@ -484,7 +525,16 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         j.slices = sl < 1 ? 1 : sl;
     }
     for (int k = 0; k < tab.n; ++k) { tab.j[k].item0 = tab.items; tab.items += tab.j[k].slices; }
-    { ProfScope ps(ctx, EONERF_PROF_WGRAD, st); HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed)); }
+    if (plan) {
+        int n_late = 0;
+        for (int i = 0; i < tab.n; ++i) n_late += late[i] ? 1 : 0;
+        plan->tab = tab;
+        plan->ready_items = tab.n > n_late ? tab.j[tab.n - n_late].item0 : 0;
+        if (n_late == 0) plan->ready_items = tab.items;
+    } else {
+        ProfScope ps(ctx, EONERF_PROF_WGRAD, st);
+        HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed));
+    }
     if (full) {   // the three weight gradients that follow from the bottleneck factors the GEMM above accumulated
         BottWgradArgs bw;
         bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_at = m_bott + 2 * 128 * 256;
@@ -555,6 +605,12 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
             if (!eo_bwd_pipe_fits_a_cu() || getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) ctx->pipe = false;
         }
         { const char* fb = getenv("EONERF_PIPE_FALLBACK"); ctx->pipe_fallback = !(fb && atoi(fb) == 0); }
+        {
+            const char* sb = getenv("EONERF_PIPE_STREAM");
+            ctx->stream_blocks = sb ? atoi(sb) : PIPE_STREAM_DEFAULT;
+            if (ctx->stream_blocks < 0 || ctx->stream_blocks > ctx->n_cu - PIPE_STAGES || ctx->deterministic || ctx->pipe_partials) ctx->stream_blocks = 0;
+            ctx->n_pipes_stream = std::min(ctx->n_pipes, (ctx->n_cu - ctx->stream_blocks) / PIPE_STAGES);
+        }
         if (!rc && ctx->pipe) rc = upload(ctx->pipe_wt, build_pipe_stream(ctx->pl));
         if (!rc && ctx->pipe) rc = upload(ctx->bwd_full_heads, build_bwd_stream(ctx->pl, true, true, false, true, 1));
         if (!rc && ctx->pipe) rc = upload(ctx->bwd_rgb_heads, build_bwd_stream(ctx->pl, true, true, false, false, 1));
@@ -878,10 +934,20 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
     mc.dy7_units = pipe ? w.pipe.dy_in : nullptr;
     { ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_CAMERA, st);
       HIP_TRY(eo_launch_mlp_bwd(mc, ctx->bf16, !density_only, density_only, transient && !density_only, grid, st, pipe ? 1 : 0)); }
-    if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, first_pipe); if (rcp) return rcp; }
-
     BottWgradArgs bott;
-    {
+    const bool stream = pipe && !density_only && ctx->stream_blocks > 0 && !ctx->deterministic && !w.det.wgrad_part && !w.det.pipe_part;
+    if (stream) {
+        // the GEMM's job table first: the pipelined launch hands its ready items to streaming workgroups (PipeStreamArgs), the GEMM launch
+        // behind it takes the rest of the SAME queue (zeroed with the backward's sync block)
+        WgradPlan plan;
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, sun, p_cap, w.m_bott, w.queue, st, true, sun != nullptr, nullptr, true, &bott, &plan);
+        if (rcw) return rcw;
+        const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, first_pipe, nullptr, &plan);
+        if (rcp) return rcp;
+        const int rcl = launch_planned_wgrad(ctx, plan, p_cap, w.queue, st);
+        if (rcl) return rcl;
+    } else {
+        if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, first_pipe); if (rcp) return rcp; }
         const PassBuffers* full = density_only ? nullptr : &w.cam;
         const PassBuffers* dens = density_only ? &w.cam : sun;
         const int rcw = run_weight_gradients(ctx, flat, d_flat, full, transient, dens, p_cap, w.m_bott, w.queue, st, pipe, pipe && dens, w.det.wgrad_part, pipe,

@@ -28,6 +28,7 @@
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
 #include "eonerf_ambient_dev.h"
+#include "eonerf_wgrad_dev.h"
 
 // Diagnostic builds only (scripts/pipe_ablate.sh): EO_PABL bit 0 drops the dW MFMAs, bit 1 the dX MFMAs, bit 2 the B-fragment LDS reads of
 // both products, bit 3 the LDS-DMA refill, bit 4 the ring / slab stores, bit 5 the epilogue's VALU work and the bias sums, bit 6 the final
@@ -95,6 +96,8 @@ struct Stage {
     int x_row;                 // first row of the 256-row block of the activation slab this stage reads as its X image
     const uint8_t* in_lin;     // != nullptr: the input tiles lie in a linear buffer [global step][16 KiB] written inside this launch (layer 5: dY_5 in the gradient slab)
     uint8_t* out_lin;          // MODE 1 / 2: the linear output buffer [global step][16 KiB]
+    int* done;                 // != nullptr (first stage of the first pipeline of a launch with streaming roles): [0] = steps run so far (every
+                               // 16th step and at the end), [1] = steps to run -- the streaming roles' clock (eonerf_wgrad_dev.h)
 };
 
 // MODE 0: the output goes to the next stage's ring; 1 (layer 6): the output goes, write-through like a ring slot, to its tile of the
@@ -275,8 +278,10 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     // steady state, where two whole steps of stores and pieces are)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * N_DMA) : "memory");
 
+    if (CTRL && lane == 0 && S.done) __hip_atomic_store(S.done + 1, n_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int k = 0; k < n_k; ++k) {
         uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
+        if (CTRL && S.done && (k & 15) == 15 && lane == 0) __hip_atomic_store(S.done, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- top of the step ----
         const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTRL ? Cnt<CTRL, ORDB>::TOP_CTRL : Cnt<CTRL, ORDB>::TOP) : "memory");
@@ -477,6 +482,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_slow; o[2] = t_top; o[3] = t_bar; o[4] = t_dx; o[5] = n_slow; o[6] = (unsigned long long)n_k;
         o[7] = 0; o[8] = t_is; o[9] = 0; o[10] = t_dw;
     }
+    if (CTRL && lane == 0 && S.done) __hip_atomic_store(S.done, n_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- drain: the last stores become visible, the last tiles are published ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -536,34 +542,27 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #endif
 }
 
-// role (pipeline, stage) of this workgroup from the arrival counter, step count of its pipeline; false: nothing to do
-EO_DEV bool take_role(const BwdPipeArgs& a, uint8_t* smem, int tid, Stage& S) {
+// role (pipeline, stage) of this workgroup from the arrival counter, step count of its pipeline; false: no stage work -- `extra` >= 0 then
+// numbers the workgroups beyond the 7 x n_pipes stage roles (-1: a stage role of a pipeline without samples)
+EO_DEV bool take_role(const BwdPipeArgs& a, uint8_t* smem, int tid, Stage& S, int& extra) {
     int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B);
     if (tid == 0) { ctl[0] = 0; ctl[1] = atomicAdd(a.role_counter, 1); }
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(ctl[1]);
     S.pipe = role / a.n_stages; S.st = role % a.n_stages;
-    if (S.pipe >= a.n_pipes) {      // no stage left for this workgroup: the launch's spare CUs take the ambient-head backward of the step
-        static_assert(NT == 128 * AMB_STREAMS && AMB_LDS_F * 4 <= NSLOT * SLOT_B, "the ambient body runs with a stage workgroup's shape and LDS");
-        if (role - a.n_pipes * a.n_stages < a.amb_blocks)
-            ambient_bwd_body(a.amb, role - a.n_pipes * a.n_stages, a.amb_blocks, reinterpret_cast<float*>(smem));
-        return false;
-    }
+    extra = -1;
+    if (S.pipe >= a.n_pipes) { extra = role - a.n_pipes * a.n_stages; return false; }
     const int n_pts = *a.n_pts;
     // whole 256-sample tiles, as the chain kernels process them (dead samples carry zero gradients): the GEMM jobs that follow read
     // the saved dY_0 / dY_5 rows of every sample tile up to that bound
     const int n_steps = (n_pts + 255) / 256 * (256 / TS);
     S.n_k = S.pipe < n_steps ? (n_steps - S.pipe + a.n_pipes - 1) / a.n_pipes : 0;
     S.has_in = S.st > 0;
-    S.in_lin = nullptr; S.out_lin = nullptr;
+    S.in_lin = nullptr; S.out_lin = nullptr; S.done = nullptr;
     return S.n_k > 0;
 }
 
-__global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x;
-    Stage S;
-    if (!take_role(a, smem, tid, S)) return;
+EO_DEV void run_role(const BwdPipeArgs& a, Stage& S, uint8_t* smem, int tid) {
     const int layer = 7 - S.st;
     const size_t n_tiles = (size_t)a.p_pad / TS;
     S.x_row = ACT_ROW_X1 + 256 * (layer - 1);                          // input of layer `layer` = output of layer - 1
@@ -579,6 +578,43 @@ __global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
     } else {
         if (wv == 0) run_stage<true, 0>(a, S, smem, tid); else if (wv < 4) run_stage<false, 0>(a, S, smem, tid); else run_stage<false, 0, true>(a, S, smem, tid);
     }
+}
+
+__global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    Stage S;
+    int extra;
+    if (!take_role(a, smem, tid, S, extra)) {
+        // no stage left for this workgroup: the launch's spare CUs take the ambient-head backward of the step
+        static_assert(NT == 128 * AMB_STREAMS && AMB_LDS_F * 4 <= NSLOT * SLOT_B, "the ambient body runs with a stage workgroup's shape and LDS");
+        if (extra >= 0 && extra < a.amb_blocks) ambient_bwd_body(a.amb, extra, a.amb_blocks, reinterpret_cast<float*>(smem));
+        return;
+    }
+    run_role(a, S, smem, tid);
+}
+
+// The same launch with STREAMING roles (the camera pass' launch): the stages are MFMA-bound and use about half of the HBM bandwidth, the
+// weight-gradient GEMM that follows is HBM-bound -- and most of its jobs read operands that are final before this launch starts (the
+// heads' gradients of this pass, everything of the shadow pass).  s.blocks workgroups beyond the stage roles therefore run the GEMM's
+// work loop on those items (eonerf_wgrad_dev.h: the same queue, bounded claims) until the first stage-0 workgroup reports its last
+// step; the k_wgrad launch that follows takes what is left, including the jobs that read the dY_0 / dY_5 tiles written here.
+__global__ __launch_bounds__(NT) void k_bwd_pipe_stream(BwdPipeArgs a, PipeStreamArgs s) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    static_assert(NT == eo_wgrad::WG_NT, "the GEMM's work loop runs with a stage workgroup's shape");
+    const int tid = threadIdx.x;
+    Stage S;
+    int extra;
+    if (!take_role(a, smem, tid, S, extra)) {
+        if (extra >= 0 && extra < a.amb_blocks) ambient_bwd_body(a.amb, extra, a.amb_blocks, reinterpret_cast<float*>(smem));
+        else if (extra >= a.amb_blocks && extra < a.amb_blocks + s.blocks) {
+            __syncthreads();      // (take_role's control words share the LDS with the GEMM ring)
+            eo_wgrad::wgrad_work<PBf16, WgradJobTableS, true>(s.tab, s.queue, nullptr, smem, s.ready_items, s.stop);
+        }
+        return;
+    }
+    if (S.st == 0 && S.pipe == 0) S.done = s.stop;
+    run_role(a, S, smem, tid);
 }
 
 // deterministic mode: block = (stage, row), thread = column; pipelines that had no step wrote nothing and are skipped
@@ -611,6 +647,18 @@ bool eo_bwd_pipe_fits_a_cu() {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bwd_pipe, NT, SMEM_B) != hipSuccess) return false;
     return nb >= 1;
+}
+
+hipError_t eo_launch_bwd_pipe_stream(const BwdPipeArgs& a, const PipeStreamArgs& s, hipStream_t st) {
+    if (a.n_stages != PIPE_STAGES || a.partials) return hipErrorInvalidValue;
+    constexpr int LDS = SMEM_B > eo_wgrad::WG_SMEM ? SMEM_B : eo_wgrad::WG_SMEM;
+    static EoAttrOnce attr;
+    {
+        const hipError_t e = attr.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_pipe_stream), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_bwd_pipe_stream, dim3(a.n_pipes * PIPE_STAGES + a.amb_blocks + s.blocks), dim3(NT), LDS, st, a, s);
+    return hipGetLastError();
 }
 
 hipError_t eo_launch_bwd_pipe(const BwdPipeArgs& a, hipStream_t st) {

@@ -185,6 +185,21 @@ struct WgradAux {
 struct WgradJobTable { WgradJob j[WGRAD_MAX_JOBS]; WgradAux aux; int n; int items; };   // by value in the kernel-argument segment; jobs sorted heaviest first
 // partials != nullptr (deterministic mode): every work item stores its tile to partials[item] ([256][256] dW | [256] db) instead of
 // adding it atomically, and a second kernel sums the items of a job in slice order
+// The streaming roles of the pipelined camera launch (eonerf_bwd_pipe.hip) get the job table of the GEMM that follows as a second
+// kernel argument: the pipelined path leaves at most 11 jobs (camera: bottleneck factors, albedo output, 3 transient layers, transient
+// outputs, layer 0 and skip columns against the encoding; shadow pass: layer 0, skip columns, sigma row), so a short table fits the
+// 4-KiB kernel-argument segment beside BwdPipeArgs.
+constexpr int WGRAD_STREAM_JOBS = 16;
+struct WgradJobTableS { WgradJob j[WGRAD_STREAM_JOBS]; WgradAux aux; int n; int items; };
+struct PipeStreamArgs {
+    int blocks;               // workgroups beyond the stage (and ambient) roles that run GEMM items; 0: none (the table is not read)
+    int ready_items;          // items [0, ready_items) read operands that are final before this launch starts
+    int* queue;               // the GEMM's work queue (zeroed with the sync block of the backward's first pipelined launch)
+    int* stop;                // [2] the streaming roles' clock: steps run / to run by the first pipeline's first stage (zeroed with the sync block)
+    WgradJobTableS tab;
+};
+static_assert(sizeof(BwdPipeArgs) + sizeof(PipeStreamArgs) <= 4096, "pipelined launch: arguments exceed the kernel-argument segment");
+hipError_t eo_launch_bwd_pipe_stream(const BwdPipeArgs& a, const PipeStreamArgs& s, hipStream_t st);
 constexpr int WGRAD_PART_F = 256 * 256 + 256;
 hipError_t eo_launch_wgrad(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, bool bf16, hipStream_t st, float* partials = nullptr,
                            bool zero_queue = true);

@@ -161,6 +161,9 @@ def test_bf16_backward_matches_the_bf16_arithmetic_model_at_the_bench_size(batch
     print(f"[fullsize bf16 backward epoch {epoch}] worst per-tensor rel L2 / cosine: " + ", ".join(f"{n} {r:.2e}/{c:.5f}" for r, c, n in rows[:6]))
 
 
+P999_BOUND = 1e-2      # (measured values: see the test's print)
+
+
 @pytest.mark.parametrize("epoch", [0, 3])
 def test_bf16_forward_matches_the_bf16_emulating_oracle_at_the_bench_size(batch, epoch):
     sd, rays, ts, rgbs, u_cam, u_sun = batch
@@ -170,11 +173,17 @@ def test_bf16_forward_matches_the_bf16_emulating_oracle_at_the_bench_size(batch,
         res, n = hip_render(f, rays, ts, noise_for(u_cam, u_sun, R), epoch, R)
     assert n == n_ref
     assert torch.equal(res["pts_per_ray"].cpu(), ref[:, 14:15])
+    stats = []
     for name in ("rgb", "albedo_rgb", "shadowless_rgb", "transient_s", "geo_shadows", "depth", "beta", "ambient_rgb"):
         a, b = orc.RESULT_SLICES[name]
         d = (res[name].cpu() - ref[:, a:b]).abs()
-        # same rounding points on both sides; what is left is the summation order inside a bf16-input dot product and __sinf
-        assert d.max().item() < 3e-2 and d.mean().item() < 1e-3, (name, d.max().item(), d.mean().item())
+        # same rounding points on both sides; what is left is the summation order inside a bf16-input dot product and __sinf.  The MEAN
+        # and the 99.9th percentile are the bounds that would catch a defect; the max is an outlier bound (one ray in 4096 whose surface
+        # sample flips a bf16 rounding of sigma): a single-ray defect shows in p99.9 only if it hits > 4 rays, in the max always
+        p999 = d.flatten().kthvalue(max(1, int(0.999 * d.numel()))).values.item()
+        stats.append(f"{name} max {d.max().item():.1e} p99.9 {p999:.1e} mean {d.mean().item():.1e}")
+        assert d.max().item() < 3e-2 and p999 < P999_BOUND and d.mean().item() < 1e-3, (name, d.max().item(), p999, d.mean().item())
+    print(f"[fullsize bf16 forward epoch {epoch}] " + "; ".join(stats))
     if epoch >= 2:      # rays whose shadow ray keeps/loses a sample at the cube face differ by a whole sample: rare
         assert (res["sc_pts_per_ray"].cpu() != ref[:, 15:16]).float().mean().item() < 0.02
 
