@@ -23,7 +23,7 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_train_loss", "eonerf_sample_rays", "eonerf_rendering", "eonerf_generate_rays",
            "eonerf_field_train_workspace_bytes", "eonerf_field_forward_train",
            "eonerf_field_backward", "eonerf_set_noise_seed", "eonerf_render_status", "eonerf_device_status", "eonerf_grad_floats",
-           "eonerf_grad_seal", "eonerf_profile_name", "eonerf_adam_step_zero_grad", "eonerf_rendering_train", "eonerf_rendering_backward", "eonerf_clock_probe", "eonerf_range_status"]
+           "eonerf_grad_seal", "eonerf_profile_name", "eonerf_adam_step_zero_grad", "eonerf_rendering_train", "eonerf_rendering_backward", "eonerf_clock_probe", "eonerf_range_status", "eonerf_set_n_samples"]
 
 
 class EonerfRpc(C.Structure):
@@ -111,6 +111,7 @@ def lib():
                                        C.POINTER(fp), C.POINTER(fp), vp, vp, vp, vp]
     L.eonerf_sample_rays.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_set_noise_seed.argtypes = [vp, C.c_uint64]
+    L.eonerf_set_n_samples.argtypes = [vp, i]
     L.eonerf_rendering.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_rendering_train.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.eonerf_rendering_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp, sz, vp]

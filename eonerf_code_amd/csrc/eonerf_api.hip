@@ -31,6 +31,7 @@ constexpr int RANGE_WORD = 16;      // ctx->dev_status[RANGE_WORD]: fp16 x 3 ran
 
 struct eonerf_ctx {
     eonerf_config cfg;
+    int n_samples = 128;  // int(2 / render_step_size) of the next calls: 64, 128 or 256 (eonerf_set_n_samples; cfg.n_samples at create)
     int prec;             // cfg.precision: EONERF_FP32 / EONERF_BF16 / EONERF_F16X3 (inference only)
     bool bf16;
     int n_cu;
@@ -75,7 +76,7 @@ namespace {
 CarveCfg carve_cfg(const eonerf_ctx* ctx) {
     CarveCfg c;
     c.bf16 = ctx->bf16; c.pipe = ctx->pipe; c.deterministic = ctx->deterministic; c.pipe_partials = ctx->pipe_partials;
-    c.n_pipes = ctx->n_pipes;
+    c.n_pipes = ctx->n_pipes; c.n_samples = ctx->n_samples;
     return c;
 }
 
@@ -271,6 +272,8 @@ struct ProfScope {      // brackets one kernel launch with events when profiling
 };
 
 inline bool slabs_addressable(const eonerf_ctx* ctx, size_t p_cap) { return slab_blocks_addressable(ctx->bf16, p_cap); }
+// rays per call: n_rays x (n_samples - 1) samples must stay below 2^31
+inline bool rays_in_range(const eonerf_ctx* ctx, int n_rays) { return n_rays <= (1 << 24) / (ctx->n_samples > 128 ? ctx->n_samples / 128 : 1); }
 
 CarveCfg carve_cfg(const eonerf_ctx* ctx);
 RenderWs carve_render(const eonerf_ctx* ctx, void* base, int n_rays, int flags) { return carve_render(carve_cfg(ctx), base, n_rays, flags); }
@@ -570,11 +573,12 @@ const char* eonerf_strerror(int code) {
 
 int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     if (!out || !cfg || cfg->n_images < 1) return EONERF_E_ARG;
-    if (cfg->n_samples != 128) return EONERF_E_UNSUPPORTED;
+    if (cfg->n_samples != 64 && cfg->n_samples != 128 && cfg->n_samples != 256) return EONERF_E_UNSUPPORTED;
     if (cfg->precision != EONERF_FP32 && cfg->precision != EONERF_BF16 && cfg->precision != EONERF_F16X3) return EONERF_E_ARG;
     eonerf_ctx* ctx = new (std::nothrow) eonerf_ctx();
     if (!ctx) return EONERF_E_ARG;
     ctx->cfg = *cfg;
+    ctx->n_samples = cfg->n_samples;
     ctx->prec = cfg->precision;
     ctx->bf16 = cfg->precision == EONERF_BF16;
     const bool infer_only = cfg->precision == EONERF_F16X3;      // forward streams only
@@ -912,6 +916,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
     auto dptr = [&](int ti) { return d_flat + pl.t[ti].offset; };
     CompositeBwdArgs cb;
     memset(&cb, 0, sizeof(cb));
+    cb.n_samples = ctx->n_samples;
     cb.rays = rays; cb.p_pad = p_cap; cb.n_rays = n_rays; cb.ray_rec = w.ray_rec; cb.g_ray = w.g_ray;
     cb.offsets = w.cam.offsets; cb.counts = w.cam.counts; cb.sigma = w.cam.sigma; cb.delta = w.cam.delta; cb.tmid = w.cam.tmid;
     cb.albedo = w.cam.albedo; cb.ts = w.cam.ts; cb.tb = w.cam.tb;
@@ -958,6 +963,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
     if (!ctx->deterministic) {
         // the three independent tails of the backward -- bottleneck-factor products, embedding table, per-ray ambient head -- in ONE launch
         EmbGradArgs eg;
+        eg.n_samples = ctx->n_samples;
         eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays;
         eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0; eg.d_emb_rays = nullptr;
         AmbientBwdArgs ag;
@@ -969,6 +975,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
     if (transient) {
         EmbGradArgs eg;
+        eg.n_samples = ctx->n_samples;
         eg.offsets = w.cam.offsets; eg.counts = w.cam.counts; eg.img_idx = img_idx; eg.g_emb = w.cam.g_emb; eg.d_emb = dptr(pl.emb); eg.n_rays = n_rays; eg.lds_images = ctx->cfg.n_images <= 4096 ? ctx->cfg.n_images : 0;
         eg.d_emb_rays = w.det.emb_rays;
         HIP_TRY(eo_launch_emb_grad(eg, st));
@@ -982,6 +989,13 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
     ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
     ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
     HIP_TRY(eo_launch_ambient_bwd(ag, st, ctx->deterministic));
+    return EONERF_OK;
+}
+
+int eonerf_set_n_samples(eonerf_ctx* ctx, int n_samples) {
+    if (!ctx) return EONERF_E_ARG;
+    if (n_samples != 64 && n_samples != 128 && n_samples != 256) return EONERF_E_UNSUPPORTED;
+    ctx->n_samples = n_samples;
     return EONERF_OK;
 }
 
@@ -1001,6 +1015,7 @@ int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, 
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     SampleArgs sa;
     memset(&sa, 0, sizeof(sa));
+    sa.n_samples = ctx->n_samples;
     sa.rays = rays; sa.zsteps = zsteps; sa.u = u; sa.n_rays = n_rays; sa.perturb = perturb ? 1 : 0;
     if (perturb && !u) { sa.seed = ctx->noise_seed; sa.call = ctx->noise_call++; }
     sa.cnt_first = w.cnt_first; sa.cnt_retry = w.cnt_retry; sa.counts = w.cam.counts; sa.offsets = w.cam.offsets;
@@ -1022,11 +1037,11 @@ int eonerf_rendering(eonerf_ctx* ctx, const float* flat, const float* rays, cons
     if (n > 0 && (!t_starts || !t_ends || !ray_indices)) return EONERF_E_ARG;
     if (!depth_only && (!albedo || !beta || !transient_s || !ambient || !entropy || !img_idx)) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
-    if (n_rays > (1 << 24) || (long long)n > (long long)n_rays * 127) return EONERF_E_UNSUPPORTED;      // at most 127 intervals per ray (n_samples = 128)
+    if (!rays_in_range(ctx, n_rays) || (long long)n > (long long)n_rays * (ctx->n_samples - 1)) return EONERF_E_UNSUPPORTED;      // at most n_samples - 1 intervals per ray
     const int flags = depth_only ? EONERF_F_ONLY_DEPTH : 0;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
-    const int p_cap = p_cap_of(n_rays);
+    const int p_cap = p_cap_of(n_rays, ctx->n_samples);
     PackedArgs pa;
     pa.rays = rays; pa.img_idx = img_idx; pa.t_starts = t_starts; pa.t_ends = t_ends; pa.ray_indices = ray_indices;
     pa.n = n; pa.n_rays = n_rays; pa.counts = w.cam.counts; pa.offsets = w.cam.offsets; pa.n_pts = w.cam.n_pts;
@@ -1036,6 +1051,7 @@ int eonerf_rendering(eonerf_ctx* ctx, const float* flat, const float* rays, cons
     if (rc) return rc;
     CompositeArgs ca;
     memset(&ca, 0, sizeof(ca));
+    ca.n_samples = ctx->n_samples;
     ca.rays = rays; ca.offsets = w.cam.offsets; ca.counts = w.cam.counts;
     ca.sigma = w.cam.sigma; ca.delta = w.cam.delta; ca.tmid = w.cam.tmid; ca.albedo = w.cam.albedo; ca.ts = w.cam.ts; ca.tb = w.cam.tb;
     ca.p_pad = p_cap; ca.n_rays = n_rays; ca.depth_only = depth_only ? 1 : 0; ca.amb = ambient_w(ctx, flat); ca.ray_out = w.ray_rec;
@@ -1055,14 +1071,14 @@ int eonerf_rendering_train(eonerf_ctx* ctx, const float* flat, const float* rays
     if (n > 0 && (!t_starts || !t_ends || !ray_indices)) return EONERF_E_ARG;
     if (!depth_only && (!albedo || !beta || !transient_s || !ambient || !entropy || !img_idx)) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
-    if (n_rays > (1 << 24) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays))) return EONERF_E_UNSUPPORTED;
-    if ((long long)n > (long long)n_rays * 127) return EONERF_E_UNSUPPORTED;           // at most 127 intervals per ray (n_samples = 128)
+    if (!rays_in_range(ctx, n_rays) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays, ctx->n_samples))) return EONERF_E_UNSUPPORTED;
+    if ((long long)n > (long long)n_rays * (ctx->n_samples - 1)) return EONERF_E_UNSUPPORTED;           // at most n_samples - 1 intervals per ray
     if (ctx->need_repack) { const int rcr = eonerf_set_weights(ctx, flat, stream); if (rcr) return rcr; }      // (after the fault fallback)
     const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     note_train_forward(ctx, ws);
-    const int p_cap = p_cap_of(n_rays);
+    const int p_cap = p_cap_of(n_rays, ctx->n_samples);
     PackedArgs pa;
     pa.rays = rays; pa.img_idx = img_idx; pa.t_starts = t_starts; pa.t_ends = t_ends; pa.ray_indices = ray_indices;
     pa.n = n; pa.n_rays = n_rays; pa.counts = w.cam.counts; pa.offsets = w.cam.offsets; pa.n_pts = w.cam.n_pts;
@@ -1072,6 +1088,7 @@ int eonerf_rendering_train(eonerf_ctx* ctx, const float* flat, const float* rays
     if (rc) return rc;
     CompositeArgs ca;
     memset(&ca, 0, sizeof(ca));
+    ca.n_samples = ctx->n_samples;
     ca.rays = rays; ca.offsets = w.cam.offsets; ca.counts = w.cam.counts;
     ca.sigma = w.cam.sigma; ca.delta = w.cam.delta; ca.tmid = w.cam.tmid; ca.albedo = w.cam.albedo; ca.ts = w.cam.ts; ca.tb = w.cam.tb;
     ca.p_pad = p_cap; ca.n_rays = n_rays; ca.depth_only = depth_only ? 1 : 0; ca.amb = ambient_w(ctx, flat); ca.ray_out = w.ray_rec;
@@ -1091,12 +1108,12 @@ int eonerf_rendering_backward(eonerf_ctx* ctx, const float* flat, const float* r
     if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
     if (!depth_only && !img_idx) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
-    if (n_rays > (1 << 24) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays))) return EONERF_E_UNSUPPORTED;      // (the forward's own bounds)
+    if (!rays_in_range(ctx, n_rays) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays, ctx->n_samples))) return EONERF_E_UNSUPPORTED;      // (the forward's own bounds)
     PipeModeGuard mode(ctx, ws);
     const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
-    const int p_cap = p_cap_of(n_rays);
+    const int p_cap = p_cap_of(n_rays, ctx->n_samples);
     RenderingOutBwdArgs rb{w.ray_rec, n_rays, depth_only ? nullptr : g_albedo, g_depth, depth_only ? nullptr : g_beta,
                            depth_only ? nullptr : g_transient_s, depth_only ? nullptr : g_ambient, w.g_ray};
     HIP_TRY(eo_launch_rendering_out_bwd(rb, st));
@@ -1117,15 +1134,16 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     const bool philox = u_cam == nullptr;       // production: no noise buffers, the sampler draws its own jitter
     if (philox ? (u_retry || u_sun) : (shadows && !u_sun)) return EONERF_E_ARG;
     if (train && od) return EONERF_E_UNSUPPORTED;
-    if (n_rays > (1 << 24) || (train && !slabs_addressable(ctx, (size_t)p_cap_of(n_rays)))) return EONERF_E_UNSUPPORTED;
+    if (!rays_in_range(ctx, n_rays) || (train && !slabs_addressable(ctx, (size_t)p_cap_of(n_rays, ctx->n_samples)))) return EONERF_E_UNSUPPORTED;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     if (train) note_train_forward(ctx, ws);
-    const int p_cap = p_cap_of(n_rays);
+    const int p_cap = p_cap_of(n_rays, ctx->n_samples);
 
     // ---- camera pass: sample -> field -> composite -------------------------------------------------------
     SampleArgs sa;
     memset(&sa, 0, sizeof(sa));
+    sa.n_samples = ctx->n_samples;
     sa.rays = rays; sa.img_idx = img_idx; sa.zsteps = zsteps; sa.u = u_cam; sa.u_retry = u_retry;
     sa.perturb = 1; sa.retry = (philox || u_retry) ? 1 : 0;
     if (philox) { sa.seed = ctx->noise_seed; sa.call = ctx->noise_call++; }
@@ -1139,6 +1157,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     if (rc) return rc;
     CompositeArgs ca;
     memset(&ca, 0, sizeof(ca));
+    ca.n_samples = ctx->n_samples;
     ca.rays = rays; ca.offsets = w.cam.offsets; ca.counts = w.cam.counts;
     ca.sigma = w.cam.sigma; ca.delta = w.cam.delta; ca.tmid = w.cam.tmid; ca.albedo = w.cam.albedo; ca.ts = w.cam.ts; ca.tb = w.cam.tb;
     ca.p_pad = p_cap; ca.n_rays = n_rays; ca.shadow_only = 0; ca.depth_only = od ? 1 : 0;
@@ -1182,12 +1201,12 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n_rays == 0) return EONERF_OK;
-    if (n_rays > (1 << 24) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays))) return EONERF_E_UNSUPPORTED;
+    if (!rays_in_range(ctx, n_rays) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays, ctx->n_samples))) return EONERF_E_UNSUPPORTED;
     PipeModeGuard mode(ctx, ws);
     const bool shadows = flags & EONERF_F_SHADOWS;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
-    const int p_cap = p_cap_of(n_rays);
+    const int p_cap = p_cap_of(n_rays, ctx->n_samples);
     const ParamLayout& pl = ctx->pl;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
@@ -1206,6 +1225,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
 
     CompositeBwdArgs cb;
     memset(&cb, 0, sizeof(cb));
+    cb.n_samples = ctx->n_samples;
     cb.rays = rays; cb.p_pad = p_cap; cb.n_rays = n_rays; cb.ray_rec = w.ray_rec; cb.g_ray = w.g_ray;
     bool ambient_done = false;
 

@@ -14,6 +14,7 @@ constexpr int BOTT_SCRATCH_F = 2 * 128 * 256 + 256;       // bottleneck factors 
 struct CarveCfg {          // what the layout depends on besides (n_rays, flags): see eonerf_ctx
     bool bf16 = true, pipe = false, deterministic = false, pipe_partials = false;
     int n_pipes = 0;
+    int n_samples = 128;   // int(2 / render_step_size) of the calls this layout serves (eonerf_set_n_samples)
 };
 
 // bump allocator over the caller's workspace (256-byte aligned); with base == nullptr it only measures
@@ -64,7 +65,8 @@ struct RenderWs {
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-inline int p_cap_of(int n_rays) { return round_up(std::max(n_rays, 1) * 127, 256); }
+// capacity of the compact per-sample arrays of a pass: a ray has n_samples - 1 intervals at most (n_samples = int(2 / render_step_size))
+inline int p_cap_of(int n_rays, int n_samples) { return round_up(std::max(n_rays, 1) * (n_samples - 1), 256); }
 // a 256-row block of a training slab ([sample tile][256 rows][64 B]) is addressed through ONE buffer descriptor with 32-bit byte offsets
 // (SlabWriter, the GEMM's and the pipeline's operand loads): p_cap / samples-per-tile x 16 KiB must stay below 4 GiB --
 // 66,050 rays (8.39 M samples) per call in bf16 mode, 33,024 in fp32 mode.  Larger batches are chunked by the caller (render_image does)
@@ -101,7 +103,7 @@ inline RenderWs carve_render(const CarveCfg& cfg, void* base, int n_rays, int fl
     const CarveCfg* ctx = &cfg;
     Carver c(base);
     RenderWs w;
-    const int p_cap = p_cap_of(n_rays);
+    const int p_cap = p_cap_of(n_rays, ctx->n_samples);
     const bool train = flags & EONERF_F_TRAIN, shadows = flags & EONERF_F_SHADOWS, od = flags & EONERF_F_ONLY_DEPTH;
     const int ab = ctx->bf16 ? 2 : 4;
     w.cnt_first = c.take<int>(n_rays); w.cnt_retry = c.take<int>(n_rays); w.flags = c.take<int>(4);

@@ -11,9 +11,10 @@ struct AmbientW { const float *w1, *b1, *w2, *b2; };   // ambient_mlp: [128][27]
 struct SampleArgs {
     const float* rays;        // [R][11] fp32: o3 d3 near far sun3  (datasets/satellite.py:23-26)
     const int64_t* img_idx;   // [R] or nullptr
-    const float* zsteps;      // [128] = torch.linspace(0,1,128)
-    const float* u;           // [R][128] jitter of this pass, or nullptr: drawn in the kernel (Philox4x32-10, seed/call below)
-    const float* u_retry;     // [R][128] noise of the "some ray is empty -> resample" branch (nullptr with retry: Philox)
+    int n_samples;            // int(2 / render_step_size): 64, 128 or 256 (sat_rendering.py:64); a ray has n_samples - 1 intervals
+    const float* zsteps;      // [n_samples] = torch.linspace(0,1,n_samples)
+    const float* u;           // [R][n_samples] jitter of this pass, or nullptr: drawn in the kernel (Philox4x32-10, seed/call below)
+    const float* u_retry;     // [R][n_samples] noise of the "some ray is empty -> resample" branch (nullptr with retry: Philox)
     int retry;                // 1: the resample branch exists (camera pass of render_image, sat_rendering.py:260-262)
     int perturb;              // 0: perturb=False, z_vals stay on the uniform grid (sat_rendering.py:70-71 skipped)
     uint64_t seed; uint32_t call;   // Philox key and the per-call word of its counter
@@ -42,6 +43,7 @@ struct ShadeArgs {
 };
 
 struct CompositeArgs {
+    int n_samples;            // as SampleArgs::n_samples
     const float* rays;
     const int *offsets, *counts;
     const float *sigma, *delta, *tmid, *albedo, *ts, *tb;
@@ -72,6 +74,7 @@ struct ShadeBwdArgs {
 };
 
 struct CompositeBwdArgs {
+    int n_samples;            // as SampleArgs::n_samples
     const float* rays;
     const int *offsets, *counts;
     const float *sigma, *delta, *tmid, *albedo, *ts, *tb;
@@ -111,6 +114,7 @@ struct BottWgradArgs {
 };
 
 struct EmbGradArgs {
+    int n_samples;           // as SampleArgs::n_samples
     const int *offsets, *counts;
     const int64_t* img_idx;
     const float* g_emb;      // [p_pad][4]

@@ -1,7 +1,8 @@
 // Per-ray kernels of the EO-NeRF hot path: stratified sampler + cube filter (H3), sample compaction, alpha
 // compositing as a per-ray wavefront scan (H7), shadow-ray transmittance (H8), S-NeRF irradiance + radiometric
 // affine + output packing (H9), and their backward passes.  One wave (64 lanes) owns one ray; a ray has at most
-// 127 intervals -> 2 per lane (i = lane, lane + 64).
+// n_samples - 1 intervals, n_samples = int(2 / render_step_size) = 64, 128 or 256 (sat_rendering.py:64) -> SPL = 1, 2 or 4 per lane
+// (i = lane + 64 k; the kernels are instantiated per SPL).
 #include "eonerf_common.h"
 #include "eonerf_rays.h"
 #include "eonerf_rays_dev.h"
@@ -10,9 +11,9 @@ namespace {
 
 // ---- the SatNeRF sampler for one ray (sat_rendering.py:46-84), evaluated without FMA contraction so that
 //      t values and the cube-filter decisions are bit-identical to the reference's fp32 torch ops ------------
-struct RaySamples {
-    float ts[2], te[2], mid[2], x[2], y[2], z[2];
-    bool valid[2];
+template <int SPL> struct RaySamples {
+    float ts[SPL], te[SPL], mid[SPL], x[SPL], y[SPL], z[SPL];
+    bool valid[SPL];
 };
 
 EO_DEV float zval(const float* zsteps, float near, int i) {
@@ -20,47 +21,60 @@ EO_DEV float zval(const float* zsteps, float near, int i) {
     const float s = zsteps[i];
     return __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, s)), __fmul_rn(__fadd_rn(near, 2.0f), s));
 }
-EO_DEV float zperturbed(const float* zsteps, float near, int i, float u) {
+// ns = n_samples = int(2 / render_step_size) (sat_rendering.py:64); zsteps = linspace(0, 1, ns)
+EO_DEV float zperturbed(const float* zsteps, float near, int i, float u, int ns) {
     const float zi = zval(zsteps, near, i);
     const float lower = i == 0 ? zi : __fmul_rn(0.5f, __fadd_rn(zval(zsteps, near, i - 1), zi));
-    const float upper = i == 127 ? zi : __fmul_rn(0.5f, __fadd_rn(zi, zval(zsteps, near, i + 1)));
+    const float upper = i == ns - 1 ? zi : __fmul_rn(0.5f, __fadd_rn(zi, zval(zsteps, near, i + 1)));
     return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u));       // perturb_z_vals, :46-54
 }
 
 // ---- jitter source: caller-provided arrays (parity tests, torch.rand) or the in-kernel Philox4x32-10 stream -------------
 //      Philox (Salmon et al. 2011, the generator behind torch.rand on GPUs): counter = (ray, lane, draw, call), key = seed;
-//      one counter gives the lane's two jitters (samples lane and lane + 64); 24 random bits -> [0, 1) fp32, as torch.rand.
+//      one counter gives the lane's (up to four) jitters (samples lane + 64 k); 24 random bits -> [0, 1) fp32, as torch.rand.
 EO_DEV void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
     c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
 }
-EO_DEV void philox_u2(uint64_t seed, uint32_t ray, uint32_t lane, uint32_t draw, uint32_t call, float& ua, float& ub) {
+EO_DEV void philox_u4(uint64_t seed, uint32_t ray, uint32_t lane, uint32_t draw, uint32_t call, float (&u)[4]) {
     uint32_t c[4] = {ray, lane, draw, call};
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-    ua = (float)(c[0] >> 8) * 0x1p-24f;
-    ub = (float)(c[1] >> 8) * 0x1p-24f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = (float)(c[k] >> 8) * 0x1p-24f;
 }
-// jitters of samples `lane` and `lane + 64` of draw `draw` (0 camera, 1 camera retry, 2 sun) of ray `ray`
-EO_DEV void jitter2(const SampleArgs& a, const float* u_arr, int draw, int ray, int lane, float& ua, float& ub) {
-    if (u_arr) { ua = u_arr[(size_t)ray * 128 + lane]; ub = u_arr[(size_t)ray * 128 + lane + 64]; }
-    else philox_u2(a.seed, (uint32_t)ray, (uint32_t)lane, (uint32_t)draw, a.call, ua, ub);
+// jitters of samples lane + 64 k of draw `draw` (0 camera, 1 camera retry, 2 sun) of ray `ray`
+template <int SPL>
+EO_DEV void jitter(const SampleArgs& a, const float* u_arr, int draw, int ray, int lane, float (&u)[SPL]) {
+    if (u_arr) {
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) u[k] = u_arr[(size_t)ray * (64 * SPL) + lane + 64 * k];
+    } else {
+        float u4[4];
+        philox_u4(a.seed, (uint32_t)ray, (uint32_t)lane, (uint32_t)draw, a.call, u4);
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) u[k] = u4[k];
+    }
 }
 
-EO_DEV RaySamples sample_ray(const float* zsteps, bool perturb, float ua, float ub, float near, float ox, float oy, float oz,
-                             float dx, float dy, float dz, int lane) {
-    RaySamples s;
-    const float za = perturb ? zperturbed(zsteps, near, lane, ua) : zval(zsteps, near, lane);          // perturb=False: :70-71 skipped
-    const float zb = perturb ? zperturbed(zsteps, near, lane + 64, ub) : zval(zsteps, near, lane + 64);
-    float za1 = __shfl_down(za, 1, 64);
-    const float zb0 = __shfl(zb, 0, 64);
-    if (lane == 63) za1 = zb0;
-    const float zb1 = __shfl_down(zb, 1, 64);     // lane 63: interval 127 does not exist
-    const float zs[2] = {za, zb}, zn[2] = {za1, zb1};
+template <int SPL>
+EO_DEV RaySamples<SPL> sample_ray(const float* zsteps, bool perturb, const float (&u)[SPL], float near, float ox, float oy, float oz,
+                                  float dx, float dy, float dz, int lane) {
+    RaySamples<SPL> s;
+    constexpr int NS = 64 * SPL;
+    float zs[SPL], zn[SPL];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SPL; ++k)      // perturb=False: :70-71 skipped
+        zs[k] = perturb ? zperturbed(zsteps, near, lane + 64 * k, u[k], NS) : zval(zsteps, near, lane + 64 * k);
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        zn[k] = __shfl_down(zs[k], 1, 64);
+        if (k + 1 < SPL) { const float z0 = __shfl(zs[k + 1 < SPL ? k + 1 : k], 0, 64); if (lane == 63) zn[k] = z0; }      // (last group, lane 63: interval NS - 1 does not exist)
+    }
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
         s.ts[k] = zs[k];
         s.te[k] = __fadd_rn(zs[k], __fsub_rn(zn[k], zs[k]));               // a + (b - a), :74
         s.mid[k] = __fdiv_rn(__fadd_rn(s.ts[k], s.te[k]), 2.0f);           // :79
@@ -68,9 +82,15 @@ EO_DEV RaySamples sample_ray(const float* zsteps, bool perturb, float ua, float 
         s.y[k] = __fadd_rn(oy, __fmul_rn(dy, s.mid[k]));
         s.z[k] = __fadd_rn(oz, __fmul_rn(dz, s.mid[k]));
         const bool inside = fabsf(s.x[k]) < 1.0f && fabsf(s.y[k]) < 1.0f && fabsf(s.z[k]) < 1.0f;   // :18-22
-        s.valid[k] = inside && (k == 0 || lane < 63);
+        s.valid[k] = inside && (k + 1 < SPL || lane < 63);
     }
     return s;
+}
+template <int SPL> EO_DEV int count_valid(const RaySamples<SPL>& s) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) n += __popcll(__ballot(s.valid[k]));
+    return n;
 }
 
 struct RayGeom { float ox, oy, oz, dx, dy, dz, near; };
@@ -99,27 +119,29 @@ EO_DEV RayGeom ray_geom(const SampleArgs& a, int ray) {
 }
 
 // ---- kernel 1: count samples per ray (for both the first draw and the "retry" draw; k_scan decides which one counts) ----
+template <int SPL>
 EO_DEV void count_ray(const SampleArgs& a, int ray, int lane, const RayGeom& g) {
-    float ua, ub;
-    jitter2(a, a.u, a.sun_pass ? 2 : 0, ray, lane, ua, ub);
-    RaySamples s = sample_ray(a.zsteps, a.perturb, ua, ub, g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
-    const int cnt = __popcll(__ballot(s.valid[0])) + __popcll(__ballot(s.valid[1]));
+    float u[SPL];
+    jitter<SPL>(a, a.u, a.sun_pass ? 2 : 0, ray, lane, u);
+    const RaySamples<SPL> s = sample_ray<SPL>(a.zsteps, a.perturb, u, g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+    const int cnt = count_valid(s);
     int cnt_retry = cnt;
     if (a.retry) {
         // the reference's retry passes near=None -> zeros (sat_rendering.py:262)
-        jitter2(a, a.u_retry, 1, ray, lane, ua, ub);
-        RaySamples s2 = sample_ray(a.zsteps, a.perturb, ua, ub, 0.f, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
-        cnt_retry = __popcll(__ballot(s2.valid[0])) + __popcll(__ballot(s2.valid[1]));
+        jitter<SPL>(a, a.u_retry, 1, ray, lane, u);
+        const RaySamples<SPL> s2 = sample_ray<SPL>(a.zsteps, a.perturb, u, 0.f, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+        cnt_retry = count_valid(s2);
     }
     if (lane == 0) {
         a.cnt_first[ray] = cnt;
         a.cnt_retry[ray] = cnt_retry;
     }
 }
+template <int SPL>
 __global__ __launch_bounds__(256) void k_count(SampleArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
-    count_ray(a, ray, lane, ray_geom(a, ray));
+    count_ray<SPL>(a, ray, lane, ray_geom(a, ray));
 }
 
 // ---- kernel 2: exclusive scan of the chosen counts -> offsets[R+1]; n_pts; pts_per_ray (first draw) ---------
@@ -162,23 +184,26 @@ __global__ __launch_bounds__(1024) void k_scan(SampleArgs a) {
 }
 
 // ---- kernel 3: recompute the samples and write them compactly ---------------------------------------------
+template <int SPL>
 __global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
     const RayGeom g = ray_geom(a, ray);
     const bool retry = a.retry && (*a.flags & 1);
-    float ua, ub;
-    jitter2(a, retry ? a.u_retry : a.u, retry ? 1 : (a.sun_pass ? 2 : 0), ray, lane, ua, ub);
-    RaySamples s = sample_ray(a.zsteps, a.perturb, ua, ub, retry ? 0.f : g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
-    const unsigned long long m0 = __ballot(s.valid[0]), m1 = __ballot(s.valid[1]);
-    const int n0 = __popcll(m0), n = n0 + __popcll(m1);
+    float u[SPL];
+    jitter<SPL>(a, retry ? a.u_retry : a.u, retry ? 1 : (a.sun_pass ? 2 : 0), ray, lane, u);
+    const RaySamples<SPL> s = sample_ray<SPL>(a.zsteps, a.perturb, u, retry ? 0.f : g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+    unsigned long long m[SPL];
+    int before[SPL], n = 0;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) { m[k] = __ballot(s.valid[k]); before[k] = n; n += __popcll(m[k]); }
     const int off = a.offsets[ray];
     const unsigned long long below = (1ull << lane) - 1ull;
     const int img = a.img_idx ? (int)a.img_idx[ray] : 0;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SPL; ++k) {
         if (!s.valid[k]) continue;
-        const int rank = k == 0 ? __popcll(m0 & below) : n0 + __popcll(m1 & below);
+        const int rank = before[k] + __popcll(m[k] & below);
         const int p = off + rank;
         a.px[p] = s.x[k]; a.py[p] = s.y[k]; a.pz[p] = s.z[k];
         a.simg[p] = img;
@@ -226,15 +251,19 @@ __global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
     shade_ray(a, ray, a.ray_rec + (size_t)ray * RAY_REC);
 }
 
+template <int SPL>
 __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
     const int off = a.offsets[ray], n = a.counts[ray];
-    const RayWeights rw = ray_weights(a.sigma, a.delta, off, n, lane);
+    const RayWeights<SPL> rw = ray_weights<SPL>(a.sigma, a.delta, off, n, lane);
     if (a.shadow_only) {
         // geo_shadow = T at the LAST valid sample (exclusive), 1 for an empty ray (sat_rendering.py:112-116)
         const int last = n - 1;
-        const float Tl = __shfl(last >= 64 ? rw.T[1] : rw.T[0], last & 63, 64);
+        float Tsel = rw.T[0];
+#pragma unroll
+        for (int k = 1; k < SPL; ++k) Tsel = (last >> 6) == k ? rw.T[k] : Tsel;      // (wave-uniform selection)
+        const float Tl = __shfl(Tsel, last & 63, 64);
         if (lane == 0) {
             float* o = a.ray_out + (size_t)ray * RAY_REC;
             o[RR_GEO] = n > 0 ? Tl : 1.0f;
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
     }
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // depth, albedo3, ts, tb, wsum
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SPL; ++k) {
         const int i = lane + 64 * k;
         if (i < n) {
             const int p = off + i;
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
         }
     }
     // the shadow ray of this ray starts at the surface point it has just rendered: count its samples here (acc[0] = depth on every lane)
-    if (a.count_sun) count_ray(a.sun, ray, lane, sun_geom(a.rays + (size_t)ray * 11, acc[0]));
+    if (a.count_sun) count_ray<SPL>(a.sun, ray, lane, sun_geom(a.rays + (size_t)ray * 11, acc[0]));
 }
 
 // ---- caller-provided flattened samples (radiance_fields/eonerf.py:196-220: gather, mid points, last t_end := 1e10) ----
@@ -378,9 +407,12 @@ __global__ void k_soa3_to_aos(const float* soa, int p_pad, int n, float* aos) {
 
 hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st, bool counted) {
     const int blocks = (a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
-    if (!counted) hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, st, a);
+    eo_dispatch_spl(a.n_samples, [&](auto spl) {
+        constexpr int SPL = decltype(spl)::value;
+        if (!counted) hipLaunchKernelGGL(k_count<SPL>, dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(k_emit<SPL>, dim3(blocks), dim3(256), 0, st, a);
+    });
     return hipGetLastError();
 }
 hipError_t eo_launch_from_packed(const PackedArgs& a, hipStream_t st) {
@@ -402,7 +434,9 @@ hipError_t eo_launch_rendering_out(const RenderingOutArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t eo_launch_composite_fwd(const CompositeArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_composite_fwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    eo_dispatch_spl(a.n_samples, [&](auto spl) {
+        hipLaunchKernelGGL(k_composite_fwd<decltype(spl)::value>, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    });
     return hipGetLastError();
 }
 hipError_t eo_launch_shade_fwd(const ShadeArgs& a, hipStream_t st) {

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void k_shade_bwd(ShadeBwdArgs a) {
 }
 
 // ---- shadow-ray transmittance backward: geo = exp(-sum_{j<last} sigma_j delta_j) ------------------------------
+template <int SPL>
 __global__ __launch_bounds__(256) void k_sun_composite_bwd(CompositeBwdArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_sun_composite_bwd(CompositeBwdArgs a) {
     const float g_geo = a.g_ray[(size_t)ray * RAY_REC + RR_GEO];
     const float geo = a.ray_rec[(size_t)ray * RAY_REC + RR_GEO];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SPL; ++k) {
         const int i = lane + 64 * k;
         if (i < n) a.g_sigma[off + i] = i < n - 1 ? -g_geo * geo * a.delta[off + i] : 0.f;
     }
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void k_sun_composite_bwd(CompositeBwdArgs a) {
 // ---- camera compositing backward ---------------------------------------------------------------------------
 //   w_i = T_i (1 - e_i), e_i = exp(-sd_i), T_i = exp(-sum_{j<i} sd_j)
 //   dL/dsd_i = g_w_i T_i e_i - sum_{j>i} g_w_j w_j          dL/dsigma_i = delta_i dL/dsd_i
+template <int SPL>
 __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= a.n_rays) return;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
         const float* r = a.rays + (size_t)ray * 11;
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < SPL; ++k) {
             const int i = lane + 64 * k;
             if (i < sn) {
                 const int p = so + i;
@@ -106,10 +108,10 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
         g_depth += wave_sum(acc);
     }
     const float g_alb[3] = {g[RR_ALB], g[RR_ALB + 1], g[RR_ALB + 2]};
-    const RayWeights rw = ray_weights(a.sigma, a.delta, off, n, lane);
-    float gw_w[2], gw[2];
+    const RayWeights<SPL> rw = ray_weights<SPL>(a.sigma, a.delta, off, n, lane);
+    float gw_w[SPL], gw[SPL];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SPL; ++k) {
         const int i = lane + 64 * k;
         gw[k] = 0.f; gw_w[k] = 0.f;
         if (i < n) {
@@ -131,13 +133,16 @@ __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
         }
     }
     // exclusive suffix sums of g_w*w over the ray (element i = lane + 64k)
-    const float suf1 = wave_suffix_scan(gw_w[1], lane);
-    const float tot1 = __shfl(suf1, 0, 64);
-    const float suf0 = wave_suffix_scan(gw_w[0], lane);
-    const float n1 = __shfl_down(suf1, 1, 64), n0 = __shfl_down(suf0, 1, 64);
-    const float after[2] = {(lane == 63 ? 0.f : n0) + tot1, lane == 63 ? 0.f : n1};
+    float after[SPL], carry = 0.f;      // carry = the sum over the 64-element groups behind group k
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = SPL - 1; k >= 0; --k) {
+        const float suf = wave_suffix_scan(gw_w[k], lane);
+        const float nxt = __shfl_down(suf, 1, 64);
+        after[k] = k == SPL - 1 ? (lane == 63 ? 0.f : nxt) : (lane == 63 ? 0.f : nxt) + carry;
+        carry += __shfl(suf, 0, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
         const int i = lane + 64 * k;
         if (i < n) {
             const int p = off + i;
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
 
 // ---- transient embedding gradient: per-sample d emb (from the backward chain) summed per ray, added per image ---
 // body of one (virtual) block of 256 threads; s_de: [n_img][4] block-local accumulation (unused when lds_images == 0)
-EO_DEV void emb_grad_body(const EmbGradArgs& a, int vblk, int tid, float* s_de) {
+template <int SPL>
+EO_DEV void emb_grad_body_spl(const EmbGradArgs& a, int vblk, int tid, float* s_de) {
     const int lane = tid & 63, ray = vblk * RAYS_PER_BLOCK * 8 + (tid >> 6);
     const bool lds_acc = a.lds_images > 0 && !a.d_emb_rays;
     if (lds_acc) {
@@ -335,11 +341,11 @@ EO_DEV void emb_grad_body(const EmbGradArgs& a, int vblk, int tid, float* s_de) 
         off8[k8] = a.offsets[rc];
         n8[k8] = rr < a.n_rays ? a.counts[rc] : 0;
     }
-    f32x4 v8[8][2];
+    f32x4 v8[8][SPL];
 #pragma unroll
     for (int k8 = 0; k8 < 8; ++k8)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < SPL; ++k) {
             const int i = lane + 64 * k;
             v8[k8][k] = i < n8[k8] ? *reinterpret_cast<const f32x4*>(a.g_emb + 4 * (size_t)(off8[k8] + i)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -349,7 +355,12 @@ EO_DEV void emb_grad_body(const EmbGradArgs& a, int vblk, int tid, float* s_de) 
         if (rr >= a.n_rays) break;
         float acc[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = wave_sum(v8[k8][0][e] + v8[k8][1][e]);
+        for (int e = 0; e < 4; ++e) {
+            float t = v8[k8][0][e];
+#pragma unroll
+            for (int k = 1; k < SPL; ++k) t += v8[k8][k][e];
+            acc[e] = wave_sum(t);
+        }
         if (lane < 4) {
             const float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
             if (a.d_emb_rays) a.d_emb_rays[(size_t)rr * 4 + lane] = v;
@@ -361,6 +372,11 @@ EO_DEV void emb_grad_body(const EmbGradArgs& a, int vblk, int tid, float* s_de) 
         __syncthreads();
         for (int i = tid; i < a.lds_images * 4; i += 256) { const float v = s_de[i]; if (v != 0.f) atomicAdd(a.d_emb + i, v); }
     }
+}
+EO_DEV void emb_grad_body(const EmbGradArgs& a, int vblk, int tid, float* s_de) {
+    if (a.n_samples == 64) emb_grad_body_spl<1>(a, vblk, tid, s_de);
+    else if (a.n_samples == 256) emb_grad_body_spl<4>(a, vblk, tid, s_de);
+    else emb_grad_body_spl<2>(a, vblk, tid, s_de);
 }
 __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
     extern __shared__ float s_de[];
@@ -478,11 +494,15 @@ hipError_t eo_launch_rendering_out_bwd(const RenderingOutBwdArgs& a, hipStream_t
     return hipGetLastError();
 }
 hipError_t eo_launch_sun_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_sun_composite_bwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    eo_dispatch_spl(a.n_samples, [&](auto spl) {
+        hipLaunchKernelGGL(k_sun_composite_bwd<decltype(spl)::value>, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    });
     return hipGetLastError();
 }
 hipError_t eo_launch_cam_composite_bwd(const CompositeBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_cam_composite_bwd, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    eo_dispatch_spl(a.n_samples, [&](auto spl) {
+        hipLaunchKernelGGL(k_cam_composite_bwd<decltype(spl)::value>, dim3((a.n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), dim3(256), 0, st, a);
+    });
     return hipGetLastError();
 }
 hipError_t eo_launch_field_grads_to_soa(const float* g_sigma, const float* g_albedo, const float* g_ts, const float* g_tb, int n, int p_pad,

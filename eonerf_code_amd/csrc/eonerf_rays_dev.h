@@ -2,6 +2,7 @@
 #pragma once
 #include "eonerf_common.h"
 #include "eonerf_rays.h"
+#include <type_traits>
 
 namespace {
 
@@ -85,32 +86,43 @@ EO_DEV AmbientRay ambient_forward(const AmbientW& w, float sx, float sy, float s
 // ---- compositing forward ------------------------------------------------------------------------------------
 //   sd = sigma*delta;  T = exp(-exclusive_sum(sd));  alpha = 1-exp(-sd);  w = T*alpha   (nerfacc v0.5.2 volrend,
 //   call sites radiance_fields/eonerf.py:229-243)            per-ray sums of w*{mid, albedo, ts, tb, 1}
-struct RayWeights { float w[2], T[2], sd[2]; float total; };
+// SPL = samples per lane: a ray has n_samples - 1 = 64 SPL - 1 intervals at most (n_samples = int(2 / render_step_size) = 64, 128 or
+// 256, sat_rendering.py:64), element i = lane + 64 k sits in slot k of its lane
+template <int SPL> struct RayWeights { float w[SPL], T[SPL], sd[SPL]; float total; };
 
-EO_DEV RayWeights ray_weights(const float* sigma, const float* delta, int off, int n, int lane) {
-    RayWeights r;
-    float sd[2];
+template <int SPL>
+EO_DEV RayWeights<SPL> ray_weights(const float* sigma, const float* delta, int off, int n, int lane) {
+    RayWeights<SPL> r;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SPL; ++k) {
         const int i = lane + 64 * k;
-        sd[k] = i < n ? sigma[off + i] * delta[off + i] : 0.f;
+        r.sd[k] = i < n ? sigma[off + i] * delta[off + i] : 0.f;
     }
     // exclusive prefix = inclusive prefix of the PREVIOUS lane (never "inclusive - self": the last interval has
-    // sigma*delta ~ 1e10 and would cancel the whole prefix)
-    const float inc0 = wave_incl_scan(sd[0], lane);
-    const float tot0 = __shfl(inc0, 63, 64);
-    const float inc1 = wave_incl_scan(sd[1], lane);
-    const float p0 = __shfl_up(inc0, 1, 64), p1 = __shfl_up(inc1, 1, 64);
-    const float ex[2] = {lane == 0 ? 0.f : p0, lane == 0 ? tot0 : tot0 + p1};
-    r.total = tot0 + __shfl(inc1, 63, 64);
+    // sigma*delta ~ 1e10 and would cancel the whole prefix), plus the total of the 64-element groups in front
+    float carry = 0.f, ex[SPL];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < SPL; ++k) {
+        const float inc = wave_incl_scan(r.sd[k], lane);
+        const float prev = __shfl_up(inc, 1, 64);
+        ex[k] = lane == 0 ? carry : carry + prev;
+        carry += __shfl(inc, 63, 64);
+    }
+    r.total = carry;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
         const int i = lane + 64 * k;
-        r.sd[k] = sd[k];
         r.T[k] = expf(-ex[k]);
-        r.w[k] = i < n ? r.T[k] * (1.f - expf(-sd[k])) : 0.f;
+        r.w[k] = i < n ? r.T[k] * (1.f - expf(-r.sd[k])) : 0.f;
     }
     return r;
+}
+
+// run f(std::integral_constant<int, SPL>) for the samples-per-lane count of n_samples (64 -> 1, 128 -> 2, 256 -> 4)
+template <class F> inline void eo_dispatch_spl(int n_samples, F&& f) {
+    if (n_samples == 64) f(std::integral_constant<int, 1>());
+    else if (n_samples == 256) f(std::integral_constant<int, 4>());
+    else f(std::integral_constant<int, 2>());
 }
 
 

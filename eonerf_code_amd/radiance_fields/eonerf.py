@@ -157,6 +157,7 @@ class EONerfMLP(nn.Module):
         self.eval_precision = (eval_precision or os.environ.get("EONERF_EVAL_PRECISION", "fp16x3")).lower()
         if self.eval_precision not in ("fp32", "fp16x3", "same"):
             raise ValueError("eval_precision must be 'fp16x3', 'fp32' or 'same'")
+        self._n_samples = 128     # int(2 / render_step_size) of the native contexts' next calls (set_n_samples: 64, 128 or 256)
         self._ctx = None          # eonerf_ctx*
         self._ctx_eval = None     # second native context (fp32) for export renders of a bf16 field, created on first use
         self._packed_version_eval = None
@@ -172,7 +173,7 @@ class EONerfMLP(nn.Module):
     def _context(self):
         if self._ctx is None:
             L = _lib.lib()
-            cfg = _lib.EonerfConfig(self.n_input_images, _lib.PRECISIONS[self.precision], 128, 1 if self.radiometric_normalization else 0)
+            cfg = _lib.EonerfConfig(self.n_input_images, _lib.PRECISIONS[self.precision], self._n_samples, 1 if self.radiometric_normalization else 0)
             ctx = C.c_void_p()
             _lib.check(L.eonerf_create(C.byref(ctx), C.byref(cfg)))
             self._ctx = ctx
@@ -197,7 +198,7 @@ class EONerfMLP(nn.Module):
         flat = self.flat_params()
         L = _lib.lib()
         if self._ctx_eval is None:
-            cfg = _lib.EonerfConfig(self.n_input_images, _lib.PRECISIONS[self.eval_precision], 128, 1 if self.radiometric_normalization else 0)
+            cfg = _lib.EonerfConfig(self.n_input_images, _lib.PRECISIONS[self.eval_precision], self._n_samples, 1 if self.radiometric_normalization else 0)
             ctx = C.c_void_p()
             _lib.check(L.eonerf_create(C.byref(ctx), C.byref(cfg)))
             self._ctx_eval = ctx
@@ -272,6 +273,18 @@ class EONerfMLP(nn.Module):
             _lib.check(_lib.lib().eonerf_set_weights(self._ctx, _ptr(flat), _stream()))
             self._packed_version = ver
         return flat
+
+    def set_n_samples(self, n_samples):
+        """n_samples = int(2 / render_step_size) (sat_rendering.py:64, opt.py:54) of the calls that follow: 64, 128 or 256 -- render_image
+        and satnerf_sampling call this with the step size they are given; everything sized 128 / 127 in the library follows it."""
+        n_samples = int(n_samples)
+        if n_samples not in (64, 128, 256):
+            raise ValueError(f"{n_samples} samples per ray: the HIP path supports render_step_size = 2/64, 2/128 (run_JAX_RGB.sh:11) and 2/256")
+        if n_samples != self._n_samples:
+            self._n_samples = n_samples
+            for ctx in (self._ctx, self._ctx_eval):
+                if ctx is not None:
+                    _lib.check(_lib.lib().eonerf_set_n_samples(ctx, n_samples))
 
     def set_noise_seed(self, seed):
         """Key of the sampler's in-kernel jitter stream (what torch.manual_seed is to perturb_z_vals' rand_like)."""

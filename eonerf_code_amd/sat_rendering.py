@@ -23,12 +23,20 @@ RESULT_SLICES = (("rgb", 0, 3), ("depth", 3, 4), ("albedo_rgb", 4, 7), ("ambient
 _ZSTEPS = {}
 
 
-def _zsteps(device):
-    z = _ZSTEPS.get(device)
+def _zsteps(device, n_samples=128):
+    z = _ZSTEPS.get((device, n_samples))
     if z is None:
-        z = torch.linspace(0, 1, 128).to(device)     # the reference's fp32 table (sat_rendering.py:67), computed once
-        _ZSTEPS[device] = z
+        z = torch.linspace(0, 1, n_samples).to(device)     # the reference's fp32 table (sat_rendering.py:67), computed once per size
+        _ZSTEPS[(device, n_samples)] = z
     return z
+
+
+def n_samples_of(render_step_size):
+    """sat_rendering.py:64: n_samples = int(2 / render_step_size); the HIP per-ray kernels exist for 64, 128 and 256."""
+    n = int(2 / render_step_size)
+    if n not in (64, 128, 256):
+        raise ValueError(f"render_step_size={render_step_size} gives {n} samples/ray; the HIP path supports 64, 128 (run_JAX_RGB.sh:11) and 256")
+    return n
 
 
 def count_number_of_pts_per_nerfacc_ray(rays, ray_indices):
@@ -40,9 +48,8 @@ def count_number_of_pts_per_nerfacc_ray(rays, ray_indices):
 @torch.no_grad()
 def satnerf_sampling(origins, viewdirs, sampling_args, near=None, far=None, perturb=True, noise=None, radiance_field=None):
     """sat_rendering.py:56-84: (ray_indices, t_starts, t_ends) of the cube-filtered stratified samples.
-    `far` is ignored exactly as in the reference (far = near + 2); noise [R,128] replaces the rand_like draw."""
-    if int(2 / sampling_args["render_step_size"]) != 128:
-        raise ValueError("the HIP sampler supports 128 samples per ray (run_JAX_RGB.sh:11)")
+    `far` is ignored exactly as in the reference (far = near + 2); noise [R,n_samples] replaces the rand_like draw."""
+    ns = n_samples_of(sampling_args["render_step_size"])
     n, dev = origins.shape[0], origins.device
     table = torch.zeros(n, 11, dtype=torch.float32, device=dev)
     table[:, 0:3], table[:, 3:6] = origins, viewdirs
@@ -50,15 +57,17 @@ def satnerf_sampling(origins, viewdirs, sampling_args, near=None, far=None, pert
         table[:, 6:7] = near.reshape(n, 1)
     # noise=None: the jitter is drawn inside the sampler kernel (Philox); perturb=False: no jitter at all (:70-71)
     u = None if (noise is None or not perturb) else noise.to(dev, torch.float32).contiguous()
-    cap = max(n * 127, 1)
+    cap = max(n * (ns - 1), 1)
     ri = torch.empty(cap, dtype=torch.int64, device=dev)
     ts_, te_ = torch.empty(cap, dtype=torch.float32, device=dev), torch.empty(cap, dtype=torch.float32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     L = _lib.lib()
     field = radiance_field if radiance_field is not None else _any_field(dev)
+    field._context()
+    field.set_n_samples(ns)
     nb = L.eonerf_render_workspace_bytes(field._ctx, n, _lib.F_ONLY_DEPTH)
     ws = field._workspace("render", nb)
-    _lib.check(L.eonerf_sample_rays(field._ctx, _ptr(table), _ptr(_zsteps(dev)), _ptr(u), 1 if perturb else 0, n, _ptr(ri), _ptr(ts_), _ptr(te_), None,
+    _lib.check(L.eonerf_sample_rays(field._ctx, _ptr(table), _ptr(_zsteps(dev, ns)), _ptr(u), 1 if perturb else 0, n, _ptr(ri), _ptr(ts_), _ptr(te_), None,
                                     _ptr(cnt), _ptr(ws), ws.numel(), _stream()))
     k = int(cnt.item())
     return ri[:k], ts_[:k], te_[:k]
@@ -86,17 +95,18 @@ class _RenderChunk(torch.autograd.Function):
         L = _lib.lib()
         train = bool(flags & _lib.F_TRAIN)
         native, flat = field._native(export and not train)      # export renders of a bf16 field: its fp32 context (EONerfMLP.eval_precision)
+        ns = field._n_samples                                   # (render_image has set it from its render_step_size)
         n = table.shape[0]
         nb = L.eonerf_render_workspace_bytes(native, n, flags)
         # a training chunk keeps its own workspace alive until its backward; inference chunks share one
         ws = torch.empty(nb, dtype=torch.uint8, device=table.device) if train else field._workspace("render", nb)
         out = torch.empty(n, 21, dtype=torch.float32, device=table.device)
         n_samples = torch.zeros(1, dtype=torch.int32, device=table.device)
-        _lib.check(L.eonerf_render_forward(native, _ptr(flat), _ptr(table), _ptr(img), _ptr(_zsteps(table.device)),
+        _lib.check(L.eonerf_render_forward(native, _ptr(flat), _ptr(table), _ptr(img), _ptr(_zsteps(table.device, ns)),
                                            _ptr(u_cam), _ptr(u_retry), _ptr(u_sun), n, flags, _ptr(out), _ptr(n_samples),
                                            _ptr(ws), ws.numel(), _stream()))
         if train:
-            ctx.field, ctx.flags, ctx.ws = field, flags, ws
+            ctx.field, ctx.flags, ctx.ws, ctx.ns = field, flags, ws, ns
             ctx.save_for_backward(table, img)
             ctx.mark_non_differentiable(n_samples)
         else:       # inference / only_depth chunks keep nothing for a backward pass: their outputs carry no graph
@@ -108,6 +118,7 @@ class _RenderChunk(torch.autograd.Function):
         field, flags, ws = ctx.field, ctx.flags, ctx.ws
         table, img = ctx.saved_tensors
         L = _lib.lib()
+        field.set_n_samples(ctx.ns)                             # the backward runs under its forward's sample count
         flat = field.flat_params()
         d_flat = torch.zeros_like(flat)
         d_out = d_out.contiguous().float()
@@ -162,10 +173,8 @@ def render_image(
     noise=None,
 ):
     """Render the pixels of an image (sat_rendering.py:176-335).  Returns (results dict, n_rendering_samples)."""
-    n_samples = int(2 / render_step_size)
-    if n_samples != 128:
-        raise ValueError(f"render_step_size={render_step_size} gives {n_samples} samples/ray; the HIP path supports 128 "
-                         "(run_JAX_RGB.sh:11)")
+    radiance_field._context()
+    radiance_field.set_n_samples(n_samples_of(render_step_size))
     rays_shape = rays.origins.shape
     if len(rays_shape) == 3:
         height, width, _ = rays_shape

@@ -44,7 +44,7 @@ def rank_slice(n_total, rank, world):
 
 class FusedTrainer:
     def __init__(self, field: EONerfMLP, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_rays: int = 4096,
-                 keep_message: bool = True):
+                 keep_message: bool = True, n_samples: int = 128):
         """keep_message=True: the gradient message survives the update (d_flat can be read after step()) and is sealed with the
         fault flag even when there are no peers -- what tests and debugging want.  The launcher and bench.py pass False: the update
         consumes the message (eonerf_adam_step_zero_grad: optimizer.step() + the next optimizer.zero_grad(), train_eonerf.py:158-161,
@@ -53,6 +53,8 @@ class FusedTrainer:
         self.keep_message = keep_message
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat = field._ensure_packed()
+        self.n_samples_per_ray = int(n_samples)      # int(2 / render_step_size), train_eonerf.py:50-53: 64, 128 or 256
+        field.set_n_samples(self.n_samples_per_ray)
         dev = self.flat.device
         self.L = _lib.lib()
         self.ctx = field._ctx
@@ -72,7 +74,7 @@ class FusedTrainer:
         self.d_out = torch.zeros(max_rays, 21, dtype=torch.float32, device=dev)
         self.n_samples = torch.zeros(1, dtype=torch.int32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.zsteps = _zsteps(dev)
+        self.zsteps = _zsteps(dev, self.n_samples_per_ray)
         if self.world > 1:     # identical replicas: broadcast rank 0's parameters once (train_eonerf.py has one process)
             torch.distributed.broadcast(self.flat, src=0)
             _lib.check(self.L.eonerf_set_weights(self.ctx, _ptr(self.flat), _stream()))
@@ -128,6 +130,7 @@ class FusedTrainer:
             u_cam = u_retry = u_sun = None
         else:
             u_cam, u_retry, u_sun = noise
+        self.field.set_n_samples(self.n_samples_per_ray)      # (another caller of the module may have rendered at another step size)
         self._render_forward(rays, img_idx, n, flags, (u_cam, u_retry, u_sun))
         loss = self.loss_grad(self.out[:n], pixels.contiguous(), epoch_idx, self.d_out)
         self._render_backward(rays, img_idx, n, flags)

@@ -48,7 +48,7 @@ typedef struct eonerf_ctx eonerf_ctx;
 typedef struct {
     int n_images;        /* EONerfMLP(n_input_images), radiance_fields/eonerf.py:70-77 */
     int precision;       /* EONERF_FP32 | EONERF_BF16 | EONERF_F16X3 */
-    int n_samples;       /* int(2/render_step_size); only 128 is supported (run_JAX_RGB.sh:11, sat_rendering.py:64) */
+    int n_samples;       /* int(2/render_step_size) (sat_rendering.py:64): 64, 128 (run_JAX_RGB.sh:11) or 256; eonerf_set_n_samples changes it */
     int radiometric;     /* radiometric_normalization (opt.py:98-99 forces 1 for eo-nerf) */
 } eonerf_config;
 
@@ -116,13 +116,19 @@ int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double
                          double sun_elevation_deg, double sun_azimuth_deg, const float offset[3], const float scale[3],
                          float* raw8, float* rays, double* geo, void* stream);
 
+/* n_samples = int(2 / render_step_size) of the calls that follow (sat_rendering.py:64, opt.py:54): 64, 128 or 256 -- the per-ray kernels are
+ * instantiated for 1, 2 and 4 samples per lane of the ray's wavefront; anything else: EONERF_E_UNSUPPORTED.  Every size below that is
+ * written with 128 / 127 (zsteps, jitter arrays, samples per ray, workspace sizes) follows it.  A backward call must run under the
+ * n_samples of its forward (the Python layer restores it). */
+int eonerf_set_n_samples(eonerf_ctx* ctx, int n_samples);
+
 /* Key of the in-kernel jitter stream (torch.manual_seed's role for perturb_z_vals' rand_like, sat_rendering.py:52;
  * data-parallel ranks use different seeds).  Every call that draws noise advances the stream. */
 int eonerf_set_noise_seed(eonerf_ctx* ctx, uint64_t seed);
 
 /* sat_rendering.satnerf_sampling (sat_rendering.py:56-84) + count_number_of_pts_per_nerfacc_ray (:10-16):
- * rays[R,11] (origin, dir and near columns are used), u[R,128] jitter -> flattened, cube-filtered samples
- * ray_indices[n] (int64), t_starts[n], t_ends[n] (capacity R*127 each), pts_per_ray[R] (fp32) and *n_dev = n.
+ * rays[R,11] (origin, dir and near columns are used), u[R,n_samples] jitter -> flattened, cube-filtered samples
+ * ray_indices[n] (int64), t_starts[n], t_ends[n] (capacity R*(n_samples-1) each), pts_per_ray[R] (fp32) and *n_dev = n.
  * perturb = 0: the z values stay on the uniform grid (perturb=False, :70-71 skipped; u is ignored).  perturb != 0 with
  * u == NULL: the jitter is drawn inside the kernel (Philox4x32-10, eonerf_set_noise_seed). */
 int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, const float* u, int perturb, int n_rays,
@@ -154,8 +160,9 @@ int eonerf_rendering_backward(eonerf_ctx* ctx, const float* flat_params, const f
 
 /* One chunk of sat_rendering.render_image (sat_rendering.py:252-312) = satnerf_sampling + EONerfMLP.rendering +
  * compute_geometric_shadows + irradiance/radiometric model + output packing.
- *   rays[R,11] fp32 (o3 d3 near far sun3), img_idx[R] int64, zsteps[128] = linspace(0,1,128),
- *   u_cam/u_sun[R,128] jitter in [0,1) (the reference draws rand_like inside perturb_z_vals, :52),
+ *   rays[R,11] fp32 (o3 d3 near far sun3), img_idx[R] int64, zsteps[n_samples] = linspace(0,1,n_samples) (n_samples: 128 unless
+ *   eonerf_set_n_samples said otherwise),
+ *   u_cam/u_sun[R,n_samples] jitter in [0,1) (the reference draws rand_like inside perturb_z_vals, :52),
  *   u_retry (may be NULL): noise of the ":260-262 resample if some ray is empty" branch.
  *   u_cam == NULL (then u_retry and u_sun must be NULL too): production mode, no noise buffers -- the sampler kernels draw the
  *   jitter themselves (Philox4x32-10 keyed by eonerf_set_noise_seed, counter = (ray, sample lane, draw, call number); the

@@ -296,6 +296,50 @@ def g8():
     save("g8_render", **out)
 
 
+# ------------------------------------------------------------------ G10 other step sizes: n_samples = int(2 / render_step_size) = 64, 256
+def g10(ns):
+    """sat_rendering.py:64 / opt.py:54 accept any --n_samples; the build implements 64, 128 and 256.  The G4 sampler rays and a short G8
+    (render_image forward for epoch_idx 0 and 3, loss, reference autograd) at the other two sizes."""
+    step = 2.0 / ns
+    o, d = _g4_rays()
+    u = rand_with_replay((o.shape[0], ns), 44 + ns)
+    ri, ts_, te_ = ref_sr.satnerf_sampling(o, d, {"render_step_size": step}, near=torch.zeros(o.shape[0], 1))
+    pts = ref_sr.count_number_of_pts_per_nerfacc_ray(types.SimpleNamespace(origins=o), ri)
+    out = {"origins": o, "viewdirs": d, "u": u, "step": step, "ray_indices": ri, "t_starts": ts_, "t_ends": te_, "pts_per_ray": pts,
+           "z_steps": torch.linspace(0, 1, ns)}
+    n_img, R = 5, 32
+    sd = orc.closed_form_state_dict(n_img)
+    sd["sigma_layer.output_layer.bias"] = sd["sigma_layer.output_layer.bias"] + 1.5
+    f = _ref_field(n_img, sd)
+    rays, ts, rgbs, _, _ = orc.synthetic_batch(R, n_img, seed=8 + ns)
+    rays[28:31, :3], rays[28:31, 3:6] = o[50:53], d[50:53]        # rays that exit through the side faces ...
+    rays[28:31, :2] *= 0.93                                       # ... after a few samples at every step size (no empty ray: no retry draw)
+    satrays = define_satrays_from_tensors(rays, ts)
+    args = types.SimpleNamespace()
+    out.update({"rays": rays, "ts": ts, "rgbs": rgbs, "n_img": n_img, "sigma_bias_shift": 1.5})
+    for tag, epoch in (("e0", 0), ("e3", 3)):
+        seed = 1000 + ns + epoch
+        torch.manual_seed(seed)
+        u1, u2 = torch.rand(R, ns), torch.rand(R, ns)
+        torch.manual_seed(seed)          # rand_like draws: camera pass, then sun pass
+        f.zero_grad()
+        res, n = ref_sr.render_image(f, None, satrays, None, args, epoch_idx=epoch, chunk=R, render_step_size=step)
+        keys = ["rgb", "depth", "albedo_rgb", "ambient_rgb", "geo_shadows", "transient_s", "beta", "entropy",
+                "pts_per_ray", "sc_pts_per_ray", "opacity_after_surface", "shadowless_rgb"]
+        packed = torch.cat([res[k] for k in keys], dim=1)
+        assert not (packed[:, 14] == 0).any()      # no retry draw in this fixture
+        out.update({f"{tag}.u_cam": u1, f"{tag}.u_sun": u2, f"{tag}.out": packed, f"{tag}.n_samples": n})
+        if epoch < 2:
+            loss = torch.nn.functional.mse_loss(res["rgb"], rgbs)
+        else:
+            loss, _ = ref_metrics.uncertainty_aware_loss(rgbs, res["rgb"], res["beta"])
+        loss.backward()
+        out[f"{tag}.loss"] = loss
+        for k, p in f.named_parameters():
+            out[f"{tag}.grad.{k}"] = compact_grad(p.grad if p.grad is not None else torch.zeros_like(p))
+    save(f"g10_n{ns}", **out)
+
+
 # ------------------------------------------------------------------ G9 vanilla NeRF field (BASELINE.json configs[0])
 def vanilla_fill(name, shape):
     """Closed-form weights of the G9 field: only this formula is committed, both sides regenerate the tensors from it."""
@@ -347,6 +391,7 @@ def g9():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for name, fn in (("g1", g1), ("g2", g2), ("g3_g7", g3_g7), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8), ("g9", g9)):
+    for name, fn in (("g1", g1), ("g2", g2), ("g3_g7", g3_g7), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8), ("g9", g9),
+                     ("g10", lambda: (g10(64), g10(256)))):
         if not only or name in only:
             fn()

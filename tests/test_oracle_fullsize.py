@@ -161,7 +161,9 @@ def test_bf16_backward_matches_the_bf16_arithmetic_model_at_the_bench_size(batch
     print(f"[fullsize bf16 backward epoch {epoch}] worst per-tensor rel L2 / cosine: " + ", ".join(f"{n} {r:.2e}/{c:.5f}" for r, c, n in rows[:6]))
 
 
-P999_BOUND = 1e-2      # (measured values: see the test's print)
+# Bounds = ~5 x the values measured on MI355X (round 5, printed by the test: worst column max 2.2e-4, p99.9 1.3e-4, mean 1.4e-5); the
+# round-4 gate was max 3e-2 / mean 1e-3, wide enough at the tail to hide a single-ray defect
+MAX_BOUND, P999_BOUND, MEAN_BOUND = 1.5e-3, 6e-4, 7e-5
 
 
 @pytest.mark.parametrize("epoch", [0, 3])
@@ -182,7 +184,7 @@ def test_bf16_forward_matches_the_bf16_emulating_oracle_at_the_bench_size(batch,
         # sample flips a bf16 rounding of sigma): a single-ray defect shows in p99.9 only if it hits > 4 rays, in the max always
         p999 = d.flatten().kthvalue(max(1, int(0.999 * d.numel()))).values.item()
         stats.append(f"{name} max {d.max().item():.1e} p99.9 {p999:.1e} mean {d.mean().item():.1e}")
-        assert d.max().item() < 3e-2 and p999 < P999_BOUND and d.mean().item() < 1e-3, (name, d.max().item(), p999, d.mean().item())
+        assert d.max().item() < MAX_BOUND and p999 < P999_BOUND and d.mean().item() < MEAN_BOUND, (name, d.max().item(), p999, d.mean().item())
     print(f"[fullsize bf16 forward epoch {epoch}] " + "; ".join(stats))
     if epoch >= 2:      # rays whose shadow ray keeps/loses a sample at the cube face differ by a whole sample: rare
         assert (res["sc_pts_per_ray"].cpu() != ref[:, 15:16]).float().mean().item() < 0.02
