@@ -511,6 +511,16 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     //     0.26 at 512 and 0.28 at 352 (heavy items spill into a second round)
     //   many jobs (the full state with the pipelined trunk: 11): ~2.5 items per CU: flat (0.472-0.478 ms) from 650 to 830 items,
     //     0.49-0.50 at 512-600 and at 1,024
+    {   // diagnostics (scripts/wgrad_jobs.sh): EONERF_WGRAD_MASK keeps only the jobs whose bit is set -- gradients are WRONG, timing only
+        static const char* mk = getenv("EONERF_WGRAD_MASK");
+        if (mk) {
+            const unsigned long mask = strtoul(mk, nullptr, 0);
+            int k = 0;
+            for (int i = 0; i < tab.n; ++i) if (mask & (1ul << i)) { if (i == tab.aux.job) tab.aux.job = k; else if (k == tab.aux.job && i != k) tab.aux.job = -1; tab.j[k] = tab.j[i]; late[k] = late[i]; ++k; }
+            if (tab.aux.job >= k) tab.aux.job = -1;
+            tab.n = k;
+        }
+    }
     double wmax = 0.0, wj[WGRAD_MAX_JOBS];
     for (int k = 0; k < tab.n; ++k) {
         wj[k] = (double)((tab.j[k].m_rows + 15) / 16 * 16 + (tab.j[k].n_rows + 15) / 16 * 16) * SEG_B;
@@ -1192,11 +1202,12 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     return EONERF_OK;
 }
 
-int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
-                           int n_rays, int flags, const float* d_out, float* d_flat,
-                           void* ws, size_t ws_bytes, void* stream) {
+struct LossSpec { const float *out, *pixels; int kind; float* loss; };      // fused loss (eonerf_render_backward_loss) or nullptr
+static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
+                                int n_rays, int flags, const float* d_out, const LossSpec* ls, float* d_flat,
+                                void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!ctx || !flat || !rays || !img_idx || !d_out || !d_flat || n_rays < 0 || !ws) return EONERF_E_ARG;
+    if (!ctx || !flat || !rays || !img_idx || (!d_out && !ls) || !d_flat || n_rays < 0 || !ws) return EONERF_E_ARG;
     if (!(flags & EONERF_F_TRAIN) || (flags & EONERF_F_ONLY_DEPTH)) return EONERF_E_STATE;
     if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
     if (!ctx->weights_set) return EONERF_E_STATE;
@@ -1215,11 +1226,22 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
     // ---- d out -> d ray record (+ radiometric table) -----------------------------------------------------
     ShadeBwdArgs sb;
     sb.ray_rec = w.ray_rec; sb.d_out = d_out; sb.img_idx = img_idx;
+    sb.loss_kind = -1; sb.loss_out = nullptr; sb.loss_gt = nullptr; sb.loss = nullptr; sb.loss_scratch = nullptr;
+    if (ls) { sb.loss_kind = ls->kind; sb.loss_out = ls->out; sb.loss_gt = ls->pixels; sb.loss = ls->loss; sb.loss_scratch = ctx->loss_scratch; }
     sb.radiometric = ctx->cfg.radiometric ? flat + pl.t[pl.rad].offset : nullptr;
     sb.d_radiometric = ctx->cfg.radiometric ? dptr(pl.rad) : nullptr;
     sb.g_ray = w.g_ray; sb.n_rays = n_rays; sb.use_shadow = shadows ? 1 : 0; sb.eval = (flags & EONERF_F_EVAL) ? 1 : 0;
     sb.lds_images = ctx->cfg.n_images <= 2048 ? ctx->cfg.n_images : 0;
     sb.d_rad_rays = sb.d_radiometric ? w.det.rad_rays : nullptr;
+    // pipelined path: this first kernel of the call also zeroes [bottleneck factors | GEMM queue | sync blocks] (pipe_clear's memset)
+    const bool prezeroed = ctx->pipe && w.pipe.dy_in;
+    sb.zero_base = nullptr; sb.zero_bytes = 0;
+    if (prezeroed) {
+        uint8_t* lo = reinterpret_cast<uint8_t*>(w.m_bott);
+        uint8_t* hi = reinterpret_cast<uint8_t*>(w.pipe.sync) + PIPE_LAUNCHES * w.pipe.sync_bytes;
+        sb.zero_base = reinterpret_cast<uint32_t*>(lo); sb.zero_bytes = (size_t)(hi - lo);
+        if ((reinterpret_cast<uintptr_t>(lo) | sb.zero_bytes) & 15) return EONERF_E_STATE;
+    }
     HIP_TRY(eo_launch_shade_bwd(sb, st));
     if (sb.d_rad_rays) HIP_TRY(eo_launch_table_reduce(sb.d_rad_rays, img_idx, n_rays, 6, 9, ctx->cfg.n_images, sb.eval, sb.d_radiometric, st));
 
@@ -1251,7 +1273,7 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
             ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
             ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
             ambient_done = pipe_spare_cus(ctx) > 0;
-            const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, EONERF_PROF_BWD_PIPE_SUN, st, 0, true, ambient_done ? &ag : nullptr);
+            const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, EONERF_PROF_BWD_PIPE_SUN, st, 0, !prezeroed, ambient_done ? &ag : nullptr);
             if (rcp) return rcp;
             IgTailArgs ta;
             ta.n_pts = w.sun.n_pts; ta.p_pad = p_cap; ta.grd = w.sun.grd; ta.wt = ctx->ig_tail_wt.data;
@@ -1263,8 +1285,28 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays
         }
     }
 
-    return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows && !ambient_done, !shadows,
+    return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows && !ambient_done, !shadows && !prezeroed,
                            shadows ? &w.sun : nullptr, false, st);
+}
+
+int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
+                           int n_rays, int flags, const float* d_out, float* d_flat,
+                           void* ws, size_t ws_bytes, void* stream) {
+    if (!d_out) return EONERF_E_ARG;
+    return render_backward_impl(ctx, flat, rays, img_idx, n_rays, flags, d_out, nullptr, d_flat, ws, ws_bytes, stream);
+}
+
+int eonerf_render_backward_loss(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
+                                int n_rays, int flags, const float* out, const float* pixels, int kind, float* d_out_scratch, float* loss,
+                                float* d_flat, void* ws, size_t ws_bytes, void* stream) {
+    if (!ctx || !out || !pixels || !loss || (kind != 0 && kind != 1) || n_rays < 1) return EONERF_E_ARG;
+    if ((n_rays + 255) / 256 > LOSS_MAX_BLOCKS) {      // beyond the fused kernel's ticket sum: the two calls it replaces
+        if (!d_out_scratch) return EONERF_E_ARG;
+        const int rc = eonerf_train_loss(ctx, out, pixels, n_rays, kind, d_out_scratch, loss, stream);
+        return rc ? rc : render_backward_impl(ctx, flat, rays, img_idx, n_rays, flags, d_out_scratch, nullptr, d_flat, ws, ws_bytes, stream);
+    }
+    const LossSpec ls{out, pixels, kind, loss};
+    return render_backward_impl(ctx, flat, rays, img_idx, n_rays, flags, nullptr, &ls, d_flat, ws, ws_bytes, stream);
 }
 
 // diagnostics: copies the cycle sums of the last pipelined backward ([n_pipes * 7 roles][2 waves][8] u64) to the host; returns the

@@ -71,6 +71,14 @@ struct ShadeBwdArgs {
     int n_rays, use_shadow, eval;
     int lds_images;             // > 0: accumulate d_radiometric[n_img][6] in LDS first (n_img <= 2048)
     float* d_rad_rays;          // deterministic mode: [R][6] per-ray contributions instead of atomics (summed in ray order afterwards)
+    // the first kernel of a backward call also zeroes what the call's later launches need zeroed (bottleneck factors, GEMM work queue,
+    // the pipelined launches' sync blocks: one contiguous region of the workspace) -- a memset launch fewer; nullptr: nothing
+    uint32_t* zero_base; size_t zero_bytes;      // 16-byte aligned, a multiple of 16 bytes
+    // loss_kind >= 0: d_out is NOT read -- the training loss of eo_launch_loss (kind 0 MSE, 1 uncertainty-aware) is evaluated here on the
+    // forward's packed outputs `loss_out` [R][21] against `loss_gt` [R][3], its gradient feeds the shading backward directly and the
+    // scalar goes to *loss (same fixed-order ticket sum, scratch as in eo_launch_loss): one launch for train_eonerf.py:139-143 + the head
+    // of :160.  Needs (n_rays + 255) / 256 <= LOSS_MAX_BLOCKS
+    int loss_kind; const float *loss_out, *loss_gt; float *loss, *loss_scratch;
 };
 
 struct CompositeBwdArgs {

@@ -184,12 +184,50 @@ __global__ __launch_bounds__(1024) void k_scan(SampleArgs a) {
 }
 
 // ---- kernel 3: recompute the samples and write them compactly ---------------------------------------------
-template <int SPL>
+// SCAN: the launch has no k_scan in front (batches of up to SCAN_FUSED_MAX_RAYS rays): every block sums the counts of the rays in front of
+// its own itself -- 2 x 16 KB of L2-resident reads per block at 4096 rays, a few microseconds for the whole grid, against a launch of
+// its own for a 4096-element scan -- and decides the "resample if any ray is empty" branch (sat_rendering.py:260-262) from the same pass;
+// block 0 leaves the totals (n_pts, offsets[R], the retry flag).
+constexpr int SCAN_FUSED_MAX_RAYS = 8192;
+template <int SPL, bool SCAN>
 __global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
-    const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ray = blockIdx.x * RAYS_PER_BLOCK + wave;
+    bool retry_scan = false;
+    int off_scan = 0;
+    if constexpr (SCAN) {
+        __shared__ int s_red[RAYS_PER_BLOCK][5];
+        const int base = blockIdx.x * RAYS_PER_BLOCK;
+        int v[5] = {0, 0, 0, 0, 0};      // counts in front of this block (first draw, retry draw), totals (first, retry), any empty ray
+        for (int i = threadIdx.x; i < a.n_rays; i += 256) {
+            const int cf = a.cnt_first[i], cr = a.retry ? a.cnt_retry[i] : cf;
+            v[2] += cf; v[3] += cr; v[4] |= cf == 0 ? 1 : 0;
+            if (i < base) { v[0] += cf; v[1] += cr; }
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v[q], o, 64); v[q] = q == 4 ? (v[q] | t) : (v[q] + t); }
+        }
+        if (lane == 0) { for (int q = 0; q < 5; ++q) s_red[wave][q] = v[q]; }
+        __syncthreads();
+        int t[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) t[q] = q == 4 ? (s_red[0][q] | s_red[1][q] | s_red[2][q] | s_red[3][q]) : (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);
+        retry_scan = a.retry && t[4] != 0;
+        const int* cnt = retry_scan ? a.cnt_retry : a.cnt_first;
+        off_scan = retry_scan ? t[1] : t[0];
+        for (int j = base; j < ray && j < a.n_rays; ++j) off_scan += cnt[j];
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const int total = retry_scan ? t[3] : t[2];
+            a.flags[0] = retry_scan ? 1 : 0;
+            a.offsets[a.n_rays] = total; *a.n_pts = total;
+            if (a.n_pts_copy) *a.n_pts_copy = total;
+        }
+        if (ray < a.n_rays && lane == 0) { a.offsets[ray] = off_scan; a.counts[ray] = cnt[ray]; }
+    }
     if (ray >= a.n_rays) return;
     const RayGeom g = ray_geom(a, ray);
-    const bool retry = a.retry && (*a.flags & 1);
+    const bool retry = SCAN ? retry_scan : (a.retry && (*a.flags & 1));
     float u[SPL];
     jitter<SPL>(a, retry ? a.u_retry : a.u, retry ? 1 : (a.sun_pass ? 2 : 0), ray, lane, u);
     const RaySamples<SPL> s = sample_ray<SPL>(a.zsteps, a.perturb, u, retry ? 0.f : g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
@@ -197,7 +235,7 @@ __global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
     int before[SPL], n = 0;
 #pragma unroll
     for (int k = 0; k < SPL; ++k) { m[k] = __ballot(s.valid[k]); before[k] = n; n += __popcll(m[k]); }
-    const int off = a.offsets[ray];
+    const int off = SCAN ? off_scan : a.offsets[ray];
     const unsigned long long below = (1ull << lane) - 1ull;
     const int img = a.img_idx ? (int)a.img_idx[ray] : 0;
 #pragma unroll
@@ -410,8 +448,12 @@ hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st, bool counted) 
     eo_dispatch_spl(a.n_samples, [&](auto spl) {
         constexpr int SPL = decltype(spl)::value;
         if (!counted) hipLaunchKernelGGL(k_count<SPL>, dim3(blocks), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a);
-        hipLaunchKernelGGL(k_emit<SPL>, dim3(blocks), dim3(256), 0, st, a);
+        if (a.n_rays <= SCAN_FUSED_MAX_RAYS) {      // the scan rides in the emit kernel
+            hipLaunchKernelGGL((k_emit<SPL, true>), dim3(blocks), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a);
+            hipLaunchKernelGGL((k_emit<SPL, false>), dim3(blocks), dim3(256), 0, st, a);
+        }
     });
     return hipGetLastError();
 }

@@ -13,14 +13,41 @@ namespace {
 __global__ __launch_bounds__(256) void k_shade_bwd(ShadeBwdArgs a) {
     extern __shared__ float s_dT[];                    // [n_img][6] block-local radiometric gradient (0 floats if unused)
     const int ray = blockIdx.x * 256 + threadIdx.x;
+    if (a.zero_base) {
+        u32x4* z = reinterpret_cast<u32x4*>(a.zero_base);
+        const size_t n16 = a.zero_bytes / 16;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) z[i] = u32x4{0u, 0u, 0u, 0u};
+    }
     const bool lds_acc = a.d_radiometric && a.lds_images > 0 && !a.d_rad_rays;
     if (lds_acc) {
         for (int i = threadIdx.x; i < a.lds_images * 6; i += 256) s_dT[i] = 0.f;
         __syncthreads();
     }
+    float loss_part = 0.f;
     if (ray < a.n_rays) {
         const float* r = a.ray_rec + (size_t)ray * RAY_REC;
-        const float* go = a.d_out + (size_t)ray * 21;
+        float go[21];
+        if (a.loss_kind < 0) {
+#pragma unroll
+            for (int c = 0; c < 21; ++c) go[c] = a.d_out[(size_t)ray * 21 + c];
+        } else {      // the loss and its gradient, exactly as k_loss computes them
+#pragma unroll
+            for (int c = 0; c < 21; ++c) go[c] = 0.f;
+            const float* o = a.loss_out + (size_t)ray * 21;
+            const int n = a.n_rays;
+            const float inv = 1.f / (3.f * n);
+            if (a.loss_kind == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const float df = o[c] - a.loss_gt[(size_t)ray * 3 + c]; loss_part += df * df * inv; go[c] = 2.f * df * inv; }
+            } else {
+                const float beta = o[12], ib2 = 1.f / (beta * beta);
+                float sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const float df = o[c] - a.loss_gt[(size_t)ray * 3 + c]; sq += df * df; go[c] = df * ib2 * inv; }
+                loss_part += 0.5f * sq * ib2 * inv + 0.5f * logf(beta) / n;
+                go[12] = -sq * ib2 / beta * inv + 0.5f / (n * beta);
+            }
+        }
         float* g = a.g_ray + (size_t)ray * RAY_REC;
         const float wsum = r[RR_WSUM], ts = r[RR_TS];
         const float geo = a.use_shadow ? r[RR_GEO] : 1.0f;
@@ -64,6 +91,26 @@ __global__ __launch_bounds__(256) void k_shade_bwd(ShadeBwdArgs a) {
             const float v = s_dT[i];
             if (v != 0.f) atomicAdd(a.d_radiometric + (i / 6) * 9 + (i % 6), v);
         }
+    }
+    if (a.loss_kind >= 0) {      // the scalar: per-block partials, summed in block order by the last block to arrive (as k_loss)
+        __shared__ float s_part[4];
+        __shared__ int s_last;
+        loss_part = wave_sum(loss_part);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = loss_part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.loss_scratch[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+            __threadfence();
+            int* ticket = reinterpret_cast<int*>(a.loss_scratch + LOSS_MAX_BLOCKS);
+            s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!s_last || threadIdx.x != 0) return;
+        __threadfence();
+        float total = a.loss_kind == 1 ? 1.5f : 0.f;                 // the constant 3/2 of the beta term (metrics.py:20)
+        for (unsigned b = 0; b < gridDim.x; ++b) total += __hip_atomic_load(a.loss_scratch + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *a.loss = total;
+        *reinterpret_cast<int*>(a.loss_scratch + LOSS_MAX_BLOCKS) = 0;
     }
 }
 

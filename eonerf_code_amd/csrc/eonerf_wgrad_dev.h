@@ -6,6 +6,14 @@
 #include "eonerf_kernels.h"
 #include <type_traits>
 
+// Diagnostic builds only (scripts/wgrad_ablate.sh): EO_WG_ABL bit 0 drops the atomic flush of an item's tile, bit 1 the MFMAs, bit 2 the LDS-DMA
+// of the operands (the counted waits then wait for nothing), bit 3 the per-step barrier.  Results are WRONG with any bit set.
+#ifndef EO_WG_ABL
+#define EO_WG_ABL 0
+#endif
+
+#define EO_WG_MMA(a, b, c) ((EO_WG_ABL & 2) ? (c) : P::mma(a, b, c))
+
 namespace eo_wgrad {
 
 constexpr int WG_NT = 512;
@@ -130,6 +138,7 @@ EO_DEV void wgrad_work(const Tab& tab, int* queue, float* partials, uint8_t* sme
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_aux + slot * AUX_B + 1024), 16, lane * 16, 0, 0, 2);
         }
         }
+        if (EO_WG_ABL & 4) return;
         uint8_t* base = smem + slot * SLOT_B + (32 * wid) * ROW_B;
         const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.a)) + (size_t)step * job.a_stride, 0, job.m_rows * SEG_B, 0x00020000);
@@ -193,7 +202,8 @@ EO_DEV void wgrad_work(const Tab& tab, int* queue, float* partials, uint8_t* sme
             const int slot = (s - s0) & (NS - 1);
             // this wave's share of step s has landed once at most (DEPTH-1) younger steps are outstanding; the barrier then
             // (a) publishes every wave's share and (b) retires all reads of the slot refilled next
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_DMA * (DEPTH - 1)) : "memory");
+            if (EO_WG_ABL & 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DMA * (DEPTH - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_DMA * (DEPTH - 1)) : "memory");
             issue(s + DEPTH < s1 ? s + DEPTH : s1 - 1, (slot + DEPTH) & (NS - 1), aux_c);
             if (active) {
                 const uint8_t* T = smem + slot * SLOT_B;
@@ -219,8 +229,8 @@ EO_DEV void wgrad_work(const Tab& tab, int* queue, float* partials, uint8_t* sme
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             const U af = __builtin_bit_cast(U, u32x4{t[4 * kg + 2 * i][0], t[4 * kg + 2 * i][1], t[4 * kg + 2 * i + 1][0], t[4 * kg + 2 * i + 1][1]});
-                            acc[i][0] = P::mma(af, bf0, acc[i][0]);
-                            if (do_bias && i == wn_idx) accb = P::mma(af, ones, accb);
+                            acc[i][0] = EO_WG_MMA(af, bf0, acc[i][0]);
+                            if (do_bias && i == wn_idx) accb = EO_WG_MMA(af, ones, accb);
                         }
                     }
                 } else {
@@ -238,7 +248,7 @@ EO_DEV void wgrad_work(const Tab& tab, int* queue, float* partials, uint8_t* sme
                         if (sig_here) {      // wave-uniform
                             U as = P::zero();
                             if (r == 0) as = lds_unit<P>(X);                                                    // row 0 = d sigma_pre
-                            sr->acc = P::mma(as, wm_idx == 0 ? bf[0] : bf[NMAX - 1], sr->acc);
+                            sr->acc = EO_WG_MMA(as, wm_idx == 0 ? bf[0] : bf[NMAX - 1], sr->acc);
                             if (wid == 0) {
 #pragma unroll
                                 for (int e = 0; e < P::NE; ++e) sr->b += (float)as[e];
@@ -250,8 +260,8 @@ EO_DEV void wgrad_work(const Tab& tab, int* queue, float* partials, uint8_t* sme
                         if (i < wm) {
 #pragma unroll
                             for (int j = 0; j < NMAX; ++j)
-                                if (j < wn) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
-                            if (do_bias && i == wn_idx) accb = P::mma(af[i], baux, accb);
+                                if (j < wn) acc[i][j] = EO_WG_MMA(af[i], bf[j], acc[i][j]);
+                            if (do_bias && i == wn_idx) accb = EO_WG_MMA(af[i], baux, accb);
                         }
                 }
                 }
@@ -311,7 +321,7 @@ EO_DEV void wgrad_work(const Tab& tab, int* queue, float* partials, uint8_t* sme
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail prefetches before the LDS is released
 
     // ---- flush: fp32 atomics, 32 consecutive columns per half-wave instruction ----
-    if (active) {
+    if (active && !(EO_WG_ABL & 1)) {
 #pragma unroll
     for (int i = 0; i < WMAX; ++i)
         if (i < wm) {

@@ -51,6 +51,7 @@ class FusedTrainer:
         in one kernel) and a single process skips the seal (k_adam reads the status word itself): two launches fewer per step."""
         self.field = field
         self.keep_message = keep_message
+        self.fused_loss = os.environ.get("EONERF_FUSED_LOSS", "1") != "0"      # (A/B and test switch: 0 = eonerf_train_loss + eonerf_render_backward)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat = field._ensure_packed()
         self.n_samples_per_ray = int(n_samples)      # int(2 / render_step_size), train_eonerf.py:50-53: 64, 128 or 256
@@ -132,6 +133,9 @@ class FusedTrainer:
             u_cam, u_retry, u_sun = noise
         self.field.set_n_samples(self.n_samples_per_ray)      # (another caller of the module may have rendered at another step size)
         self._render_forward(rays, img_idx, n, flags, (u_cam, u_retry, u_sun))
+        if self.fused_loss:      # loss + backward in one library call: d out[R,21] is never written (eonerf_render_backward_loss)
+            self._render_backward(rays, img_idx, n, flags, pixels=pixels.contiguous(), kind=0 if epoch_idx < 2 else 1)
+            return self.loss
         loss = self.loss_grad(self.out[:n], pixels.contiguous(), epoch_idx, self.d_out)
         self._render_backward(rays, img_idx, n, flags)
         return loss
@@ -142,13 +146,17 @@ class FusedTrainer:
                                                 _ptr(noise[0]), _ptr(noise[1]), _ptr(noise[2]), n, flags, _ptr(self.out), _ptr(self.n_samples),
                                                 _ptr(ws), ws.numel(), st))
 
-    def _render_backward(self, rays, img_idx, n, flags):
+    def _render_backward(self, rays, img_idx, n, flags, pixels=None, kind=0):
         ws, st = self._workspace(n, flags), _stream()
         if not self._grad_clean:      # (the update consumes the message: eonerf_adam_step_zero_grad)
             self.d_flat.zero_()
         self._grad_clean = False
-        _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
-                                                 _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
+        if pixels is not None:
+            _lib.check(self.L.eonerf_render_backward_loss(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.out), _ptr(pixels),
+                                                          kind, _ptr(self.d_out), _ptr(self.loss), _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
+        else:
+            _lib.check(self.L.eonerf_render_backward(self.ctx, _ptr(self.flat), _ptr(rays), _ptr(img_idx), n, flags, _ptr(self.d_out),
+                                                     _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
         if self.keep_message or self._exchanges():     # the flag travels with the message; alone, k_adam reads the status word itself
             _lib.check(self.L.eonerf_grad_seal(self.ctx, _ptr(self.d_flat), st))
 

@@ -184,6 +184,15 @@ int eonerf_render_backward(eonerf_ctx* ctx, const float* flat_params, const floa
                            int n_rays, int flags, const float* d_out, float* d_flat_params,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* eonerf_train_loss + eonerf_render_backward in one call (train_eonerf.py:139-143 and :160 back to back, what a training loop does): the
+ * loss of `kind` on the forward's packed outputs out[R,21] against pixels[R,3] -> *loss (device scalar, bit-identical to eonerf_train_loss's)
+ * and, without d out[R,21] ever being written, the gradients of every parameter ACCUMULATED into d_flat_params -- the loss gradient is
+ * formed inside the backward's first kernel (one launch fewer per step).  d_out_scratch[R,21] is only used beyond 65,536 rays per call
+ * (there the two calls run one after the other) and may be NULL below. */
+int eonerf_render_backward_loss(eonerf_ctx* ctx, const float* flat_params, const float* rays, const int64_t* img_idx,
+                                int n_rays, int flags, const float* out, const float* pixels, int kind, float* d_out_scratch, float* loss,
+                                float* d_flat_params, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Device-side health.  In bf16 mode the trunk / heads backward are persistent, layer-pipelined kernels whose workgroups hand
  * tiles to each other inside the launch; every wait in them is bounded by a wall-clock watchdog, so a launch always drains, and a
  * wait that expired is recorded in a STICKY status word owned by the context: no later launch clears it, eonerf_adam_step refuses

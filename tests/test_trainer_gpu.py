@@ -317,3 +317,21 @@ def test_ten_step_trajectory_across_the_loss_switch_follows_the_oracle_under_tor
         assert err <= bound and cos > 0.998, (name, err, ref_err, d64.norm().item(), cos)
     print(f"10-step trajectory: losses (oracle, hip) first {losses[0]}, at the switch {losses[5]}, last {losses[-1]}; "
           f"worst movement err / bound {worst:.3f}, worst cosine to the fp32 oracle {worst_cos:.6f}")
+
+
+@pytest.mark.parametrize("precision,epoch", [("fp32", 0), ("fp32", 3), ("bf16", 3)])
+def test_fused_loss_backward_matches_the_two_calls_it_replaces(precision, epoch):
+    """eonerf_render_backward_loss (train_eonerf.py:139-143 + :160 in one call: the loss gradient is formed inside the backward's first
+    kernel, d out[R,21] is never written) against eonerf_train_loss + eonerf_render_backward: the same per-ray arithmetic and the same
+    fixed-order loss sum -- the loss is bit identical, the gradients differ by the order of the backward's fp32 atomics only."""
+    rays, img, pix, noise = _batch()
+    res = []
+    for fused in (True, False):
+        f, tr, _ = _make(seed=91, precision=precision)
+        tr.fused_loss = fused
+        loss = tr.step(rays, img, pix, epoch, noise=noise).clone()
+        tr.check_device_status()
+        res.append((float(loss), tr.d_flat.clone()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.isfinite(res[0][1]).all() and res[0][1].norm().item() > 0
+    assert (res[0][1] - res[1][1]).norm().item() <= 2e-6 * res[1][1].norm().item()
