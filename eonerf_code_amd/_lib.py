@@ -49,8 +49,18 @@ def build(verbose=False):
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
     digest, stamp = h.hexdigest(), os.path.join(CSRC, "libeonerf_hip.digest")
-    if os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest and not os.environ.get("EONERF_LIB"):
-        return LIB_PATH
+
+    def so_digest():
+        with open(LIB_PATH, "rb") as fh:
+            return hashlib.sha1(fh.read()).hexdigest()
+
+    # the stamp names the sources AND the library build() itself produced from them with the Makefile's own flags: a library that was
+    # rebuilt by hand afterwards (an ablation build: make CXXFLAGS=... -DEO_ABL=..) does not match it and is rebuilt from scratch
+    recorded = open(stamp).read().split() if os.path.exists(stamp) else []
+    if not os.environ.get("EONERF_LIB") and os.path.exists(LIB_PATH) and len(recorded) == 2 and recorded[0] == digest:
+        if recorded[1] == so_digest():
+            return LIB_PATH
+        subprocess.run(["make", "-C", CSRC, "clean"], capture_output=True, text=True)
     cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
@@ -58,8 +68,9 @@ def build(verbose=False):
         print(r.stderr[-8000:])
     if r.returncode:
         raise RuntimeError("building libeonerf_hip.so failed")
-    with open(stamp, "w") as fh:
-        fh.write(digest + "\n")
+    if not os.environ.get("EONERF_LIB"):
+        with open(stamp, "w") as fh:
+            fh.write(digest + " " + so_digest() + "\n")
     return LIB_PATH
 
 
