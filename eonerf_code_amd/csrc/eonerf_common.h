@@ -461,21 +461,21 @@ EO_DEV Sl<PH3> split_pair(float a0, float a1) {
     return Sl<PH3>{__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo)};
 }
 // (no ReLU masks in this precision: inference only.  The `bits` / mask words carry the RANGE check instead: |v| > 65504 rounds to an
-//  infinite hi half -- and lo = v - inf = -inf, a NaN operand that the next ReLU would silently turn into 0.  One compare per element into
-//  a WAVE-UNIFORM word (ballot: scalar registers, scalar ORs -- the kernel has no vector register to spare), OR-accumulated per sample
-//  tile, looked at once per tile in k_mlp_fwd, reported through eonerf_range_status.)
-EO_DEV uint32_t f16_range_probe(float a0, float a1) {
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(a0 > 65504.f || a1 > 65504.f);
-    return (uint32_t)b | (uint32_t)(b >> 32);
-}
+//  infinite hi half -- and lo = v - inf = -inf, a NaN operand that the next ReLU would silently turn into 0.  A running maximum of the
+//  post-ReLU values of an m-tile in the slice word (one v_max3_f32 per slice), compared with 65504 once per m-tile (mask_commit) into a
+//  wave-uniform flag that k_mlp_fwd looks at once per sample tile and eonerf_range_status reports.)
 EO_DEV Sl<PH3> relu_slice(PH3, const f32x16& acc, int s, uint32_t& bits) {
-    const float a0 = acc[2 * s], a1 = acc[2 * s + 1];
-    const uint32_t t = f16_range_probe(a0, a1);
-    bits = s == 0 ? t : (bits | t);
-    return split_pair(a0 > 0.f ? a0 : 0.f, a1 > 0.f ? a1 : 0.f);
+    const float a0 = acc[2 * s] > 0.f ? acc[2 * s] : 0.f, a1 = acc[2 * s + 1] > 0.f ? acc[2 * s + 1] : 0.f;
+    const float m = s == 0 ? fmaxf(a0, a1) : fmaxf(__builtin_bit_cast(float, bits), fmaxf(a0, a1));
+    bits = __builtin_bit_cast(uint32_t, m);
+    return split_pair(a0, a1);
 }
 EO_DEV Sl<PH3> relu_only_slice(PH3, const f32x16& acc, int s) { uint32_t b; return relu_slice(PH3(), acc, s, b); }
-EO_DEV void mask_commit(PH3, int, uint32_t bits, uint32_t& m) { m |= bits; }
+// once per m-tile: the tile's maximum against fp16's largest finite value, into a WAVE-UNIFORM word (scalar registers: the kernel has
+// no vector register to spare for state that lives across a sample tile)
+EO_DEV void mask_commit(PH3, int, uint32_t bits, uint32_t& m) {
+    m |= __builtin_amdgcn_ballot_w64(__builtin_bit_cast(float, bits) > 65504.f) != 0ull ? 1u : 0u;
+}
 EO_DEV Sl<PH3> pack_slice(PH3, const f32x16& acc, int s) { return split_pair(acc[2 * s], acc[2 * s + 1]); }
 EO_DEV void put_slice(PH3, F16Pair* arr, int mt, int s, const Sl<PH3>& v) {      // same place as the bf16 policy, in both halves
     u32x4 th = __builtin_bit_cast(u32x4, arr[2 * mt + (s >> 2)].hi), tl = __builtin_bit_cast(u32x4, arr[2 * mt + (s >> 2)].lo);

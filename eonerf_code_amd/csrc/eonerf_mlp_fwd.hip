@@ -92,8 +92,8 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
         U H[HKG], N[HKG];
         uint32_t mbits[4];
         if constexpr (P::IS_SPLIT) {
-            // split policy: mbits[0] OR-accumulates the range probes of the whole sample tile (f16_range_probe); the raw coordinates are
-            // operands of layer 0 and of the skip layer
+            // split policy: mbits[0] = wave-uniform "an operand of this sample tile left fp16's range" flag (mask_commit(PH3)); the raw
+            // coordinates are operands of layer 0 and of the skip layer
             mbits[0] = __builtin_amdgcn_ballot_w64(!(fabsf(x) <= 65504.f && fabsf(y) <= 65504.f && fabsf(z) <= 65504.f)) != 0ull ? 1u : 0u;
         }
         uint32_t tbits = 0;      // ReLU flags of the tile whose epilogue is in progress

@@ -2,7 +2,7 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-RT=${RT:-r04}
+RT=${RT:-r05}
 O=$R/gpurun_out/prof_$RT
 rm -rf $O; mkdir -p $O
 cd $R

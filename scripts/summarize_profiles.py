@@ -10,7 +10,7 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RT = os.environ.get("RT", "r04")
+RT = os.environ.get("RT", "r05")
 SRC = os.path.join(REPO, "gpurun_out", "prof_" + RT)
 DST = os.path.join(REPO, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else RT + "_a"
@@ -52,6 +52,9 @@ for wl in ("rgb", "full"):
     out = [["kernel", "launches_used", "fetch_bytes_per_launch(2xFETCH_SIZE)", "write_bytes_per_launch", "total_bytes_per_launch"]]
     tot = collections.defaultdict(float)
     step_total = 0.0
+    # optimisation steps of the profiled run = launches of the Adam kernel (the bench's declared conditioning phase adds steps to the
+    # `--steps 4 --warmup 2` of the command line)
+    n_steps = float(max([len(v.get("FETCH_SIZE", [])) for k, v in f.items() if "k_adam" in k] + [1]))
     for name in sorted(set(f) | set(w)):
         fv = [v for _, v in sorted(f.get(name, {}).get("FETCH_SIZE", []))]
         wv = [v for _, v in sorted(w.get(name, {}).get("WRITE_SIZE", []))]
@@ -60,7 +63,7 @@ for wl in ("rgb", "full"):
         wa = sum(wv[len(wv) // 3:]) / max(1, len(wv[len(wv) // 3:])) * 1024 if wv else 0.0
         if fa + wa < 1e6:
             continue
-        per_step = len(fv) / 6.0 if fv else len(wv) / 6.0          # 6 steps per profiled run
+        per_step = (len(fv) if fv else len(wv)) / n_steps          # launches of this kernel per optimisation step
         out.append([name, len(fv) - len(fv) // 3, f"{fa:.0f}", f"{wa:.0f}", f"{fa + wa:.0f}"])
         s = short(name)
         if s:
