@@ -130,7 +130,7 @@ static void check_carve(const CarveCfg& cfg, int n_rays, int flags) {
     uint8_t* base = reinterpret_cast<uint8_t*>((uintptr_t)1 << 40);
     const RenderWs w = carve_render(cfg, base, n_rays, flags);
     CHECK(w.bytes == m.bytes, "measuring pass %zu != carving pass %zu", m.bytes, w.bytes);
-    const size_t p_cap = (size_t)p_cap_of(n_rays);
+    const size_t p_cap = (size_t)p_cap_of(n_rays, cfg.n_samples);
     const bool od = flags & EONERF_F_ONLY_DEPTH;
     const int ab = cfg.bf16 ? 2 : 4;
     std::vector<Span> v;
@@ -178,8 +178,15 @@ int main() {
     for (const CarveCfg& c : cfgs)
         for (int n_rays : {1, 37, 4096, 66050})
             for (int f : flag_sets) check_carve(c, n_rays, f);
-    CHECK(slab_blocks_addressable(true, (size_t)p_cap_of(66050)) && !slab_blocks_addressable(true, (size_t)p_cap_of(66051)), "bf16 size guard");
-    CHECK(slab_blocks_addressable(false, (size_t)p_cap_of(33024)) && !slab_blocks_addressable(false, (size_t)p_cap_of(33025)), "fp32 size guard");
+    // the other step sizes (eonerf_set_n_samples): 64 and 256 samples per ray
+    for (int ns : {64, 256}) {
+        CarveCfg c = cfgs[1];
+        c.n_samples = ns;
+        for (int n_rays : {1, 37, 4096, 16384})
+            for (int f : flag_sets) check_carve(c, n_rays, f);
+    }
+    CHECK(slab_blocks_addressable(true, (size_t)p_cap_of(66050, 128)) && !slab_blocks_addressable(true, (size_t)p_cap_of(66051, 128)), "bf16 size guard");
+    CHECK(slab_blocks_addressable(false, (size_t)p_cap_of(33024, 128)) && !slab_blocks_addressable(false, (size_t)p_cap_of(33025, 128)), "fp32 size guard");
     if (g_fail) { fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
     printf("host checks ok\n");
     return 0;
