@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--lr", type=float, default=5e-4)
     ap.add_argument("--max_train_steps", type=int, default=1000)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--n_samples", type=int, default=128, help="samples per ray = int(2 / render_step_size) (opt.py:54): 64, 128 or 256")
     ap.add_argument("--logs_dir", default="logs")
     ap.add_argument("--exp_name", default="eonerf_hip")
     ap.add_argument("--synthetic_rays", type=int, default=1 << 20)
@@ -59,7 +60,7 @@ def main():
         rays, ts, rgbs = synthetic_batch(args.synthetic_rays, args.n_images)
     table = RayTable(rays, ts, rgbs, dev, seed=42, rank=rank, world=world)
     field = EONerfMLP(args.n_images, radiometric_normalization=True, precision=args.precision).to(dev)
-    trainer = FusedTrainer(field, lr=args.lr, max_rays=args.batch_size, keep_message=False)
+    trainer = FusedTrainer(field, lr=args.lr, max_rays=args.batch_size, keep_message=False, n_samples=args.n_samples)
     trainer.set_noise_seed(42 + 1000003 * rank)                              # per-rank jitter stream
     steps_per_epoch = max(1, table.steps_per_epoch(args.batch_size))
     step, tic = 0, time.time()
