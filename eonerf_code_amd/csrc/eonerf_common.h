@@ -538,6 +538,9 @@ constexpr int SEG_B = 64;
 // than the caches hold; with the default policy the write-back traffic held up the chain kernels (measured: forward chain
 // -12 %, backward chain -21 %, and the weight-gradient GEMM that follows -5 %)
 constexpr int SLAB_STORE_POLICY = 2;
+#ifndef EO_ELEM_POLICY
+#define EO_ELEM_POLICY 0      // cache policy of the element-wise slab stores (encoding rows, the heads' scalar gradient rows); nt (2) measured +0.3 % on the step: 2-byte streaming stores
+#endif
 struct SlabBlk { int s, r; };
 template <class P> struct Slab {
     static constexpr int TSAMP = SEG_B / P::ACT_BYTES;     // samples per segment
@@ -687,7 +690,7 @@ template <class Map> struct SlabWriter<PBf16, Map> : SlabWriterBase {
     EO_DEV void drain() { flush_store<0>(); flush(); flush(); }
     EO_DEV void elem(int row, float v) const {
         const SlabBlk b = Map::block(row);
-        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), block_rs(b), voff1, block_off(b, row), 0);
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), block_rs(b), voff1, block_off(b, row), EO_ELEM_POLICY);
     }
 };
 

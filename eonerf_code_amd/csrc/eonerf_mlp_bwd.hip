@@ -11,6 +11,12 @@
 #ifdef EO_STAMP
 __device__ unsigned long long eo_stamps_bwd[8];
 #endif
+#ifndef EO_MASK_NT
+#define EO_MASK_NT 1
+#endif
+#ifndef EO_DY7_NT
+#define EO_DY7_NT 1
+#endif
 namespace {
 
 // k-group whose first (up to 4) features carry `v` on the h==0 lanes (rows 0..3 of a 32-row tile), zero elsewhere
@@ -69,7 +75,11 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
         // the heads' mask words are fetched at the top of the tile, with the per-sample scalars: several of the head layers have ONE
         // k-group, so a mask loaded in front of its layer is needed a few dozen cycles later -- a whole memory latency exposed per layer
         // in a kernel that is HBM-bound since the bottleneck fold (round 4)
+#if EO_MASK_NT
+        auto fetch2 = [&](int slot) { return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(a.masks + ((size_t)slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4)); };
+#else
         auto fetch2 = [&](int slot) { return *reinterpret_cast<const u32x2*>(a.masks + ((size_t)slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4); };
+#endif
         auto use2 = [&](const u32x2& v) { mb[0] = v[0]; mb[1] = v[1]; };
         // dX tile -> (optional ReLU mask) -> units of the next backward layer + feature-major save for the wgrad GEMM
         // (slice s of the epilogue of m-tile mt, see chunk_compute)
@@ -154,7 +164,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
                 // this wave's 32 samples = step wt of the pipeline: 16 units of 1 KiB
                 uint8_t* dst = a.dy7_units + (size_t)wt * 16 * 1024 + lane * 16;
 #pragma unroll
-                for (int kg = 0; kg < HKG; ++kg) *reinterpret_cast<U*>(dst + kg * 1024) = D[kg];
+                for (int kg = 0; kg < HKG; ++kg) {
+#if EO_DY7_NT
+                    __builtin_nontemporal_store(D[kg], reinterpret_cast<U*>(dst + kg * 1024));      // written once, read once by the next launch
+#else
+                    *reinterpret_cast<U*>(dst + kg * 1024) = D[kg];
+#endif
+                }
                 sw.drain();
                 continue;
             }

@@ -12,6 +12,9 @@
 #ifdef EO_STAMP
 __device__ unsigned long long eo_stamps_fwd[8];
 #endif
+#ifndef EO_MASK_NT
+#define EO_MASK_NT 1
+#endif
 namespace {
 
 template <class P> struct EncUnits { typename P::U u[ENC_SLOTS / P::KF]; };
@@ -121,8 +124,13 @@ __global__ __launch_bounds__(P::NT) void k_mlp_fwd(MlpFwdArgs a) {
             if constexpr (TRAIN) {
                 if (mask_slot < a.mask_from) return;      // wave-uniform
                 uint32_t* mp = a.masks + ((size_t)mask_slot * a.p_pad * 2 + (size_t)p * 2 + h) * 4;
+#if EO_MASK_NT      // written once, read once by the backward chain long after the caches have turned over: streaming, like the slab stores
+                if (nwords == 4) __builtin_nontemporal_store(u32x4{mbits[0], mbits[1], mbits[2], mbits[3]}, reinterpret_cast<u32x4*>(mp));
+                else __builtin_nontemporal_store(u32x2{mbits[0], mbits[1]}, reinterpret_cast<u32x2*>(mp));
+#else
                 if (nwords == 4) *reinterpret_cast<u32x4*>(mp) = u32x4{mbits[0], mbits[1], mbits[2], mbits[3]};
                 else *reinterpret_cast<u32x2*>(mp) = u32x2{mbits[0], mbits[1]};
+#endif
             }
         };
         auto plain_layer = [&](U* src, U* dst, int l) {
