@@ -21,28 +21,33 @@ __global__ __launch_bounds__(WG_NT) void k_wgrad(const WgradJobTable tab, int p_
     wgrad_work<P, WgradJobTable, false>(tab, queue, partials, smem, 0, nullptr);
 }
 
-// deterministic mode: block = (job, row), thread = column: the job's non-empty slices are summed in slice order
+// deterministic mode: block = row, thread = column; the jobs one after the other in table order, a job's non-empty slices in slice
+// order.  (Round 5: the jobs used to be a second grid dimension, "+=" without atomics -- but the camera pass' and the shadow pass' jobs of
+// one layer (layer 0, the skip columns, the sigma row) add into the SAME elements: two blocks could read-modify-write one address at the same
+// time and lose a contribution, once in a few hundred steps.  One block per row walks every job, so an element has one writer.)
 template <class P>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradJobTable tab, const float* partials) {
-    const WgradJob job = tab.j[blockIdx.y];
     const int row = blockIdx.x, col = threadIdx.x;
-    if (row >= job.m_rows) return;
-    const int n_pts = *job.n_pts;
-    const int steps = (n_pts + P::TILE - 1) / P::TILE * P::TILE / (ROW_B / P::ACT_BYTES);
-    float acc = 0.f, accb = 0.f;
-    for (int w = 0; w < job.slices; ++w) {
-        const int s0 = (int)((long long)w * steps / job.slices), s1 = (int)((long long)(w + 1) * steps / job.slices);
-        if (s0 >= s1) continue;
-        const float* pt = partials + (size_t)(job.item0 + w) * WGRAD_PART_F;
-        if (col < job.n_rows) acc += pt[row * 256 + col];
-        if (col == 0 && job.db) accb += pt[256 * 256 + row];
+    for (int jb = 0; jb < tab.n; ++jb) {
+        const WgradJob job = tab.j[jb];
+        if (row >= job.m_rows) continue;
+        const int n_pts = *job.n_pts;
+        const int steps = (n_pts + P::TILE - 1) / P::TILE * P::TILE / (ROW_B / P::ACT_BYTES);
+        float acc = 0.f, accb = 0.f;
+        for (int w = 0; w < job.slices; ++w) {
+            const int s0 = (int)((long long)w * steps / job.slices), s1 = (int)((long long)(w + 1) * steps / job.slices);
+            if (s0 >= s1) continue;
+            const float* pt = partials + (size_t)(job.item0 + w) * WGRAD_PART_F;
+            if (col < job.n_rows) acc += pt[row * 256 + col];
+            if (col == 0 && job.db) accb += pt[256 * 256 + row];
+        }
+        const bool second = row >= job.split;
+        if (col < job.n_rows) {
+            const int cm = job.col_map ? job.col_map[col] : col;
+            if (cm >= 0 && (second || job.dw)) (second ? job.dw2 + (size_t)(row - job.split) * job.dw2_ld : job.dw + (size_t)row * job.dw_ld)[cm] += acc;
+        }
+        if (col == 0 && job.db) (second ? job.db2 + (row - job.split) : job.db + row)[0] += accb;
     }
-    const bool second = row >= job.split;
-    if (col < job.n_rows) {
-        const int cm = job.col_map ? job.col_map[col] : col;
-        if (cm >= 0 && (second || job.dw)) (second ? job.dw2 + (size_t)(row - job.split) * job.dw2_ld : job.dw + (size_t)row * job.dw_ld)[cm] += acc;      // the only writer of this element in this launch
-    }
-    if (col == 0 && job.db) (second ? job.db2 + (row - job.split) : job.db + row)[0] += accb;
 }
 
 template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_pad, int* queue, hipStream_t st, float* partials) {
@@ -53,7 +58,7 @@ template <class P> hipError_t launch(const WgradJobTable& jobs, int n_wg, int p_
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_wgrad<P>), dim3(n_wg), dim3(WG_NT), SMEM, st, jobs, p_pad, queue, partials);
-    if (partials) hipLaunchKernelGGL((k_wgrad_reduce<P>), dim3(256, jobs.n), dim3(256), 0, st, jobs, partials);
+    if (partials) hipLaunchKernelGGL((k_wgrad_reduce<P>), dim3(256), dim3(256), 0, st, jobs, partials);
     return hipGetLastError();
 }
 

@@ -195,22 +195,45 @@ def test_without_radiometric_normalization_matches_the_oracle():
             assert ((g.cpu() - rg).norm() / rg.norm()).item() < 5e-3, name
 
 
-def test_lean_step_consumes_the_message_and_matches_the_kept_message_path(monkeypatch):
-    monkeypatch.setenv("EONERF_DETERMINISTIC", "1")                   # fixed-order reductions: the two trainers can be compared bit for bit
-    # keep_message=False (what bench.py and the launcher run): eonerf_adam_step_zero_grad leaves the message zeroed, no seal without
-    # peers, no separate zero fill -- same parameters and moments as the path that keeps the message, step after step
+def _lean_pair_run():
+    """Three steps (epochs 0, 3, 3) of a kept-message trainer and a lean one on identical fields and batches, interleaved.
+    Returns (tr1, tr2, f1, report): report lists what differs (empty = bit-identical losses, parameters and second moments)."""
     from eonerf_code_amd.trainer import FusedTrainer
     f1, tr1, _ = _make(seed=71, precision="bf16")
     f2, _, _ = _make(seed=71, precision="bf16")
     tr2 = FusedTrainer(f2, lr=5e-4, max_rays=R, keep_message=False)
     rays, img, pix, noise = _batch(seed=72)
-    for epoch in (0, 3, 3):
+    report = []
+    for k, epoch in enumerate((0, 3, 3)):
         l1 = float(tr1.step(rays, img, pix, epoch, noise=noise))
+        g1 = tr1.d_flat[:tr1.n_params].clone()
         l2 = float(tr2.step(rays, img, pix, epoch, noise=noise))
-        assert l1 == l2
+        if l1 != l2:
+            report.append(("loss", k, l1, l2))
         assert tr2.d_flat.abs().max().item() == 0.0                   # consumed
-        assert tr1.d_flat[:tr1.n_params].abs().max().item() > 0.0     # kept
-    assert torch.equal(tr1.flat.detach(), tr2.flat.detach()) and torch.equal(tr1.exp_avg_sq, tr2.exp_avg_sq)
+        assert g1.abs().max().item() > 0.0                            # kept
+        if not (torch.equal(tr1.flat.detach(), tr2.flat.detach()) and torch.equal(tr1.exp_avg_sq, tr2.exp_avg_sq) and torch.equal(tr1.exp_avg, tr2.exp_avg)):
+            for name, off, r, c in f1._layout:      # which tensors, by how much
+                sl = slice(off, off + r * c)
+                a, b = tr1.flat.detach()[sl], tr2.flat.detach()[sl]
+                m1, m2 = tr1.exp_avg[sl], tr2.exp_avg[sl]
+                if not (torch.equal(a, b) and torch.equal(m1, m2)):
+                    d = (m1 - m2).abs()
+                    report.append((f"step {k}", name, int((a != b).sum()), float((a - b).abs().max()), int((m1 != m2).sum()), float(d.max()),
+                                   float(m1.abs().max()), int(d.argmax()), r * c))
+            break
+    return tr1, tr2, f1, report
+
+
+def test_lean_step_consumes_the_message_and_matches_the_kept_message_path(monkeypatch):
+    monkeypatch.setenv("EONERF_DETERMINISTIC", "1")                   # fixed-order reductions: the two trainers can be compared bit for bit
+    # keep_message=False (what bench.py and the launcher run): eonerf_adam_step_zero_grad leaves the message zeroed, no seal without
+    # peers, no separate zero fill -- same parameters and moments as the path that keeps the message, step after step
+    tr1, tr2, f1, report = _lean_pair_run()
+    if report:      # (round 5: seen twice in ten runs of the whole suite, never alone: say what differs, and whether it repeats)
+        again = [bool(_lean_pair_run()[3]) for _ in range(4)]
+        raise AssertionError(f"kept-message and lean trainers diverged: {report}; four more pairs in this process diverged: {again}")
+    rays, img, pix, noise = _batch(seed=72)
     # a fault: the lean path skips the update through the status word alone and still hands back a clean message
     from eonerf_code_amd import _lib
     from eonerf_code_amd.radiance_fields.eonerf import _ptr, _stream
