@@ -336,6 +336,8 @@ def main():
         blocks = split_blocks(args.steps)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         host_ms = []
+        if world > 1:
+            trainer.tail_events = []                            # the serial tail of every timed step: all-reduce + Adam + re-pack
         barrier()
         t0 = time.perf_counter()
         marks[0].record()
@@ -352,6 +354,10 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = t.item()
+        tail_us = None
+        if trainer.tail_events:
+            tail_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.tail_events)
+        trainer.tail_events = None
         step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         block_ms = [marks[lo].elapsed_time(marks[hi]) / (hi - lo) for lo, hi in blocks]
         rec = {"rays_per_s": world * RAYS * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "final_loss": float(loss),
@@ -361,7 +367,7 @@ def main():
                            "note": "HIP events between the K timed steps (GPU time from the end of one step to the end of the next)"},
                "clock_probe": {"before_mhz": probe_pre["mhz"], "after_mhz": probe_post["mhz"], "before_us": probe_pre["us"], "after_us": probe_post["us"],
                                "note": "fixed MFMA loop outside the bracket (eonerf_clock_probe): shader clock from s_memtime / s_memrealtime"},
-               "conditioning_steps": cond_steps, "conditioning_blocks_ms_per_step": cond_blocks}
+               "conditioning_steps": cond_steps, "conditioning_blocks_ms_per_step": cond_blocks, "step_tail_us": tail_us}
         n_cam = int(trainer.n_samples.item())
         n_sun = int(trainer.out[:RAYS, 15].sum().item()) if wl == "full" else 0     # sc_pts_per_ray column (sat_rendering.py:311)
         rec["camera_samples_per_step"], rec["sun_samples_per_step"] = n_cam, n_sun
@@ -449,6 +455,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist_info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "devices": ids,
                      "allreduce_us": t.item(), "allreduce_bytes": msg.numel() * 4,
+                     # rank 0's median over the timed steps of the headline workload: gradient all-reduce (side stream) + Adam + re-fold /
+                     # re-pack, event to event -- the part of a step that no ray work overlaps
+                     "step_tail_us": recs[workloads[0]].get("step_tail_us"),
                      "rehearsal_one_gpu_gloo": rehearsal}
     if rank == 0:
         head = recs[workloads[0]]

@@ -51,6 +51,7 @@ class FusedTrainer:
         in one kernel) and a single process skips the seal (k_adam reads the status word itself): two launches fewer per step."""
         self.field = field
         self.keep_message = keep_message
+        self.tail_events = None      # a list: reduce_and_update() appends an event pair around the exchange + update (bench.py, N > 1)
         self.fused_loss = os.environ.get("EONERF_FUSED_LOSS", "1") != "0"      # (A/B and test switch: 0 = eonerf_train_loss + eonerf_render_backward)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat = field._ensure_packed()
@@ -167,6 +168,10 @@ class FusedTrainer:
         """Second half of a step: the one exchange (sum all-reduce of the message, side stream) and the fused Adam update, which
         the device skips on every rank when any rank sealed a fault into the message."""
         st = _stream()
+        tail = self.tail_events
+        if tail is not None:      # bench.py at N > 1: the serial tail of a step (exchange + update + re-pack) between two events
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         gscale = self._reduce(st)
         self.step_count += 1
         flag = C.c_void_p(self.d_flat.data_ptr() + 4 * self.n_params) if (self.keep_message or self._exchanges()) else None
@@ -176,6 +181,10 @@ class FusedTrainer:
         self._grad_clean = not self.keep_message
         self.field._packed_version = tuple(p._version for p in self.field.parameters())   # adam_step re-packed the weights of self.ctx
         self.field.weights_changed_natively()      # ... and of no other context: the fp32 export context re-packs at its next render
+        if tail is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            tail.append((e0, e1))
 
     def _reduce(self, st):
         """The gradient all-reduce on a SIDE stream: it starts when the last gradient kernel of the backward has

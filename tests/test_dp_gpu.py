@@ -196,6 +196,8 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["rehearsal_one_gpu_gloo"] is True
     assert sorted(x["rank"] for x in d["devices"]) == [0, 1] and len({x["pid"] for x in d["devices"]}) == 2
     assert d["allreduce_us"] > 0 and d["allreduce_bytes"] > 2_700_000
+    assert d["step_tail_us"] > 0                                       # exchange + update + re-pack, event to event, median of the timed steps
+    assert line["conditioning_steps"] >= 20 and len(line["step_ms"]["all"]) == 2
 
 
 def test_launcher_two_ranks_keeps_replicas_identical(tmp_path):
