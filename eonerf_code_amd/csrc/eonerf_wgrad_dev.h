@@ -11,6 +11,9 @@
 #ifndef EO_WG_ABL
 #define EO_WG_ABL 0
 #endif
+#ifndef EO_WG_DESC
+#define EO_WG_DESC 1
+#endif
 
 #define EO_WG_MMA(a, b, c) ((EO_WG_ABL & 2) ? (c) : P::mma(a, b, c))
 
@@ -124,9 +127,23 @@ EO_DEV void wgrad_work(const Tab& tab, int* queue, float* partials, uint8_t* sme
     const bool has_aux = tab.aux.job == ji, has_sig = has_aux && tab.aux.a2 != nullptr, has_emb = has_aux && tab.aux.b2 != nullptr;
     const bool dma_sig = has_sig && wid == AUX_SIG_WAVE, dma_emb = has_emb && wid == AUX_EMB_WAVE;
     n_dma += (dma_sig ? 1 : 0) + (dma_emb ? 1 : 0);
-    // K step s = sample tile s of the slabs: one contiguous rows x 64 B region per operand
+    // K step s = sample tile s of the slabs: one contiguous rows x 64 B region per operand.
+    // ONE descriptor per operand for the whole item (EO_WG_DESC=1): the step enters through the scalar offset of the load -- a descriptor
+    // per step is a 64-bit add and four scalar moves per operand and step (the GEMM spends 11 % of its wave cycles issuing scalar
+    // instructions, profiles/r05_b_pmc_sq.csv).  Rows are clamped by the per-lane offsets, so the descriptors need no bounds; step x stride
+    // stays below 2^32 inside the size guard of the training entry points (slab_blocks_addressable).
+#if EO_WG_DESC
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.a)), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.b)), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(has_sig ? tab.aux.a2 : job.a)), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(has_emb ? tab.aux.b2 : job.b)), 0, -1, 0x00020000);
+#endif
     auto issue = [&](int step, int slot, auto aux_c) {
         if constexpr (decltype(aux_c)::value) {      // (compiled into the Riders loops only: the other loops keep their instruction count)
+#if EO_WG_DESC
+        if (dma_sig) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (__attribute__((address_space(3))) void*)(lds_aux + slot * AUX_B), 16, lane * 16, (uint32_t)step * tab.aux.a2_stride, 0, 2);
+        if (dma_emb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b2, (__attribute__((address_space(3))) void*)(lds_aux + slot * AUX_B + 1024), 16, lane * 16, (uint32_t)step * tab.aux.b2_stride, 0, 2);
+#else
         if (dma_sig) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(tab.aux.a2)) + (size_t)step * tab.aux.a2_stride, 0, 1024, 0x00020000);
@@ -137,17 +154,23 @@ EO_DEV void wgrad_work(const Tab& tab, int* queue, float* partials, uint8_t* sme
                 const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(tab.aux.b2)) + (size_t)step * tab.aux.b2_stride, 0, 1024, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_aux + slot * AUX_B + 1024), 16, lane * 16, 0, 0, 2);
         }
+#endif
         }
         if (EO_WG_ABL & 4) return;
         uint8_t* base = smem + slot * SLOT_B + (32 * wid) * ROW_B;
+#if EO_WG_DESC
+        const uint32_t so_a = (uint32_t)step * job.a_stride, so_b = (uint32_t)step * job.b_stride;
+#else
+        const uint32_t so_a = 0, so_b = 0;
         const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.a)) + (size_t)step * job.a_stride, 0, job.m_rows * SEG_B, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(job.b)) + (size_t)step * job.b_stride, 0, job.n_rows * SEG_B, 0x00020000);
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (on_a[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(base + 16 * j * ROW_B), 16, voff_a[j], 0, 0, 2);
-            if (on_b[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(base + OPND_B + 16 * j * ROW_B), 16, voff_b[j], 0, 0, 2);
+            if (on_a[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(base + 16 * j * ROW_B), 16, voff_a[j], so_a, 0, 2);
+            if (on_b[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(base + OPND_B + 16 * j * ROW_B), 16, voff_b[j], so_b, 0, 2);
         }
     };
 
