@@ -287,7 +287,11 @@ def main():
 
     def one_step(i, epoch_idx):
         r, im, px = table.batch(i // spe, i % spe, RAYS)
-        return trainer.step(r, im, px, epoch_idx)
+        nxt = None
+        if trainer._exchanges() and (i + 1) // spe == i // spe:        # N > 1: the next batch's sampler runs under this step's gradient exchange
+            r2, im2, _ = table.batch(i // spe, (i + 1) % spe, RAYS)
+            nxt = (r2, im2, epoch_idx)
+        return trainer.step(r, im, px, epoch_idx, next_batch=nxt)
 
     def barrier():
         if world > 1:
@@ -354,10 +358,12 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = t.item()
-        tail_us = None
+        tail_us, tail_pre_us = None, None
         if trainer.tail_events:
             tail_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.tail_events)
-        trainer.tail_events = None
+            if trainer.presample_events:      # the next step's sampler, enqueued under the exchange: inside the tail's bracket, not serial work
+                tail_pre_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.presample_events)
+        trainer.tail_events, trainer.presample_events = None, []
         step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         block_ms = [marks[lo].elapsed_time(marks[hi]) / (hi - lo) for lo, hi in blocks]
         rec = {"rays_per_s": world * RAYS * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "final_loss": float(loss),
@@ -367,7 +373,8 @@ def main():
                            "note": "HIP events between the K timed steps (GPU time from the end of one step to the end of the next)"},
                "clock_probe": {"before_mhz": probe_pre["mhz"], "after_mhz": probe_post["mhz"], "before_us": probe_pre["us"], "after_us": probe_post["us"],
                                "note": "fixed MFMA loop outside the bracket (eonerf_clock_probe): shader clock from s_memtime / s_memrealtime"},
-               "conditioning_steps": cond_steps, "conditioning_blocks_ms_per_step": cond_blocks, "step_tail_us": tail_us}
+               "conditioning_steps": cond_steps, "conditioning_blocks_ms_per_step": cond_blocks, "step_tail_us": tail_us,
+               "step_tail_presample_us": tail_pre_us}
         n_cam = int(trainer.n_samples.item())
         n_sun = int(trainer.out[:RAYS, 15].sum().item()) if wl == "full" else 0     # sc_pts_per_ray column (sat_rendering.py:311)
         rec["camera_samples_per_step"], rec["sun_samples_per_step"] = n_cam, n_sun
@@ -458,6 +465,10 @@ def main():
                      # rank 0's median over the timed steps of the headline workload: gradient all-reduce (side stream) + Adam + re-fold /
                      # re-pack, event to event -- the part of a step that no ray work overlaps
                      "step_tail_us": recs[workloads[0]].get("step_tail_us"),
+                     # ... of which the NEXT step's camera sampler (count + emit), enqueued on the compute stream behind the start of the
+                     # exchange and in front of the update that waits for it (eonerf_presample; EONERF_PRESAMPLE=0 switches it off)
+                     "step_tail_presample_us": recs[workloads[0]].get("step_tail_presample_us"),
+                     "presample_under_exchange": os.environ.get("EONERF_PRESAMPLE", "1") != "0",
                      "rehearsal_one_gpu_gloo": rehearsal}
     if rank == 0:
         head = recs[workloads[0]]

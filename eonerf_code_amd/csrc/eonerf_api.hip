@@ -58,6 +58,10 @@ struct eonerf_ctx {
                                      // in deterministic mode; EONERF_PIPE_PARTIALS=1 alone: A/B switch against the atomic flush)
     unsigned long long* pipe_stamps = nullptr;   // diagnostics (EONERF_PIPE_STAMPS=1): cycle sums per stage, read by eonerf_debug_pipe_stamps
     uint64_t noise_seed = 0x5eed5eedULL; uint32_t noise_call = 0;   // in-kernel Philox jitter (eonerf_set_noise_seed)
+    // eonerf_presample: the camera sampler of the NEXT training forward already ran (under the gradient exchange of the step before);
+    // the forward whose arguments and carve match consumes the record, any other forward drops it and samples again
+    struct Presample { bool valid = false; const void* ws = nullptr; const float* rays = nullptr; const int64_t* img_idx = nullptr;
+                       const float* zsteps = nullptr; int n_rays = 0, flags = 0, n_samples = 0; bool pipe = false; uint32_t call = 0; } pre;
     bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
     int* dev_status = nullptr;       // STICKY device status word (watchdog bits of the pipelined backward, bit 8: a remote rank's fault);
@@ -273,6 +277,8 @@ struct ProfScope {      // brackets one kernel launch with events when profiling
 
 inline bool slabs_addressable(const eonerf_ctx* ctx, size_t p_cap) { return slab_blocks_addressable(ctx->bf16, p_cap); }
 // rays per call: n_rays x (n_samples - 1) samples must stay below 2^31
+// a call that writes `ws` ends what eonerf_presample left there
+inline void drop_presample(eonerf_ctx* ctx, const void* ws) { if (ctx->pre.valid && ctx->pre.ws == ws) ctx->pre.valid = false; }
 inline bool rays_in_range(const eonerf_ctx* ctx, int n_rays) { return n_rays <= (1 << 24) / (ctx->n_samples > 128 ? ctx->n_samples / 128 : 1); }
 
 CarveCfg carve_cfg(const eonerf_ctx* ctx);
@@ -757,6 +763,7 @@ static int field_common(eonerf_ctx* ctx, const float* flat, const float* xyz, co
     if (!ctx || !xyz || n < 0 || !ws) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (ws_bytes < eonerf_field_workspace_bytes(ctx, n)) return EONERF_E_WORKSPACE;
+    drop_presample(ctx, ws);
     p_cap = round_up(std::max(n, 1), 256);
     Carver c(ws);
     carve_pass(c, b, 1, p_cap, true, false, false, ctx->bf16 ? 2 : 4);
@@ -816,6 +823,7 @@ int eonerf_field_forward_train(eonerf_ctx* ctx, const float* flat, const float* 
     hipStream_t st = (hipStream_t)stream;
     if (!ctx || !flat || !xyz || !sigma || n < 0 || !ws) return EONERF_E_ARG;
     if (!density_only && (!sun || !img || !albedo || !ambient || !ts || !tb)) return EONERF_E_ARG;
+    drop_presample(ctx, ws);
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n == 0) return EONERF_OK;
     if (n > (1 << 30)) return EONERF_E_UNSUPPORTED;
@@ -842,6 +850,7 @@ int eonerf_field_backward(eonerf_ctx* ctx, const float* flat, const float* sun, 
     hipStream_t st = (hipStream_t)stream;
     if (!ctx || !flat || !d_flat || n < 0 || !ws) return EONERF_E_ARG;
     if (ctx->prec == EONERF_F16X3) return EONERF_E_UNSUPPORTED;
+    if (ctx->pre.valid && ctx->pre.ws == ws) return EONERF_E_STATE;
     if (!density_only && g_ambient && !sun) return EONERF_E_ARG;
     if (!ctx->weights_set) return EONERF_E_STATE;
     if (n == 0) return EONERF_OK;
@@ -1011,7 +1020,7 @@ int eonerf_set_n_samples(eonerf_ctx* ctx, int n_samples) {
 
 int eonerf_set_noise_seed(eonerf_ctx* ctx, uint64_t seed) {
     if (!ctx) return EONERF_E_ARG;
-    ctx->noise_seed = seed; ctx->noise_call = 0;
+    ctx->noise_seed = seed; ctx->noise_call = 0; ctx->pre.valid = false;
     return EONERF_OK;
 }
 
@@ -1022,6 +1031,7 @@ int eonerf_sample_rays(eonerf_ctx* ctx, const float* rays, const float* zsteps, 
     if (n_rays == 0) return EONERF_OK;
     if (!ctx || !rays || !zsteps || !ray_indices || !t_starts || !t_ends || n_rays < 0 || !ws) return EONERF_E_ARG;
     RenderWs w = carve_render(ctx, ws, n_rays, EONERF_F_ONLY_DEPTH);
+    drop_presample(ctx, ws);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     SampleArgs sa;
     memset(&sa, 0, sizeof(sa));
@@ -1050,6 +1060,7 @@ int eonerf_rendering(eonerf_ctx* ctx, const float* flat, const float* rays, cons
     if (!rays_in_range(ctx, n_rays) || (long long)n > (long long)n_rays * (ctx->n_samples - 1)) return EONERF_E_UNSUPPORTED;      // at most n_samples - 1 intervals per ray
     const int flags = depth_only ? EONERF_F_ONLY_DEPTH : 0;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    drop_presample(ctx, ws);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     const int p_cap = p_cap_of(n_rays, ctx->n_samples);
     PackedArgs pa;
@@ -1086,6 +1097,7 @@ int eonerf_rendering_train(eonerf_ctx* ctx, const float* flat, const float* rays
     if (ctx->need_repack) { const int rcr = eonerf_set_weights(ctx, flat, stream); if (rcr) return rcr; }      // (after the fault fallback)
     const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    drop_presample(ctx, ws);
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     note_train_forward(ctx, ws);
     const int p_cap = p_cap_of(n_rays, ctx->n_samples);
@@ -1122,12 +1134,51 @@ int eonerf_rendering_backward(eonerf_ctx* ctx, const float* flat, const float* r
     PipeModeGuard mode(ctx, ws);
     const int flags = EONERF_F_TRAIN | (depth_only ? EONERF_F_ONLY_DEPTH : 0);
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ctx->pre.valid && ctx->pre.ws == ws) return EONERF_E_STATE;      // eonerf_presample ran between this backward and its forward
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     const int p_cap = p_cap_of(n_rays, ctx->n_samples);
     RenderingOutBwdArgs rb{w.ray_rec, n_rays, depth_only ? nullptr : g_albedo, g_depth, depth_only ? nullptr : g_beta,
                            depth_only ? nullptr : g_transient_s, depth_only ? nullptr : g_ambient, w.g_ray};
     HIP_TRY(eo_launch_rendering_out_bwd(rb, st));
     return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, true, !depth_only, true, nullptr, depth_only != 0, st);
+}
+
+// Arguments of the camera pass's sampler launch (eonerf_render_forward, eonerf_presample); the Philox call number is the caller's
+static SampleArgs camera_sample_args(const eonerf_ctx* ctx, const RenderWs& w, const float* rays, const int64_t* img_idx, const float* zsteps,
+                                     const float* u_cam, const float* u_retry, int n_rays, int* n_samples_dev) {
+    SampleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.n_samples = ctx->n_samples;
+    sa.rays = rays; sa.img_idx = img_idx; sa.zsteps = zsteps; sa.u = u_cam; sa.u_retry = u_retry;
+    sa.perturb = 1; sa.retry = (!u_cam || u_retry) ? 1 : 0;
+    if (!u_cam) sa.seed = ctx->noise_seed;
+    sa.n_rays = n_rays; sa.sun_pass = 0; sa.patch_last = 1;
+    sa.cnt_first = w.cnt_first; sa.cnt_retry = w.cnt_retry; sa.counts = w.cam.counts; sa.offsets = w.cam.offsets;
+    sa.flags = w.flags; sa.n_pts = w.cam.n_pts; sa.n_pts_copy = n_samples_dev;       // the scan kernel also fills the caller's count
+    sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
+    return sa;
+}
+
+/* The camera pass's sampler of the NEXT eonerf_render_forward(EONERF_F_TRAIN, production noise), launched ahead of it: it reads the rays and
+ * the seed only, so a data-parallel trainer runs it on the compute stream while the gradient all-reduce of the step before is in flight
+ * (the exchange's serial tail).  The workspace must be free (the backward that used it has been enqueued on `stream`). */
+int eonerf_presample(eonerf_ctx* ctx, const float* rays, const int64_t* img_idx, const float* zsteps, int n_rays, int flags,
+                     int* n_samples_dev, void* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx || !rays || !img_idx || !zsteps || n_rays < 0 || !ws) return EONERF_E_ARG;
+    if (!(flags & EONERF_F_TRAIN) || (flags & EONERF_F_ONLY_DEPTH)) return EONERF_E_STATE;
+    ctx->pre.valid = false;
+    if (n_rays == 0) return EONERF_OK;
+    if (!rays_in_range(ctx, n_rays) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays, ctx->n_samples))) return EONERF_E_UNSUPPORTED;
+    RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
+    SampleArgs sa = camera_sample_args(ctx, w, rays, img_idx, zsteps, nullptr, nullptr, n_rays, n_samples_dev);
+    sa.call = ctx->noise_call++;
+    HIP_TRY(eo_launch_sampler(sa, st));
+    eonerf_ctx::Presample& p = ctx->pre;
+    p.valid = true; p.ws = ws; p.rays = rays; p.img_idx = img_idx; p.zsteps = zsteps; p.n_rays = n_rays; p.flags = flags;
+    p.n_samples = ctx->n_samples; p.pipe = ctx->pipe; p.call = sa.call;
+    return EONERF_OK;
 }
 
 int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
@@ -1151,17 +1202,16 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     const int p_cap = p_cap_of(n_rays, ctx->n_samples);
 
     // ---- camera pass: sample -> field -> composite -------------------------------------------------------
-    SampleArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.n_samples = ctx->n_samples;
-    sa.rays = rays; sa.img_idx = img_idx; sa.zsteps = zsteps; sa.u = u_cam; sa.u_retry = u_retry;
-    sa.perturb = 1; sa.retry = (philox || u_retry) ? 1 : 0;
-    if (philox) { sa.seed = ctx->noise_seed; sa.call = ctx->noise_call++; }
-    sa.n_rays = n_rays; sa.sun_pass = 0; sa.patch_last = 1;
-    sa.cnt_first = w.cnt_first; sa.cnt_retry = w.cnt_retry; sa.counts = w.cam.counts; sa.offsets = w.cam.offsets;
-    sa.flags = w.flags; sa.n_pts = w.cam.n_pts; sa.n_pts_copy = n_samples_dev;       // the scan kernel also fills the caller's count
-    sa.px = w.cam.px; sa.py = w.cam.py; sa.pz = w.cam.pz; sa.tmid = w.cam.tmid; sa.delta = w.cam.delta; sa.simg = w.cam.simg;
-    HIP_TRY(eo_launch_sampler(sa, st));
+    const eonerf_ctx::Presample pre = ctx->pre;
+    const bool presampled = pre.valid && philox && pre.ws == ws && pre.rays == rays && pre.img_idx == img_idx && pre.zsteps == zsteps &&
+                            pre.n_rays == n_rays && pre.flags == flags && pre.n_samples == ctx->n_samples && pre.pipe == ctx->pipe;
+    ctx->pre.valid = false;      // consumed, or dropped: this call's kernels write the workspace the record described (or the caller moved on)
+    SampleArgs sa = camera_sample_args(ctx, w, rays, img_idx, zsteps, u_cam, u_retry, n_rays, n_samples_dev);
+    if (presampled) sa.call = pre.call;                       // (the shadow pass draws under the same call number)
+    else {
+        if (philox) sa.call = ctx->noise_call++;
+        HIP_TRY(eo_launch_sampler(sa, st));
+    }
     const bool rgb_loss = train && !shadows && (flags & EONERF_F_RGB_LOSS);
     int rc = run_mlp_fwd(ctx, w.cam, flat, p_cap, !od, train ? (rgb_loss ? 2 : 1) : 0, st, EONERF_PROF_FWD_CHAIN_CAMERA, train);
     if (rc) return rc;
@@ -1216,6 +1266,7 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
     PipeModeGuard mode(ctx, ws);
     const bool shadows = flags & EONERF_F_SHADOWS;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
+    if (ctx->pre.valid && ctx->pre.ws == ws) return EONERF_E_STATE;      // eonerf_presample ran between this backward and its forward
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     const int p_cap = p_cap_of(n_rays, ctx->n_samples);
     const ParamLayout& pl = ctx->pl;

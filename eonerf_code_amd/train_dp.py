@@ -67,7 +67,11 @@ def main():
     for epoch in range(10 ** 7):
         for i in range(steps_per_epoch):
             r, im, px = table.batch(epoch, i, args.batch_size)
-            loss = trainer.step(r, im, px, epoch)
+            nxt = None
+            if trainer._exchanges() and i + 1 < steps_per_epoch:                     # the next batch's sampler runs under this step's gradient exchange
+                r2, im2, _ = table.batch(epoch, i + 1, args.batch_size)
+                nxt = (r2, im2, epoch)
+            loss = trainer.step(r, im, px, epoch, next_batch=nxt)
             if step % args.check_every == 0:                                # the only host sync, every 1000 steps (:173-178)
                 # on EVERY rank: raises (-> non-zero exit of the job) if a device-side hand-off timed out on ANY rank since the last
                 # check; the fault flag of the gradient message has kept all replicas from applying an update since

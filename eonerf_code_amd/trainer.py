@@ -52,6 +52,8 @@ class FusedTrainer:
         self.field = field
         self.keep_message = keep_message
         self.tail_events = None      # a list: reduce_and_update() appends an event pair around the exchange + update (bench.py, N > 1)
+        self.presample_events = []   # ... and one around the next step's sampler when it was enqueued under that exchange
+        self.presample = os.environ.get("EONERF_PRESAMPLE", "1") != "0"          # next step's sampler under the gradient exchange (N > 1)
         self.fused_loss = os.environ.get("EONERF_FUSED_LOSS", "1") != "0"      # (A/B and test switch: 0 = eonerf_train_loss + eonerf_render_backward)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat = field._ensure_packed()
@@ -102,10 +104,12 @@ class FusedTrainer:
         _lib.check(self.L.eonerf_train_loss(self.ctx, _ptr(out), _ptr(pixels), n, kind, _ptr(d_out), _ptr(self.loss), _stream()))
         return self.loss
 
-    def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False):
-        """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar."""
+    def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False, next_batch=None):
+        """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar.
+        next_batch = (rays, img_idx, epoch_idx) of the FOLLOWING step, if the caller knows it (RayTable does): at N > 1 its camera
+        sampler runs under this step's gradient exchange (reduce_and_update)."""
         loss = self.forward_backward(rays, img_idx, pixels, epoch_idx, noise)
-        self.reduce_and_update()
+        self.reduce_and_update(next_batch)
         return loss
 
     def forward_backward(self, rays, img_idx, pixels, epoch_idx, noise=None):
@@ -164,15 +168,18 @@ class FusedTrainer:
     def _exchanges(self):
         return self.dist_on and (self.world > 1 or os.environ.get("EONERF_FORCE_ALLREDUCE") == "1")
 
-    def reduce_and_update(self):
+    def reduce_and_update(self, next_batch=None):
         """Second half of a step: the one exchange (sum all-reduce of the message, side stream) and the fused Adam update, which
-        the device skips on every rank when any rank sealed a fault into the message."""
+        the device skips on every rank when any rank sealed a fault into the message.  With next_batch = (rays, img_idx, epoch_idx)
+        the next step's weight-independent kernels (camera sampler: count + emit) are enqueued on the compute stream BEHIND the start
+        of the exchange and IN FRONT of the update that waits for it (eonerf_presample; EONERF_PRESAMPLE=0 switches it off); the
+        forward of that batch must be the trainer's next render, with the very same tensors."""
         st = _stream()
         tail = self.tail_events
         if tail is not None:      # bench.py at N > 1: the serial tail of a step (exchange + update + re-pack) between two events
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        gscale = self._reduce(st)
+        gscale = self._reduce(st, next_batch)
         self.step_count += 1
         flag = C.c_void_p(self.d_flat.data_ptr() + 4 * self.n_params) if (self.keep_message or self._exchanges()) else None
         adam = self.L.eonerf_adam_step if self.keep_message else self.L.eonerf_adam_step_zero_grad
@@ -186,7 +193,18 @@ class FusedTrainer:
             e1.record()
             tail.append((e0, e1))
 
-    def _reduce(self, st):
+    def _presample(self, rays, img_idx, epoch_idx):
+        n = rays.shape[0]
+        if n > self.max_rays or not (rays.is_cuda and rays.dtype == torch.float32 and rays.dim() == 2 and rays.shape[1] == 11 and rays.is_contiguous()
+                                     and img_idx.is_cuda and img_idx.dtype == torch.int64 and img_idx.is_contiguous() and img_idx.numel() == n):
+            return          # (forward_backward raises for these; here the batch is only a hint)
+        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else _lib.F_RGB_LOSS)
+        self.field.set_n_samples(self.n_samples_per_ray)
+        ws = self._workspace(n, flags)
+        _lib.check(self.L.eonerf_presample(self.ctx, _ptr(rays), _ptr(img_idx), _ptr(self.zsteps), n, flags, _ptr(self.n_samples),
+                                           _ptr(ws), ws.numel(), _stream()))
+
+    def _reduce(self, st, next_batch=None):
         """The gradient all-reduce on a SIDE stream: it starts when the last gradient kernel of the backward has
         finished (event on the compute stream) and the Adam kernel waits for it; host-side launches of the next kernels are not
         held up by the collective.  Single process: no-op."""
@@ -195,7 +213,19 @@ class FusedTrainer:
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.flat.device)
         cur = torch.cuda.current_stream()
-        self._comm_stream.wait_stream(cur)
+        self._comm_stream.wait_stream(cur)                   # (an event on the compute stream: the message is final here)
+        if next_batch is not None and self.presample:
+            # the next step's camera sampler, on the compute stream BEHIND that event: it runs while the collective does.  Enqueued
+            # first because a host-blocking backend (gloo rehearsals) would otherwise hold it back until the exchange is over
+            ev = self.tail_events is not None
+            if ev:
+                p0 = torch.cuda.Event(enable_timing=True)
+                p0.record()
+            self._presample(*next_batch)
+            if ev:          # bench.py: how much of the measured tail is next-step work that ran under the exchange
+                p1 = torch.cuda.Event(enable_timing=True)
+                p1.record()
+                self.presample_events.append((p0, p1))
         with torch.cuda.stream(self._comm_stream):
             gscale = reduce_gradients(self.d_flat)
         cur.wait_stream(self._comm_stream)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EONERF_VERSION 500
+#define EONERF_VERSION 501
 
 enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4, EONERF_E_DEVICE = -5, EONERF_E_RANGE = -6 };
 
@@ -175,6 +175,16 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat_params, const float
                           const float* zsteps, const float* u_cam, const float* u_retry, const float* u_sun,
                           int n_rays, int flags, float* out, int* n_samples_dev,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* The camera pass's sampler of the NEXT eonerf_render_forward, launched ahead of it (EONERF_F_TRAIN, production noise only): it depends on
+ * the rays and the noise seed, not on the weights, so a data-parallel trainer enqueues it on the compute stream while the gradient
+ * all-reduce of the step before runs on its own stream (the reference has no counterpart: single process, train_eonerf.py:98-161; SURVEY.md
+ * 8e).  The forward that follows with the SAME rays / img_idx / zsteps pointers, n_rays, flags and workspace skips its sampler launches and
+ * draws the shadow pass under the same Philox call number: results are bit-identical to a forward that samples itself.  Any other call that
+ * writes the workspace drops the record (the next forward samples again); a backward on that workspace in between returns EONERF_E_STATE.
+ * The workspace must be free: the backward that last used it has been enqueued on `stream`. */
+int eonerf_presample(eonerf_ctx* ctx, const float* rays, const int64_t* img_idx, const float* zsteps, int n_rays, int flags,
+                     int* n_samples_dev, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Autograd of the call above (loss.backward(), train_eonerf.py:160): d_out[R,21] -> gradient of every parameter,
  * ACCUMULATED into d_flat_params (same layout as the flat parameter buffer).  `workspace` must be the one a

@@ -9,6 +9,9 @@ MODE "fault": as "pipe", but rank 1's context was created with EONERF_PIPE_FAULT
 watchdog fires, the fault flag travels in the gradient message, NEITHER rank applies the update, and BOTH ranks raise.
 MODE "nccl1": world size 1 over RCCL (backend "nccl") with EONERF_FORCE_ALLREDUCE=1: the pipelined step with the collective on the
 side stream, in the process group the 8-GPU job uses.
+MODE "pre1" / "pre0": world size 1 over RCCL with the forced all-reduce, deterministic backward, production (Philox) noise: five steps over
+a small ray table with / without the next batch's sampler enqueued under the exchange (FusedTrainer.step(next_batch=...)); the test compares
+the two runs' parameters bit for bit.
 Exit code 0 only on success."""
 import datetime
 import os
@@ -23,8 +26,10 @@ def main():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     import torch
-    backend = "nccl" if mode == "nccl1" else "gloo"
-    if mode == "nccl1":
+    backend = "nccl" if mode in ("nccl1", "pre0", "pre1") else "gloo"
+    if mode in ("pre0", "pre1"):
+        os.environ["EONERF_DETERMINISTIC"] = "1"                      # read when the context is created
+    if backend == "nccl":
         os.environ["EONERF_FORCE_ALLREDUCE"] = "1"
         torch.cuda.set_device(0)
         torch.distributed.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60),
@@ -37,7 +42,7 @@ def main():
     from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP, _ptr, _stream
     from eonerf_code_amd.trainer import FusedTrainer, rank_slice
     n_img, R = 4, 256
-    piped = mode in ("pipe", "fault", "nccl1")
+    piped = mode in ("pipe", "fault", "nccl1", "pre0", "pre1")
     # rank 1 starts from DIFFERENT weights: the trainer's initial broadcast must make the replicas identical
     sd = orc.random_state_dict(n_img, seed=91 + 7 * rank, bias_scale=0.05)
     sd["sigma_layer.output_layer.bias"] += 1.0
@@ -57,6 +62,26 @@ def main():
         L = _lib.lib()
         _lib.check(L.eonerf_render_forward(tr.ctx, None, None, None, None, None, None, None, R, _lib.F_TRAIN, None, None, None, 0, _stream()))
         raise SystemExit("unreachable: the C ABI accepted null pointers")
+    if mode in ("pre0", "pre1"):
+        from eonerf_code_amd.trainer import RayTable
+        tr.set_noise_seed(5)
+        big = orc.synthetic_batch(R * 5, n_img, seed=93)
+        table = RayTable(big[0], big[1], big[2], dev, seed=7)
+        calls = []
+        orig = tr._presample
+        tr._presample = lambda *a: (calls.append(1), orig(*a))[1]
+        losses = []
+        for i in range(5):
+            r, im, px = table.batch(0, i, R)
+            nxt = (table.batch(0, i + 1, R)[0], table.batch(0, i + 1, R)[1], epoch) if (mode == "pre1" and i < 4) else None
+            losses.append(tr.step(r, im, px, epoch, next_batch=nxt))
+        torch.cuda.synchronize()
+        tr.check_device_status()
+        assert len(calls) == (4 if mode == "pre1" else 0), calls
+        torch.save({"flat": tr.flat.detach().cpu(), "loss": [float(l) for l in losses], "n_samples": int(tr.n_samples.item())},
+                   os.path.join(out_dir, f"{mode}.pt"))
+        torch.distributed.destroy_process_group()
+        return
     args = (sl(rays), sl(ts.reshape(-1)), sl(rgbs), epoch)
     noise = (sl(u_cam), None, sl(u_sun))
     p_before = tr.flat.detach().cpu().clone()

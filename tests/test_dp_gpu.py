@@ -143,6 +143,20 @@ def test_rccl_process_group_world_one_pipelined_step(tmp_path):
     assert (tr.d_flat.cpu() - r0["d_flat"]).norm().item() <= 2e-4 * tr.d_flat.norm().item()
 
 
+@pytest.mark.parametrize("epoch", [0, 3])
+def test_next_steps_sampler_under_the_exchange_changes_nothing(tmp_path, epoch):
+    """FusedTrainer.step(next_batch=...) enqueues the next step's camera sampler (eonerf_presample) behind the start of the
+    gradient all-reduce and in front of the Adam kernel that waits for it.  Five steps over RCCL (world 1, forced all-reduce, deterministic
+    backward, in-kernel noise) with and without it: the same losses and the same parameters, bit for bit."""
+    for mode in ("pre0", "pre1"):
+        codes, outs = _run_job(tmp_path, mode, epoch, world=1)
+        assert codes == [0], outs
+    a, b = torch.load(tmp_path / "pre0.pt"), torch.load(tmp_path / "pre1.pt")
+    assert a["loss"] == b["loss"], (a["loss"], b["loss"])
+    assert a["n_samples"] == b["n_samples"]
+    assert torch.equal(a["flat"], b["flat"])
+
+
 def _single_process_reference_world1(epoch):
     from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
     from eonerf_code_amd.trainer import FusedTrainer
@@ -197,6 +211,7 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert sorted(x["rank"] for x in d["devices"]) == [0, 1] and len({x["pid"] for x in d["devices"]}) == 2
     assert d["allreduce_us"] > 0 and d["allreduce_bytes"] > 2_700_000
     assert d["step_tail_us"] > 0                                       # exchange + update + re-pack, event to event, median of the timed steps
+    assert d["presample_under_exchange"] is True and 0 < d["step_tail_presample_us"] < d["step_tail_us"]      # the next step's sampler inside it
     assert line["conditioning_steps"] >= 20 and len(line["step_ms"]["all"]) == 2
 
 

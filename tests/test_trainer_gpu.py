@@ -358,3 +358,51 @@ def test_fused_loss_backward_matches_the_two_calls_it_replaces(precision, epoch)
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     assert torch.isfinite(res[0][1]).all() and res[0][1].norm().item() > 0
     assert (res[0][1] - res[1][1]).norm().item() <= 2e-6 * res[1][1].norm().item()
+
+
+@pytest.mark.parametrize("precision,epoch", [("fp32", 0), ("bf16", 3)])
+def test_presampled_forward_is_the_forward_and_misuse_is_loud(precision, epoch):
+    """eonerf_presample (the next step's camera sampler, launched ahead of its forward): the forward that follows with the same arguments
+    renders bit for bit what a forward that samples itself renders (same Philox call number, also for the shadow pass); a forward on other
+    rays drops the record and samples again; a backward on a workspace that was presampled since its forward returns EONERF_E_STATE."""
+    rays, img, pix, _ = _batch()
+    rays2, img2, pix2, _ = _batch(seed=95)
+    flags_epoch = epoch
+
+    def fresh():
+        f, tr, _ = _make(seed=91, precision=precision)
+        tr.set_noise_seed(11)
+        return f, tr
+
+    def fwd(tr, r, i):
+        from eonerf_code_amd import _lib
+        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if flags_epoch >= 2 else _lib.F_RGB_LOSS)
+        tr._render_forward(r, i, R, flags, (None, None, None))
+        return tr.out[:R].clone(), int(tr.n_samples.item()), flags
+
+    _, a = fresh()                        # samples inside the forward
+    out_a, n_a, _ = fwd(a, rays, img)
+    _, b = fresh()                        # presample, then the forward
+    b._presample(rays, img, epoch)
+    out_b, n_b, _ = fwd(b, rays, img)
+    assert n_a == n_b and n_a > 0 and torch.equal(out_a, out_b)
+    # a forward on OTHER rays: the record is dropped, the forward samples under the next call number -- as two forwards in a row do
+    _, c = fresh()
+    c._presample(rays, img, epoch)
+    out_c, n_c, _ = fwd(c, rays2, img2)
+    _, d = fresh()
+    fwd(d, rays, img)
+    out_d, n_d, _ = fwd(d, rays2, img2)
+    assert n_c == n_d and torch.equal(out_c, out_d)
+    # presample between a forward and ITS backward: the samples the backward needs are gone
+    _, e = fresh()
+    _, _, flags = fwd(e, rays, img)
+    e._presample(rays2, img2, epoch)
+    with pytest.raises(RuntimeError, match="call sequence"):
+        e._render_backward(rays, img, R, flags, pixels=pix, kind=0 if epoch < 2 else 1)
+    # ... and the full step with the hint, no exchange: the hint is ignored (nothing to hide under), the step is the step
+    _, g = fresh()
+    l1 = float(g.step(rays, img, pix, epoch, next_batch=(rays2, img2, epoch)))
+    l2 = float(g.step(rays2, img2, pix2, epoch))
+    g.check_device_status()
+    assert l1 == l1 and l2 == l2
