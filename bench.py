@@ -307,17 +307,23 @@ def main():
         while the chip is still leaving its idle power state ("the stall of BENCH_r04"); `steps`, `warmup` and the K-step mean
         are exactly what the command line says.  EONERF_BENCH_CONDITION=0 switches it off.  Returns (steps run, block means in ms)."""
         if os.environ.get("EONERF_BENCH_CONDITION", "1") == "0":
-            return 0, []
-        blocks, n = [], 0
+            return 0, [], None
+        blocks, n, first = [], 0, None
         while n < 300:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            per = [torch.cuda.Event(enable_timing=True) for _ in range(9)] if n == 0 else None      # first block: every step boundary
             e0.record()
             for i in range(10):
                 one_step(first_step + n + i, epoch_idx)
+                if per is not None and i < 9:
+                    per[i].record()
             e1.record()
             e1.synchronize()
             n += 10
             ms = e0.elapsed_time(e1) / 10
+            if per is not None:      # where a slow first block spent its time: the process's first steps, one by one (this rank)
+                ev = [e0] + per + [e1]
+                first = [round(ev[i].elapsed_time(ev[i + 1]), 3) for i in range(10)]
             if world > 1:      # every rank must run the same number of steps (a step holds a collective): decide on the slowest rank's time
                 t = torch.tensor([ms], device=dev, dtype=torch.float64)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -325,11 +331,11 @@ def main():
             blocks.append(ms)
             if len(blocks) >= 2 and abs(blocks[-1] - blocks[-2]) <= 0.01 * min(blocks[-1], blocks[-2]):
                 break
-        return n, blocks
+        return n, blocks, first
 
     def measure(wl, first_step):
         epoch_idx = 3 if wl == "full" else 0
-        cond_steps, cond_blocks = conditioning(first_step, epoch_idx)
+        cond_steps, cond_blocks, cond_first = conditioning(first_step, epoch_idx)
         first_step += cond_steps
         for i in range(args.warmup):
             one_step(first_step + i, epoch_idx)
@@ -373,7 +379,8 @@ def main():
                            "note": "HIP events between the K timed steps (GPU time from the end of one step to the end of the next)"},
                "clock_probe": {"before_mhz": probe_pre["mhz"], "after_mhz": probe_post["mhz"], "before_us": probe_pre["us"], "after_us": probe_post["us"],
                                "note": "fixed MFMA loop outside the bracket (eonerf_clock_probe): shader clock from s_memtime / s_memrealtime"},
-               "conditioning_steps": cond_steps, "conditioning_blocks_ms_per_step": cond_blocks, "step_tail_us": tail_us,
+               "conditioning_steps": cond_steps, "conditioning_blocks_ms_per_step": cond_blocks, "conditioning_first_block_step_ms": cond_first,
+               "step_tail_us": tail_us,
                "step_tail_presample_us": tail_pre_us}
         n_cam = int(trainer.n_samples.item())
         n_sun = int(trainer.out[:RAYS, 15].sum().item()) if wl == "full" else 0     # sc_pts_per_ray column (sat_rendering.py:311)
@@ -482,6 +489,7 @@ def main():
                     "blocks_ms_per_step": f["blocks_ms_per_step"], "median_block_ms_per_step": f["median_block_ms_per_step"],
                     "step_ms": f["step_ms"], "clock_probe": f["clock_probe"], "conditioning_steps": f["conditioning_steps"],
                     "conditioning_blocks_ms_per_step": f["conditioning_blocks_ms_per_step"],
+                    "conditioning_first_block_step_ms": f["conditioning_first_block_step_ms"],
                     "camera_samples_per_step": f["camera_samples_per_step"], "sun_samples_per_step": f["sun_samples_per_step"],
                     "roofline": f.get("roofline"), "kernels": f.get("kernels"), "step_mfma_frac": f["step_mfma_frac"],
                     "final_loss": f["final_loss"]}
@@ -497,6 +505,7 @@ def main():
             "blocks_ms_per_step": head["blocks_ms_per_step"], "median_block_ms_per_step": head["median_block_ms_per_step"],
             "step_ms": head["step_ms"], "clock_probe": head["clock_probe"], "conditioning_steps": head["conditioning_steps"],
             "conditioning_blocks_ms_per_step": head["conditioning_blocks_ms_per_step"],
+            "conditioning_first_block_step_ms": head["conditioning_first_block_step_ms"],
             "roofline": head.get("roofline"),
             "kernels": head.get("kernels"),
             "step_mfma_frac": head["step_mfma_frac"],

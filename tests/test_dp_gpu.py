@@ -213,6 +213,7 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["step_tail_us"] > 0                                       # exchange + update + re-pack, event to event, median of the timed steps
     assert d["presample_under_exchange"] is True and 0 < d["step_tail_presample_us"] < d["step_tail_us"]      # the next step's sampler inside it
     assert line["conditioning_steps"] >= 20 and len(line["step_ms"]["all"]) == 2
+    assert len(line["conditioning_first_block_step_ms"]) == 10 and min(line["conditioning_first_block_step_ms"]) > 0
 
 
 def test_launcher_two_ranks_keeps_replicas_identical(tmp_path):
