@@ -337,8 +337,19 @@ def main():
         epoch_idx = 3 if wl == "full" else 0
         cond_steps, cond_blocks, cond_first = conditioning(first_step, epoch_idx)
         first_step += cond_steps
+        if world > 1:
+            # the serial tail of a step (all-reduce + Adam + re-pack, event to event) is sampled over the W WARM-UP steps, behind the
+            # conditioning phase: the timed steps carry no events but their one boundary mark (an event pair costs microseconds of queue time)
+            trainer.tail_events = []
         for i in range(args.warmup):
             one_step(first_step + i, epoch_idx)
+        tail_us, tail_pre_us = None, None
+        if trainer.tail_events:
+            torch.cuda.synchronize()
+            tail_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.tail_events)
+            if trainer.presample_events:      # the next step's sampler, enqueued under the exchange: inside the tail's bracket, not serial work
+                tail_pre_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.presample_events)
+        trainer.tail_events, trainer.presample_events = None, []
         trainer.check_device_status()                           # a hand-off fault of the warm-up would have switched paths: report it here
         probe_pre = trainer.clock_probe()                       # fixed MFMA loop: the clock the chip holds going into the bracket
         # EXACTLY K timed steps between two barrier + synchronize brackets; one HIP event per step boundary (recorded on the stream, no host
@@ -346,8 +357,6 @@ def main():
         blocks = split_blocks(args.steps)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         host_ms = []
-        if world > 1:
-            trainer.tail_events = []                            # the serial tail of every timed step: all-reduce + Adam + re-pack
         barrier()
         t0 = time.perf_counter()
         marks[0].record()
@@ -364,12 +373,6 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = t.item()
-        tail_us, tail_pre_us = None, None
-        if trainer.tail_events:
-            tail_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.tail_events)
-            if trainer.presample_events:      # the next step's sampler, enqueued under the exchange: inside the tail's bracket, not serial work
-                tail_pre_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.presample_events)
-        trainer.tail_events, trainer.presample_events = None, []
         step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         block_ms = [marks[lo].elapsed_time(marks[hi]) / (hi - lo) for lo, hi in blocks]
         rec = {"rays_per_s": world * RAYS * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "final_loss": float(loss),
@@ -469,7 +472,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist_info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "devices": ids,
                      "allreduce_us": t.item(), "allreduce_bytes": msg.numel() * 4,
-                     # rank 0's median over the timed steps of the headline workload: gradient all-reduce (side stream) + Adam + re-fold /
+                     # rank 0's median over the W warm-up steps (behind the conditioning phase) of the headline workload: gradient all-reduce (side stream) + Adam + re-fold /
                      # re-pack, event to event -- the part of a step that no ray work overlaps
                      "step_tail_us": recs[workloads[0]].get("step_tail_us"),
                      # ... of which the NEXT step's camera sampler (count + emit), enqueued on the compute stream behind the start of the

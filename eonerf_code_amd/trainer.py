@@ -53,6 +53,7 @@ class FusedTrainer:
         self.keep_message = keep_message
         self.tail_events = None      # a list: reduce_and_update() appends an event pair around the exchange + update (bench.py, N > 1)
         self.presample_events = []   # ... and one around the next step's sampler when it was enqueued under that exchange
+        self.exchange_async = os.environ.get("EONERF_EXCHANGE", "side") == "async"      # A/B: all_reduce(async_op=True) instead of a side stream
         self.presample = os.environ.get("EONERF_PRESAMPLE", "1") != "0"          # next step's sampler under the gradient exchange (N > 1)
         self.fused_loss = os.environ.get("EONERF_FUSED_LOSS", "1") != "0"      # (A/B and test switch: 0 = eonerf_train_loss + eonerf_render_backward)
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -210,26 +211,38 @@ class FusedTrainer:
         held up by the collective.  Single process: no-op."""
         if not self.dist_on or (self.world == 1 and os.environ.get("EONERF_FORCE_ALLREDUCE") != "1"):
             return 1.0
+        hint = next_batch is not None and self.presample
+        if self.exchange_async:
+            # the process group's own collective stream IS the side stream: async_op makes it wait for the compute stream as of NOW (the
+            # message is final), wait() makes the compute stream wait for the collective -- no stream of ours, two cross-stream hops fewer
+            work = torch.distributed.all_reduce(self.d_flat, op=torch.distributed.ReduceOp.SUM, async_op=True)
+            if hint:
+                self._presample_timed(next_batch)         # compute stream, behind the point the collective waits for: runs beside it
+            work.wait()
+            return 1.0 / self.world
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.flat.device)
         cur = torch.cuda.current_stream()
         self._comm_stream.wait_stream(cur)                   # (an event on the compute stream: the message is final here)
-        if next_batch is not None and self.presample:
+        if hint:
             # the next step's camera sampler, on the compute stream BEHIND that event: it runs while the collective does.  Enqueued
             # first because a host-blocking backend (gloo rehearsals) would otherwise hold it back until the exchange is over
-            ev = self.tail_events is not None
-            if ev:
-                p0 = torch.cuda.Event(enable_timing=True)
-                p0.record()
-            self._presample(*next_batch)
-            if ev:          # bench.py: how much of the measured tail is next-step work that ran under the exchange
-                p1 = torch.cuda.Event(enable_timing=True)
-                p1.record()
-                self.presample_events.append((p0, p1))
+            self._presample_timed(next_batch)
         with torch.cuda.stream(self._comm_stream):
             gscale = reduce_gradients(self.d_flat)
         cur.wait_stream(self._comm_stream)
         return gscale
+
+    def _presample_timed(self, next_batch):
+        ev = self.tail_events is not None
+        if ev:
+            p0 = torch.cuda.Event(enable_timing=True)
+            p0.record()
+        self._presample(*next_batch)
+        if ev:          # bench.py: how much of the measured tail is next-step work that ran under the exchange
+            p1 = torch.cuda.Event(enable_timing=True)
+            p1.record()
+            self.presample_events.append((p0, p1))
 
     def check_device_status(self):
         """Synchronises and raises (on THIS rank; call it on every rank) if a device-side hand-off of the pipelined backward timed out

@@ -52,8 +52,10 @@ def block(hint, n, first):
 
 block(False, 150, 0)          # conditioning
 for r in range(rounds):
-    for hint in (False, True):
-        ms, tail = block(hint, 100, 0)
-        print(f"round {r} presample={'on ' if hint else 'off'}  {ms:.4f} ms/step   step tail (exchange + Adam + re-pack) {tail:.1f} us", flush=True)
+    for mode in ("side", "async"):
+        tr.exchange_async = mode == "async"
+        for hint in (False, True):
+            ms, tail = block(hint, 100, 0)
+            print(f"round {r} exchange={mode:5s} presample={'on ' if hint else 'off'}  {ms:.4f} ms/step   step tail (exchange + Adam + re-pack) {tail:.1f} us", flush=True)
 tr.check_device_status()
 torch.distributed.destroy_process_group()

@@ -210,7 +210,7 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["rehearsal_one_gpu_gloo"] is True
     assert sorted(x["rank"] for x in d["devices"]) == [0, 1] and len({x["pid"] for x in d["devices"]}) == 2
     assert d["allreduce_us"] > 0 and d["allreduce_bytes"] > 2_700_000
-    assert d["step_tail_us"] > 0                                       # exchange + update + re-pack, event to event, median of the timed steps
+    assert d["step_tail_us"] > 0                                       # exchange + update + re-pack, event to event, median of the warm-up steps
     assert d["presample_under_exchange"] is True and 0 < d["step_tail_presample_us"] < d["step_tail_us"]      # the next step's sampler inside it
     assert line["conditioning_steps"] >= 20 and len(line["step_ms"]["all"]) == 2
     assert len(line["conditioning_first_block_step_ms"]) == 10 and min(line["conditioning_first_block_step_ms"]) > 0
