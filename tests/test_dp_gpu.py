@@ -144,7 +144,7 @@ def test_rccl_process_group_world_one_pipelined_step(tmp_path):
 
 
 @pytest.mark.parametrize("epoch", [0, 3])
-def test_next_steps_sampler_under_the_exchange_changes_nothing(tmp_path, epoch):
+def test_next_steps_sampler_under_the_exchange_changes_nothing(tmp_path, epoch, monkeypatch):
     """FusedTrainer.step(next_batch=...) enqueues the next step's camera sampler (eonerf_presample) behind the start of the
     gradient all-reduce and in front of the Adam kernel that waits for it.  Five steps over RCCL (world 1, forced all-reduce, deterministic
     backward, in-kernel noise) with and without it: the same losses and the same parameters, bit for bit."""
@@ -155,6 +155,12 @@ def test_next_steps_sampler_under_the_exchange_changes_nothing(tmp_path, epoch):
     assert a["loss"] == b["loss"], (a["loss"], b["loss"])
     assert a["n_samples"] == b["n_samples"]
     assert torch.equal(a["flat"], b["flat"])
+    if epoch == 3:      # the exchange as all_reduce(async_op=True) + wait() on the process group's stream (EONERF_EXCHANGE=async): the same again
+        monkeypatch.setenv("EONERF_EXCHANGE", "async")
+        codes, outs = _run_job(tmp_path, "pre1", epoch, world=1)
+        assert codes == [0], outs
+        c = torch.load(tmp_path / "pre1.pt")
+        assert c["loss"] == a["loss"] and torch.equal(c["flat"], a["flat"])
 
 
 def _single_process_reference_world1(epoch):
