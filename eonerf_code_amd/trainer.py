@@ -105,16 +105,22 @@ class FusedTrainer:
         _lib.check(self.L.eonerf_train_loss(self.ctx, _ptr(out), _ptr(pixels), n, kind, _ptr(d_out), _ptr(self.loss), _stream()))
         return self.loss
 
-    def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False, next_batch=None):
+    def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False, next_batch=None, aux_loss=None):
         """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar.
         next_batch = (rays, img_idx, epoch_idx) of the FOLLOWING step, if the caller knows it (RayTable does): at N > 1 its camera
-        sampler runs under this step's gradient exchange (reduce_and_update)."""
-        loss = self.forward_backward(rays, img_idx, pixels, epoch_idx, noise)
+        sampler runs under this step's gradient exchange (reduce_and_update).
+        aux_loss: see forward_backward."""
+        loss = self.forward_backward(rays, img_idx, pixels, epoch_idx, noise, aux_loss)
         self.reduce_and_update(next_batch)
         return loss
 
-    def forward_backward(self, rays, img_idx, pixels, epoch_idx, noise=None):
-        """First half of a step: render, loss, backward into the gradient message (sealed with this rank's fault flag)."""
+    def forward_backward(self, rays, img_idx, pixels, epoch_idx, noise=None, aux_loss=None):
+        """First half of a step: render, loss, backward into the gradient message (sealed with this rank's fault flag).
+        aux_loss: optional callable `out[n,21] -> scalar` in plain PyTorch for the reference's auxiliary terms (train_eonerf.py:145-155:
+        metrics.depth_loss_L2 on out[:, 3], metrics.shadow_loss_L2 on out[:, 10], already gated by the caller's epoch window as
+        update_loss_with_aux_term does).  Its gradient w.r.t. the packed outputs (torch autograd over O(n_rays) element-wise work) is
+        added to the main loss' gradient before the HIP backward; the returned loss is the sum.  With an auxiliary term the epoch < 2
+        graph pruning (EONERF_F_RGB_LOSS: "the loss depends on rgb / depth / albedo only") is not applied: the term may read any column."""
         n = rays.shape[0]
         if n > self.max_rays:
             raise ValueError(f"batch of {n} rays exceeds the trainer's max_rays={self.max_rays}")
@@ -132,13 +138,23 @@ class FusedTrainer:
                 raise RuntimeError("the field's parameters moved to another device after the trainer was built")
             self.flat = flat
         # epoch < 2: s = 1 and the loss is MSE on rgb, so the transient head is outside the autograd graph (F_RGB_LOSS)
-        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else _lib.F_RGB_LOSS)
+        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else (_lib.F_RGB_LOSS if aux_loss is None else 0))
         if noise is None:       # production: the sampler kernels draw the jitter themselves (Philox)
             u_cam = u_retry = u_sun = None
         else:
             u_cam, u_retry, u_sun = noise
         self.field.set_n_samples(self.n_samples_per_ray)      # (another caller of the module may have rendered at another step size)
         self._render_forward(rays, img_idx, n, flags, (u_cam, u_retry, u_sun))
+        if aux_loss is not None:
+            loss = self.loss_grad(self.out[:n], pixels.contiguous(), epoch_idx, self.d_out)
+            o = self.out[:n].detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                extra = aux_loss(o)
+                (g,) = torch.autograd.grad(extra, o)
+            self.d_out[:n] += g
+            self._render_backward(rays, img_idx, n, flags)
+            self.loss_total = loss + extra.detach()
+            return self.loss_total
         if self.fused_loss:      # loss + backward in one library call: d out[R,21] is never written (eonerf_render_backward_loss)
             self._render_backward(rays, img_idx, n, flags, pixels=pixels.contiguous(), kind=0 if epoch_idx < 2 else 1)
             return self.loss

@@ -406,3 +406,46 @@ def test_presampled_forward_is_the_forward_and_misuse_is_loud(precision, epoch):
     l2 = float(g.step(rays2, img2, pix2, epoch))
     g.check_device_status()
     assert l1 == l1 and l2 == l2
+
+
+@pytest.mark.parametrize("epoch", [0, 3])
+def test_auxiliary_prior_terms_through_the_fused_step_match_the_oracle_autograd(epoch):
+    """train_eonerf.py:145-155: metrics.depth_loss_L2 on the rendered depth (any epoch) and metrics.shadow_loss_L2 on the geometric shadows
+    (from epoch 2 on) are added to the main loss.  FusedTrainer.forward_backward(aux_loss=...) takes them as plain PyTorch on the packed
+    outputs; their gradient joins the main loss' gradient in front of the HIP backward.  fp32 against torch autograd through the oracle's
+    render + the same terms: loss to 1e-5, every parameter tensor's gradient to 5e-3 relative L2 (the smoke gate of the fp32 path)."""
+    rays, img, pix, noise = _batch()
+    g = torch.Generator().manual_seed(5)
+    depth_prior = (0.2 + 1.2 * torch.rand(R, generator=g))
+    depth_prior[::7] = -1.0                                        # rays without a prior (metrics.py:25)
+    conf = torch.randint(0, 8, (R,), generator=g).float()
+    smask = (torch.rand(R, generator=g) > 0.4).float()
+
+    def aux(o, dp, cf, sm):
+        term = orc.depth_loss_L2(dp, o[:, 3], cf, w=100)
+        if epoch >= 2:                                             # update_loss_with_aux_term(..., start_epoch=2)
+            term = term + orc.shadow_loss_L2(sm, o[:, 10])
+        return term
+
+    f, tr, sd = _make(seed=91, precision="fp32")
+    loss = float(tr.forward_backward(rays, img, pix, epoch, noise, aux_loss=lambda o: aux(o, depth_prior.cuda(), conf.cuda(), smask.cuda())))
+    tr.check_device_status()
+    # oracle: the same graph under torch autograd
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    crays, cts = rays.cpu(), img.cpu().reshape(-1, 1)
+    out, _ = orc.render_rays(orc.Field(sdg), orc.define_satrays_from_tensors(crays, cts), noise[0].cpu(), noise[2].cpu(), epoch, 2.0 / 128)
+    ref = orc.train_loss(out, pix.cpu(), epoch) + aux(out, depth_prior, conf, smask)
+    ref.backward()
+    ref = ref.detach()
+    assert abs(loss - float(ref)) < 1e-5 * max(1.0, abs(float(ref))), (loss, float(ref))
+    worst = 0.0
+    for (name, p), gv in zip(f.named_parameters(), f.grad_views(tr.d_flat)):
+        rg = sdg[name].grad
+        if rg is not None and rg.norm() > 0:
+            worst = max(worst, ((gv.cpu() - rg).norm() / rg.norm()).item())
+    print(f"aux terms epoch {epoch}: loss {loss:.6f} (oracle {float(ref):.6f}), worst per-tensor gradient error {worst:.2e}")
+    assert worst < 5e-3
+    # without the auxiliary term the depth prior's pull is absent: the gradients differ (the hook is not a no-op)
+    f2, tr2, _ = _make(seed=91, precision="fp32")
+    tr2.forward_backward(rays, img, pix, epoch, noise)
+    assert (tr2.d_flat - tr.d_flat).norm().item() > 1e-3 * tr.d_flat.norm().item()
