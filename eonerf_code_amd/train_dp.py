@@ -40,8 +40,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # (EONERF_FORCE_ALLREDUCE=1: the process group and the gradient exchange also at world size 1 -- the N > 1 code path on a one-GPU box)
+    if world > 1 or os.environ.get("EONERF_FORCE_ALLREDUCE") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if rehearsal:
             torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -91,7 +93,7 @@ def main():
                 trainer.check_device_status()
                 if args.dump_params:                                        # replica-equality checks of the tests
                     torch.save(field.flat_params().detach().cpu(), f"{args.dump_params}.rank{rank}")
-                if world > 1:
+                if torch.distributed.is_initialized():
                     torch.distributed.destroy_process_group()
                 return
             step += 1
