@@ -107,8 +107,8 @@ class FusedTrainer:
 
     def step(self, rays, img_idx, pixels, epoch_idx, noise=None, profile=False, next_batch=None, aux_loss=None):
         """rays [n,11] fp32, img_idx [n] int64, pixels [n,3] (all on the GPU).  Returns the loss as a device scalar.
-        next_batch = (rays, img_idx, epoch_idx) of the FOLLOWING step, if the caller knows it (RayTable does): at N > 1 its camera
-        sampler runs under this step's gradient exchange (reduce_and_update).
+        next_batch = (rays, img_idx, epoch_idx[, with_aux_loss]) of the FOLLOWING step, if the caller knows it (RayTable does): at N > 1
+        its camera sampler runs under this step's gradient exchange (reduce_and_update).
         aux_loss: see forward_backward."""
         loss = self.forward_backward(rays, img_idx, pixels, epoch_idx, noise, aux_loss)
         self.reduce_and_update(next_batch)
@@ -210,12 +210,12 @@ class FusedTrainer:
             e1.record()
             tail.append((e0, e1))
 
-    def _presample(self, rays, img_idx, epoch_idx):
+    def _presample(self, rays, img_idx, epoch_idx, with_aux_loss=False):
         n = rays.shape[0]
         if n > self.max_rays or not (rays.is_cuda and rays.dtype == torch.float32 and rays.dim() == 2 and rays.shape[1] == 11 and rays.is_contiguous()
                                      and img_idx.is_cuda and img_idx.dtype == torch.int64 and img_idx.is_contiguous() and img_idx.numel() == n):
             return          # (forward_backward raises for these; here the batch is only a hint)
-        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else _lib.F_RGB_LOSS)
+        flags = _lib.F_TRAIN | (_lib.F_SHADOWS if epoch_idx >= 2 else (0 if with_aux_loss else _lib.F_RGB_LOSS))      # as forward_backward
         self.field.set_n_samples(self.n_samples_per_ray)
         ws = self._workspace(n, flags)
         _lib.check(self.L.eonerf_presample(self.ctx, _ptr(rays), _ptr(img_idx), _ptr(self.zsteps), n, flags, _ptr(self.n_samples),
