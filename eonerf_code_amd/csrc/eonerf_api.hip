@@ -61,7 +61,7 @@ struct eonerf_ctx {
     // eonerf_presample: the camera sampler of the NEXT training forward already ran (under the gradient exchange of the step before);
     // the forward whose arguments and carve match consumes the record, any other forward drops it and samples again
     struct Presample { bool valid = false; const void* ws = nullptr; const float* rays = nullptr; const int64_t* img_idx = nullptr;
-                       const float* zsteps = nullptr; int n_rays = 0, flags = 0, n_samples = 0; bool pipe = false; uint32_t call = 0; } pre;
+                       const float* zsteps = nullptr; const int* count_out = nullptr; int n_rays = 0, flags = 0, n_samples = 0; bool pipe = false; uint32_t call = 0; } pre;
     bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
     int* dev_status = nullptr;       // STICKY device status word (watchdog bits of the pipelined backward, bit 8: a remote rank's fault);
@@ -276,9 +276,9 @@ struct ProfScope {      // brackets one kernel launch with events when profiling
 };
 
 inline bool slabs_addressable(const eonerf_ctx* ctx, size_t p_cap) { return slab_blocks_addressable(ctx->bf16, p_cap); }
-// rays per call: n_rays x (n_samples - 1) samples must stay below 2^31
 // a call that writes `ws` ends what eonerf_presample left there
 inline void drop_presample(eonerf_ctx* ctx, const void* ws) { if (ctx->pre.valid && ctx->pre.ws == ws) ctx->pre.valid = false; }
+// rays per call: n_rays x (n_samples - 1) samples must stay below 2^31
 inline bool rays_in_range(const eonerf_ctx* ctx, int n_rays) { return n_rays <= (1 << 24) / (ctx->n_samples > 128 ? ctx->n_samples / 128 : 1); }
 
 CarveCfg carve_cfg(const eonerf_ctx* ctx);
@@ -1176,7 +1176,7 @@ int eonerf_presample(eonerf_ctx* ctx, const float* rays, const int64_t* img_idx,
     sa.call = ctx->noise_call++;
     HIP_TRY(eo_launch_sampler(sa, st));
     eonerf_ctx::Presample& p = ctx->pre;
-    p.valid = true; p.ws = ws; p.rays = rays; p.img_idx = img_idx; p.zsteps = zsteps; p.n_rays = n_rays; p.flags = flags;
+    p.valid = true; p.ws = ws; p.rays = rays; p.img_idx = img_idx; p.zsteps = zsteps; p.count_out = n_samples_dev; p.n_rays = n_rays; p.flags = flags;
     p.n_samples = ctx->n_samples; p.pipe = ctx->pipe; p.call = sa.call;
     return EONERF_OK;
 }
@@ -1204,7 +1204,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     // ---- camera pass: sample -> field -> composite -------------------------------------------------------
     const eonerf_ctx::Presample pre = ctx->pre;
     const bool presampled = pre.valid && philox && pre.ws == ws && pre.rays == rays && pre.img_idx == img_idx && pre.zsteps == zsteps &&
-                            pre.n_rays == n_rays && pre.flags == flags && pre.n_samples == ctx->n_samples && pre.pipe == ctx->pipe;
+                            pre.count_out == n_samples_dev && pre.n_rays == n_rays && pre.flags == flags && pre.n_samples == ctx->n_samples && pre.pipe == ctx->pipe;
     ctx->pre.valid = false;      // consumed, or dropped: this call's kernels write the workspace the record described (or the caller moved on)
     SampleArgs sa = camera_sample_args(ctx, w, rays, img_idx, zsteps, u_cam, u_retry, n_rays, n_samples_dev);
     if (presampled) sa.call = pre.call;                       // (the shadow pass draws under the same call number)

@@ -179,7 +179,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat_params, const float
 /* The camera pass's sampler of the NEXT eonerf_render_forward, launched ahead of it (EONERF_F_TRAIN, production noise only): it depends on
  * the rays and the noise seed, not on the weights, so a data-parallel trainer enqueues it on the compute stream while the gradient
  * all-reduce of the step before runs on its own stream (the reference has no counterpart: single process, train_eonerf.py:98-161; SURVEY.md
- * 8e).  The forward that follows with the SAME rays / img_idx / zsteps pointers, n_rays, flags and workspace skips its sampler launches and
+ * 8e).  The forward that follows with the SAME rays / img_idx / zsteps / n_samples_dev pointers, n_rays, flags and workspace skips its sampler launches and
  * draws the shadow pass under the same Philox call number: results are bit-identical to a forward that samples itself.  Any other call that
  * writes the workspace drops the record (the next forward samples again); a backward on that workspace in between returns EONERF_E_STATE.
  * The workspace must be free: the backward that last used it has been enqueued on `stream`. */
