@@ -303,7 +303,7 @@ def main():
 
     def conditioning(first_step, epoch_idx):
         """DECLARED conditioning phase, in front of the W warm-up steps and outside every timed region: untimed steps in event-timed blocks
-        of 10 until two consecutive blocks agree within 1 % (cap 300 steps).  A fresh process on a fresh box starts its first kernels
+        of 10 until three consecutive blocks agree within 1 % (cap 300 steps).  A fresh process on a fresh box starts its first kernels
         while the chip is still leaving its idle power state ("the stall of BENCH_r04"); `steps`, `warmup` and the K-step mean
         are exactly what the command line says.  EONERF_BENCH_CONDITION=0 switches it off.  Returns (steps run, block means in ms)."""
         if os.environ.get("EONERF_BENCH_CONDITION", "1") == "0":
@@ -329,7 +329,7 @@ def main():
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
                 ms = t.item()
             blocks.append(ms)
-            if len(blocks) >= 2 and abs(blocks[-1] - blocks[-2]) <= 0.01 * min(blocks[-1], blocks[-2]):
+            if len(blocks) >= 3 and max(blocks[-3:]) <= 1.01 * min(blocks[-3:]):
                 break
         return n, blocks, first
 
