@@ -44,7 +44,7 @@ struct eonerf_ctx {
     int stream_blocks = 0;           // EONERF_PIPE_STREAM: workgroups of the pipelined CAMERA launch that run ready weight-gradient GEMM items
     int n_pipes_stream = 0;          // ... and the pipelines that launch keeps: (CUs - stream_blocks) / 7
     float* loss_scratch = nullptr;   // [LOSS_MAX_BLOCKS] per-block partial sums of k_loss + its arrival counter (self-resetting: no memset per step)
-    float* fold = nullptr;           // [FOLD_FLOATS] fp32: the heads' first layers folded with the bottleneck layer (eonerf_pack.h), re-computed
+    float* fold = nullptr;           // [FOLD_FLOATS (+ 256 x 256: W_bott transposed, for the backward's tail kernel)] fp32: the heads' first layers folded with the bottleneck layer (eonerf_pack.h), re-computed
                                      // by k_fold in front of every re-pack
     bool pipe_fallback = true;       // after a REPORTED watchdog fault the context leaves the pipelined path for good (EONERF_PIPE_FALLBACK=0: stay)
     bool need_repack = false;        // ... and the chain + GEMM path's weight streams have to be packed before the next call
@@ -156,7 +156,7 @@ int pack(const eonerf_ctx* ctx, const std::vector<const DevStream*>& streams, co
 // W_AT[o][k] b_b[k] + b_AT[o], with W_AT = [W_A1; W_T1[:, :256]].  fp32 FMAs in a fixed order (four interleaved partial sums over k:
 // deterministic).  Block = 2 output rows, thread = column i: 16.8 M MACs on 128 workgroups in front of every re-pack; the k loop is
 // unrolled so that 64 loads of a W_b column are in flight (a batch of 16 was still a chain of L2 round trips: 14 us).
-struct FoldArgs { const float *w_a1, *b_a1, *w_t1, *b_t1, *w_b, *b_b; float* fold; };
+struct FoldArgs { const float *w_a1, *b_a1, *w_t1, *b_t1, *w_b, *b_b; float* fold; float* wbt; };
 __global__ __launch_bounds__(256) void k_fold(FoldArgs a) {
     __shared__ float wat[2][256];
     const int o0 = blockIdx.x * 2, i = threadIdx.x;
@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256) void k_fold(FoldArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) a.fold[(size_t)(o0 + r) * 256 + i] = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
+    // by-product for the backward's tail kernel (bott_wgrad_body): W_bott transposed, two of its rows per block
+#pragma unroll
+    for (int r = 0; r < 2; ++r) a.wbt[(size_t)i * 256 + o0 + r] = a.w_b[(size_t)(o0 + r) * 256 + i];
     if (i < 2) {
         const int o = o0 + i;
         float b4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -232,7 +235,7 @@ int weight_range(const eonerf_ctx* ctx, const float* flat, hipStream_t st) {
 int fold_heads(const eonerf_ctx* ctx, const float* flat, hipStream_t st) {
     const ParamLayout& pl = ctx->pl;
     FoldArgs a{flat + pl.t[pl.a1_w].offset, flat + pl.t[pl.a1_b].offset, flat + pl.t[pl.t_w[0]].offset, flat + pl.t[pl.t_b[0]].offset,
-               flat + pl.t[pl.bot_w].offset, flat + pl.t[pl.bot_b].offset, ctx->fold};
+               flat + pl.t[pl.bot_w].offset, flat + pl.t[pl.bot_b].offset, ctx->fold, ctx->fold + FOLD_FLOATS};
     hipLaunchKernelGGL(k_fold, dim3(128), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
@@ -558,7 +561,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         BottWgradArgs bw;
         bw.w_a1 = flat + pl.t[pl.a1_w].offset; bw.m_a = m_bott; bw.db_at = m_bott + 2 * 128 * 256;
         bw.w_t1 = transient ? flat + pl.t[pl.t_w[0]].offset : nullptr; bw.m_t = m_bott + 128 * 256;
-        bw.w_bott = flat + pl.t[pl.bot_w].offset; bw.b_bott = flat + pl.t[pl.bot_b].offset;
+        bw.w_bott_t = ctx->fold + FOLD_FLOATS; bw.b_bott = flat + pl.t[pl.bot_b].offset;       // (the transposed copy is as current as the packed streams)
         bw.d_w = dptr(pl.bot_w); bw.d_b = dptr(pl.bot_b);
         bw.d_w_a1 = dptr(pl.a1_w); bw.d_b_a1 = dptr(pl.a1_b);
         bw.d_w_t1 = transient ? dptr(pl.t_w[0]) : nullptr; bw.d_b_t1 = transient ? dptr(pl.t_b[0]) : nullptr;
@@ -640,7 +643,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
         { const char* f = getenv("EONERF_PIPE_STAMPS");
           if (!rc && ctx->pipe && f && atoi(f)) rc = (int)hipMalloc(&ctx->pipe_stamps, (size_t)ctx->n_pipes * PIPE_STAGES * 128 * sizeof(unsigned long long)); }
     }
-    if (!rc) rc = (int)hipMalloc(&ctx->fold, FOLD_FLOATS * sizeof(float));
+    if (!rc) rc = (int)hipMalloc(&ctx->fold, (FOLD_FLOATS + 256 * 256) * sizeof(float));      // + W_bott transposed (k_fold)
     if (!rc) rc = (int)hipMalloc(&ctx->loss_scratch, (LOSS_MAX_BLOCKS + 4) * sizeof(float));
     if (!rc) rc = (int)hipMemset(ctx->loss_scratch, 0, (LOSS_MAX_BLOCKS + 4) * sizeof(float));
     if (!rc) rc = (int)hipMalloc(&ctx->dev_status, 64 * sizeof(int));

@@ -115,7 +115,7 @@ struct BottWgradArgs {
     const float *w_a1, *m_a;             // [128][256] weights, [128][256] dA1^T X8
     const float *w_t1, *m_t;             // transient head's first layer ([128][260] weights) or nullptr, [128][256] dT1^T X8
     const float* db_at;                  // [256] scratch: db_A1 | db_T1 of THIS backward call (not yet in the flat gradient buffer)
-    const float *w_bott, *b_bott;        // [256][256], [256]
+    const float *w_bott_t, *b_bott;      // W_bott TRANSPOSED ([in j][out i], the copy k_fold leaves beside the folded weights at every re-pack), [256]
     float *d_w, *d_b;                    // bottleneck layer: [256][256], [256] inside the flat gradient buffer
     float *d_w_a1, *d_b_a1;              // [128][256], [128]
     float *d_w_t1, *d_b_t1;              // [128][260] (columns 0..255 written), [128]; nullptr without the transient head

@@ -317,50 +317,62 @@ __global__ void k_table_reduce(const float* contrib, const int64_t* idx, int n_r
 constexpr int BOTT_LDS_F = 256 + 256 * 17;
 // body of one (virtual) block of 256 threads: vblk = block index, j = thread; s_w [256], s_t [256][17].  Every barrier is executed by
 // all threads of the REAL block (two virtual blocks of the same branch share one in the merged tail kernel).
+#ifndef EO_TAIL_SKIP      // diagnostic builds only (results WRONG): bit 0 / 1 / 2 drop the bottleneck-row / head-row / embedding roles of the tail kernel
+#define EO_TAIL_SKIP 0
+#endif
 EO_DEV void bott_wgrad_body(const BottWgradArgs& a, int vblk, int j, float* s_w, float (*s_t)[17]) {
+    if ((EO_TAIL_SKIP & 1) && vblk < 256) return;
+    if ((EO_TAIL_SKIP & 2) && vblk >= 256) return;
     if (vblk < 256) {
         const int i = vblk;
         float acc = 0.f, accb = 0.f;
         if (j < 128) s_w[j] = a.w_a1[j * 256 + i];
         else s_w[j] = a.w_t1 ? a.w_t1[(j - 128) * 260 + i] : 0.f;
         __syncthreads();
-        // (unrolled: the 128 loads of a column are independent, 32 of them in flight instead of the few the compiler keeps by itself;
+        // (unrolled: the 128 loads of a column are independent, 64 of them in flight instead of the few the compiler keeps by itself;
         //  four partial sums keep the adds off one dependency chain)
         float p4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 32
+#pragma unroll 64
         for (int k = 0; k < 128; ++k) p4[k & 3] += s_w[k] * a.m_a[k * 256 + j];
         if (a.w_t1) {
-#pragma unroll 32
+#pragma unroll 64
             for (int k = 0; k < 128; ++k) p4[k & 3] += s_w[128 + k] * a.m_t[k * 256 + j];
         }
         acc = (p4[0] + p4[1]) + (p4[2] + p4[3]);
         a.d_w[i * 256 + j] += acc;                      // the only writer of this block of the gradient buffer
-        if (j == 0) {
-            for (int k = 0; k < 128; ++k) accb += s_w[k] * a.db_at[k];
-            if (a.w_t1)
-                for (int k = 0; k < 128; ++k) accb += s_w[128 + k] * a.db_at[128 + k];
-            a.d_b[i] += accb;
-        }
+        // bias: sum_k W_AT[k][i] db_AT[k] -- one term per thread and a fixed-order tree (a single thread walking the 256 terms cost
+        // this role 2 us)
+        accb = (j < 128 || a.w_t1) ? s_w[j] * a.db_at[j] : 0.f;
+        accb = wave_sum(accb);
+        if ((j & 63) == 0) s_t[0][j >> 6] = accb;
+        __syncthreads();
+        if (j == 0) a.d_b[i] += (s_t[0][0] + s_t[0][1]) + (s_t[0][2] + s_t[0][3]);
         return;
     }
-    // first layer of a head, row m:  dW[m][i] += sum_j M[m][j] W_bott[i][j] + db[m] b_bott[i]
+    // first layer of a head, row m:  dW[m][i] += sum_j M[m][j] W_bott[i][j] + db[m] b_bott[i];  thread = i.  W_bott is read through its
+    // TRANSPOSED copy (w_bott_t[j][i]: coalesced over i, no staging, no barriers; until round 5 this role walked 16 LDS-transposed tiles of
+    // W_bott behind 32 barriers and was the longest chain of the tail kernel, 21 us of its 25).  One accumulator, j ascending: the sums of
+    // the tiled version, bit for bit; the loads run 64 ahead of the adds.
     const int mm = vblk - 256, m = mm & 127;
     const bool tr = mm >= 128;
     const float* M = (tr ? a.m_t : a.m_a) + m * 256;
     s_w[j] = M[j];
     const float dbm = a.db_at[mm];
+    const float bb = a.b_bott[j];
+    float* dw = (tr ? a.d_w_t1 + m * 260 : a.d_w_a1 + m * 256) + j;
+    const float old = *dw;
+    __syncthreads();
     float acc = 0.f;
-    for (int j0 = 0; j0 < 256; j0 += 16) {             // W_bott tile [256 rows][16 columns]: 16 threads read one 64-B row segment
-        __syncthreads();
+#pragma unroll 1
+    for (int j0 = 0; j0 < 256; j0 += 64) {
+        float w[64];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_t[(j >> 4) + 16 * r][j & 15] = a.w_bott[((j >> 4) + 16 * r) * 256 + j0 + (j & 15)];
-        __syncthreads();
+        for (int c = 0; c < 64; ++c) w[c] = a.w_bott_t[(j0 + c) * 256 + j];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc += s_w[j0 + c] * s_t[j][c];
+        for (int c = 0; c < 64; ++c) acc += s_w[j0 + c] * w[c];
     }
-    acc += dbm * a.b_bott[j];
-    float* dw = tr ? a.d_w_t1 + m * 260 : a.d_w_a1 + m * 256;
-    dw[j] += acc;                                       // the only writer of this row in this launch
+    acc += dbm * bb;
+    *dw = old + acc;                                    // the only writer of this row in this launch
     if (j == 0) (tr ? a.d_b_t1 : a.d_b_a1)[m] += dbm;
 }
 __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
@@ -371,33 +383,36 @@ __global__ __launch_bounds__(256) void k_bott_wgrad(BottWgradArgs a) {
 
 // ---- transient embedding gradient: per-sample d emb (from the backward chain) summed per ray, added per image ---
 // body of one (virtual) block of 256 threads; s_de: [n_img][4] block-local accumulation (unused when lds_images == 0)
+constexpr int EMB_RPW = 4, EMB_RAYS_PER_VBLOCK = 4 * EMB_RPW;      // rays per wave / per 256-thread (virtual) block of the embedding gradient
 template <int SPL>
 EO_DEV void emb_grad_body_spl(const EmbGradArgs& a, int vblk, int tid, float* s_de) {
-    const int lane = tid & 63, ray = vblk * RAYS_PER_BLOCK * 8 + (tid >> 6);
+    const int lane = tid & 63, ray = vblk * EMB_RAYS_PER_VBLOCK + (tid >> 6);
     const bool lds_acc = a.lds_images > 0 && !a.d_emb_rays;
     if (lds_acc) {
         for (int i = tid; i < a.lds_images * 4; i += 256) s_de[i] = 0.f;
         __syncthreads();
     }
-    // 32 rays per block, 8 per wave.  Two passes without early exits, so that the eight (offset, count) loads and then the sixteen
-    // gradient loads of a wave are in flight together (one dependent chain per ray otherwise)
-    int off8[8], n8[8];
+    // 16 rays per block, 4 per wave (8 until round 5: twice the blocks start on twice the CUs, and the role is a chain of HBM round trips).
+    // Two passes without early exits, so that the (offset, count, image) loads and then the gradient loads of a wave are in flight together
+    // (one dependent chain per ray otherwise)
+    int off8[EMB_RPW], n8[EMB_RPW], img8[EMB_RPW];
 #pragma unroll
-    for (int k8 = 0; k8 < 8; ++k8) {
+    for (int k8 = 0; k8 < EMB_RPW; ++k8) {
         const int rr = ray + 4 * k8, rc = rr < a.n_rays ? rr : a.n_rays - 1;
         off8[k8] = a.offsets[rc];
         n8[k8] = rr < a.n_rays ? a.counts[rc] : 0;
+        img8[k8] = a.d_emb_rays ? 0 : (int)a.img_idx[rc];      // (with the first batch: loaded ray by ray it was eight more round trips)
     }
-    f32x4 v8[8][SPL];
+    f32x4 v8[EMB_RPW][SPL];
 #pragma unroll
-    for (int k8 = 0; k8 < 8; ++k8)
+    for (int k8 = 0; k8 < EMB_RPW; ++k8)
 #pragma unroll
         for (int k = 0; k < SPL; ++k) {
             const int i = lane + 64 * k;
             v8[k8][k] = i < n8[k8] ? *reinterpret_cast<const f32x4*>(a.g_emb + 4 * (size_t)(off8[k8] + i)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-    for (int k8 = 0; k8 < 8; ++k8) {
+    for (int k8 = 0; k8 < EMB_RPW; ++k8) {
         const int rr = ray + 4 * k8;
         if (rr >= a.n_rays) break;
         float acc[4];
@@ -411,8 +426,8 @@ EO_DEV void emb_grad_body_spl(const EmbGradArgs& a, int vblk, int tid, float* s_
         if (lane < 4) {
             const float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
             if (a.d_emb_rays) a.d_emb_rays[(size_t)rr * 4 + lane] = v;
-            else if (lds_acc) atomicAdd(&s_de[a.img_idx[rr] * 4 + lane], v);
-            else atomicAdd(a.d_emb + a.img_idx[rr] * 4 + lane, v);
+            else if (lds_acc) atomicAdd(&s_de[img8[k8] * 4 + lane], v);
+            else atomicAdd(a.d_emb + img8[k8] * 4 + lane, v);
         }
     }
     if (lds_acc) {
@@ -450,6 +465,9 @@ __global__ __launch_bounds__(512) void k_step_tail(StepTailArgs a) {
     }
     blk -= a.n_bott / 2;
     // (an odd last virtual block runs with an idle partner: rays beyond n_rays are skipped inside)
+    // (measured, round 5: these blocks behind the bottleneck products in the SAME workgroups -- one round of 256 instead of 384 workgroups on
+    //  256 CUs -- is slower, 23.9 vs 21.4 us: the embedding role is three dependent HBM round trips, better started on a free CU)
+    if (EO_TAIL_SKIP & 4) return;
     emb_grad_body(a.emb, 2 * blk + half, tid, lds + half * (AMB_LDS_F / 2));
 }
 
@@ -585,7 +603,7 @@ hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb
     if (bott) { a.bott = *bott; a.n_bott = 256 + 128 + (bott->w_t1 ? 128 : 0); }
     if (emb) {
         a.emb = *emb;
-        a.n_emb = (emb->n_rays + 31) / 32;
+        a.n_emb = (emb->n_rays + EMB_RAYS_PER_VBLOCK - 1) / EMB_RAYS_PER_VBLOCK;
         if (a.emb.lds_images * 4 > AMB_LDS_F / 2) a.emb.lds_images = 0;      // table too large for the shared staging area: direct atomics
     }
     if (amb) {
@@ -604,7 +622,7 @@ hipError_t eo_launch_table_reduce(const float* contrib, const int64_t* idx, int 
     return hipGetLastError();
 }
 hipError_t eo_launch_emb_grad(const EmbGradArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_emb_grad, dim3((a.n_rays + 31) / 32), dim3(256), (size_t)a.lds_images * 4 * sizeof(float), st, a);
+    hipLaunchKernelGGL(k_emb_grad, dim3((a.n_rays + EMB_RAYS_PER_VBLOCK - 1) / EMB_RAYS_PER_VBLOCK), dim3(256), (size_t)a.lds_images * 4 * sizeof(float), st, a);
     return hipGetLastError();
 }
 hipError_t eo_launch_loss(const float* out, const float* gt, int n, int kind, float* d_out, float* loss, float* scratch, hipStream_t st) {
