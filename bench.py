@@ -385,7 +385,9 @@ def main():
                "conditioning_steps": cond_steps, "conditioning_blocks_ms_per_step": cond_blocks, "conditioning_first_block_step_ms": cond_first,
                "step_tail_us": tail_us,
                "step_tail_presample_us": tail_pre_us}
-        n_cam = int(trainer.n_samples.item())
+        # (at N > 1 the device counter already holds the NEXT batch's count -- its sampler ran under the last exchange -- so the count of the
+        #  step that was timed is read from that step's own outputs: pts_per_ray, column 14 of sat_rendering.py:311)
+        n_cam = int(trainer.out[:RAYS, 14].sum().item()) if trainer._exchanges() else int(trainer.n_samples.item())
         n_sun = int(trainer.out[:RAYS, 15].sum().item()) if wl == "full" else 0     # sc_pts_per_ray column (sat_rendering.py:311)
         rec["camera_samples_per_step"], rec["sun_samples_per_step"] = n_cam, n_sun
         # ---- untimed pass: the same steps with the library's per-kernel HIP-event scopes (on the stream the kernels run on) ----

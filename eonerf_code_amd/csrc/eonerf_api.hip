@@ -28,6 +28,9 @@ struct DevStream {
 
 constexpr int PIPE_STREAM_DEFAULT = 0;      // (A/B: scripts/stream_ab.sh)
 constexpr int RANGE_WORD = 16;      // ctx->dev_status[RANGE_WORD]: fp16 x 3 range flag (a cache line of its own; eonerf_range_status)
+constexpr int RANGE_STICKY_WORD = 17;   // ... and the WEIGHT criteria of the last re-pack: reported like RANGE_WORD, cleared only by the next eonerf_set_weights
+constexpr int DIGEST_WORD = 32;     // ctx->dev_status[32..35]: two 64-bit ray digests (eonerf_rays.h: ray_word_digest) -- [0] what eonerf_presample's
+                                    // sampler read, [1] what the backward of the forward that consumed those samples finds in the same buffers
 
 struct eonerf_ctx {
     eonerf_config cfg;
@@ -62,6 +65,7 @@ struct eonerf_ctx {
     // the forward whose arguments and carve match consumes the record, any other forward drops it and samples again
     struct Presample { bool valid = false; const void* ws = nullptr; const float* rays = nullptr; const int64_t* img_idx = nullptr;
                        const float* zsteps = nullptr; const int* count_out = nullptr; int n_rays = 0, flags = 0, n_samples = 0; bool pipe = false; uint32_t call = 0; } pre;
+    const void* pre_consumed_ws = nullptr;   // workspace of the training forward that consumed a presample record: its backward checks the ray digest
     bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
     int* dev_status = nullptr;       // STICKY device status word (watchdog bits of the pipelined backward, bit 8: a remote rank's fault);
@@ -129,7 +133,7 @@ __global__ void k_pack(const float* flat, const float* fold, int fold_base, Pack
         else {
             const _Float16 hi = (_Float16)v;
             *reinterpret_cast<_Float16*>(jb.data + pe.dst) = jb.kind == 2 ? hi : (_Float16)(v - (float)hi);
-            if (jb.kind == 2 && !(fabsf(v) <= 65504.f)) atomicOr(range_flag, 1);      // a weight (or folded weight) outside fp16's range, or not finite
+            if (jb.kind == 2 && !(fabsf(v) <= 65504.f)) atomicOr(range_flag + (RANGE_STICKY_WORD - RANGE_WORD), 1);      // a weight (or folded weight) outside fp16's range, or not finite
         }
     }
 }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void k_weight_range(RangeJobs jobs, int* range
     if (threadIdx.x == 0) {
         const float mx = red[0];
         const float hi_lim = jb.check_min ? F16X3_W_MAX : 65504.f;       // (operands that are not weights -- the embedding rows -- only have to fit)
-        if (bad[0] || mx > hi_lim || (jb.check_min && mx > 0.f && mx < F16X3_W_MIN)) atomicOr(range_flag, 1);
+        if (bad[0] || mx > hi_lim || (jb.check_min && mx > 0.f && mx < F16X3_W_MIN)) atomicOr(range_flag + (RANGE_STICKY_WORD - RANGE_WORD), 1);
     }
 }
 int weight_range(const eonerf_ctx* ctx, const float* flat, hipStream_t st) {
@@ -293,11 +297,12 @@ void note_train_forward(eonerf_ctx* ctx, const void* ws) {
 }
 struct PipeModeGuard {      // a backward call runs on the path its forward ran on; the context's own choice is restored on return
     eonerf_ctx* c; bool keep;
-    PipeModeGuard(eonerf_ctx* ctx, const void* ws) : c(ctx), keep(ctx->pipe) {
+    PipeModeGuard(eonerf_ctx* ctx, const void* ws) : c(ctx), keep(ctx->pipe), ws_(ws) {
         auto it = c->ws_pipe.find(ws);
         if (it != c->ws_pipe.end()) c->pipe = it->second;
     }
-    ~PipeModeGuard() { c->pipe = keep; }
+    const void* ws_;
+    ~PipeModeGuard() { c->pipe = keep; c->ws_pipe.erase(ws_); }      // the forward's record is spent (a backward runs once per forward)
 };
 
 AmbientW ambient_w(const eonerf_ctx* ctx, const float* flat) {
@@ -520,7 +525,9 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     //     0.26 at 512 and 0.28 at 352 (heavy items spill into a second round)
     //   many jobs (the full state with the pipelined trunk: 11): ~2.5 items per CU: flat (0.472-0.478 ms) from 650 to 830 items,
     //     0.49-0.50 at 512-600 and at 1,024
-    {   // diagnostics (scripts/wgrad_jobs.sh): EONERF_WGRAD_MASK keeps only the jobs whose bit is set -- gradients are WRONG, timing only
+#ifdef EO_WGRAD_MASK
+    {   // DIAGNOSTIC BUILDS ONLY (scripts/wgrad_jobs.sh builds with -DEO_WGRAD_MASK): EONERF_WGRAD_MASK keeps only the jobs whose bit is set --
+        // gradients are WRONG, timing only.  The shipped library does not read the variable.
         static const char* mk = getenv("EONERF_WGRAD_MASK");
         if (mk) {
             const unsigned long mask = strtoul(mk, nullptr, 0);
@@ -530,6 +537,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
             tab.n = k;
         }
     }
+#endif
     double wmax = 0.0, wj[WGRAD_MAX_JOBS];
     for (int k = 0; k < tab.n; ++k) {
         wj[k] = (double)((tab.j[k].m_rows + 15) / 16 * 16 + (tab.j[k].n_rows + 15) / 16 * 16) * SEG_B;
@@ -582,7 +590,7 @@ const char* eonerf_strerror(int code) {
         case EONERF_OK: return "ok";
         case EONERF_E_ARG: return "eonerf: invalid argument";
         case EONERF_E_WORKSPACE: return "eonerf: workspace too small";
-        case EONERF_E_STATE: return "eonerf: call sequence error (set_weights / train forward missing)";
+        case EONERF_E_STATE: return "eonerf: call sequence error (set_weights / train forward missing, or a ray buffer refilled between eonerf_presample and its forward)";
         case EONERF_E_UNSUPPORTED: return "eonerf: unsupported configuration";
         case EONERF_E_RANGE: return "eonerf: a weight, an activation or a position left fp16's range (|v| > 65504 or not finite) in an fp16 x 3 call since the last check; its outputs are invalid -- render in fp32";
         case EONERF_E_DEVICE: return "eonerf: a device-side hand-off timed out (pipelined backward watchdog) on this or another rank; the gradients of that step are invalid and every optimizer update since has been skipped";
@@ -742,7 +750,10 @@ int eonerf_set_weights(eonerf_ctx* ctx, const float* flat, void* stream) {
     }
     ctx->need_repack = false;
     int rc = fold_heads(ctx, flat, st);      // the folded head weights are a gather source of the streams below
-    if (!rc && ctx->prec == EONERF_F16X3) rc = weight_range(ctx, flat, st);
+    if (!rc && ctx->prec == EONERF_F16X3) {      // the weight criteria describe THESE weights until the next re-pack (eonerf_range_status does not clear them)
+        rc = (int)hipMemsetAsync(ctx->dev_status + RANGE_STICKY_WORD, 0, sizeof(int), st);
+        if (!rc) rc = weight_range(ctx, flat, st);
+    }
     if (!rc) rc = pack(ctx, v, flat, st);
     if (!rc) { ctx->weights_set = true; ctx->dens_dirty = !with_dens; ctx->full_ig_dirty = true; ctx->dens_used = false; }
     return rc;
@@ -931,7 +942,8 @@ int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double
 // gradients (together with the sun pass' remaining jobs, if any) -> embedding table and, with `ambient`, the per-ray ambient head.
 // density_only: the pass was a density-only one (render_depth): its gradient flows through the sigma row alone.
 static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat, const float* rays, const int64_t* img_idx, int n_rays, int p_cap,
-                           float* d_flat, bool transient, bool ambient, bool first_pipe, const PassBuffers* sun, bool density_only, hipStream_t st) {
+                           float* d_flat, bool transient, bool ambient, bool first_pipe, const PassBuffers* sun, bool density_only, hipStream_t st,
+                           const unsigned long long* digest = nullptr) {
     const ParamLayout& pl = ctx->pl;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
@@ -945,6 +957,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
     cb.g_sigma = w.cam.g_sigma; cb.g_albedo = w.cam.g_albedo; cb.g_ts = w.cam.g_ts; cb.g_tb = w.cam.g_tb;
     cb.depth_only = density_only ? 1 : 0;
     if (sun && !density_only) { cb.sun_offsets = sun->offsets; cb.sun_counts = sun->counts; cb.sun_g_pos = sun->g_pos; }      // d depth of the shadow rays' origins
+    if (digest) { cb.chk_a = digest; cb.chk_b = digest + 1; cb.chk_status = ctx->dev_status; }      // presample guard (eonerf_rays.h)
     HIP_TRY(eo_launch_cam_composite_bwd(cb, st));
     MlpBwdArgs mc;
     memset(&mc, 0, sizeof(mc));
@@ -1177,10 +1190,21 @@ int eonerf_presample(eonerf_ctx* ctx, const float* rays, const int64_t* img_idx,
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
     SampleArgs sa = camera_sample_args(ctx, w, rays, img_idx, zsteps, nullptr, nullptr, n_rays, n_samples_dev);
     sa.call = ctx->noise_call++;
+    // content guard: the sampler sums a digest of the rays it reads; the backward of the forward that consumes the record sums it again
+    // from the same buffers and raises the status word if they were refilled in between (pointer identity alone cannot see that)
+    unsigned long long* digest = reinterpret_cast<unsigned long long*>(ctx->dev_status + DIGEST_WORD);
+    HIP_TRY(hipMemsetAsync(digest, 0, 2 * sizeof(unsigned long long), st));
+    sa.digest = digest;
     HIP_TRY(eo_launch_sampler(sa, st));
     eonerf_ctx::Presample& p = ctx->pre;
     p.valid = true; p.ws = ws; p.rays = rays; p.img_idx = img_idx; p.zsteps = zsteps; p.count_out = n_samples_dev; p.n_rays = n_rays; p.flags = flags;
     p.n_samples = ctx->n_samples; p.pipe = ctx->pipe; p.call = sa.call;
+    return EONERF_OK;
+}
+
+int eonerf_presample_cancel(eonerf_ctx* ctx) {
+    if (!ctx) return EONERF_E_ARG;
+    ctx->pre.valid = false;
     return EONERF_OK;
 }
 
@@ -1209,6 +1233,7 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat, const float* rays,
     const bool presampled = pre.valid && philox && pre.ws == ws && pre.rays == rays && pre.img_idx == img_idx && pre.zsteps == zsteps &&
                             pre.count_out == n_samples_dev && pre.n_rays == n_rays && pre.flags == flags && pre.n_samples == ctx->n_samples && pre.pipe == ctx->pipe;
     ctx->pre.valid = false;      // consumed, or dropped: this call's kernels write the workspace the record described (or the caller moved on)
+    ctx->pre_consumed_ws = (presampled && train) ? ws : nullptr;
     SampleArgs sa = camera_sample_args(ctx, w, rays, img_idx, zsteps, u_cam, u_retry, n_rays, n_samples_dev);
     if (presampled) sa.call = pre.call;                       // (the shadow pass draws under the same call number)
     else {
@@ -1281,12 +1306,17 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
     ShadeBwdArgs sb;
     sb.ray_rec = w.ray_rec; sb.d_out = d_out; sb.img_idx = img_idx;
     sb.loss_kind = -1; sb.loss_out = nullptr; sb.loss_gt = nullptr; sb.loss = nullptr; sb.loss_scratch = nullptr;
+    sb.chk_rays = nullptr; sb.chk_sum = nullptr;
     if (ls) { sb.loss_kind = ls->kind; sb.loss_out = ls->out; sb.loss_gt = ls->pixels; sb.loss = ls->loss; sb.loss_scratch = ctx->loss_scratch; }
     sb.radiometric = ctx->cfg.radiometric ? flat + pl.t[pl.rad].offset : nullptr;
     sb.d_radiometric = ctx->cfg.radiometric ? dptr(pl.rad) : nullptr;
     sb.g_ray = w.g_ray; sb.n_rays = n_rays; sb.use_shadow = shadows ? 1 : 0; sb.eval = (flags & EONERF_F_EVAL) ? 1 : 0;
     sb.lds_images = ctx->cfg.n_images <= 2048 ? ctx->cfg.n_images : 0;
     sb.d_rad_rays = sb.d_radiometric ? w.det.rad_rays : nullptr;
+    const bool chk = ctx->pre_consumed_ws == ws;      // this backward's forward ran on presampled rays: digest of the buffers as they are now
+    ctx->pre_consumed_ws = nullptr;
+    unsigned long long* digest = reinterpret_cast<unsigned long long*>(ctx->dev_status + DIGEST_WORD);
+    sb.chk_rays = chk ? rays : nullptr; sb.chk_sum = chk ? digest + 1 : nullptr;
     // pipelined path: this first kernel of the call also zeroes [bottleneck factors | GEMM queue | sync blocks] (pipe_clear's memset)
     const bool prezeroed = ctx->pipe && w.pipe.dy_in;
     sb.zero_base = nullptr; sb.zero_bytes = 0;
@@ -1340,7 +1370,7 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
     }
 
     return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows && !ambient_done, !shadows && !prezeroed,
-                           shadows ? &w.sun : nullptr, false, st);
+                           shadows ? &w.sun : nullptr, false, st, chk ? digest : nullptr);
 }
 
 int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
@@ -1381,6 +1411,10 @@ int eonerf_device_status(eonerf_ctx* ctx, void* stream) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (!err) return EONERF_OK;
     HIP_TRY(hipMemsetAsync(ctx->dev_status, 0, sizeof(int), (hipStream_t)stream));
+    // only the presample guard: a training forward consumed samples eonerf_presample had drawn for OTHER ray contents (the caller refilled
+    // the buffer in place); k_adam skipped that step's update like any flagged step.  A call-sequence error, not a device fault: the
+    // pipelined path stays
+    if ((err & ~0x100) == EO_STATUS_PRESAMPLE_STALE) return EONERF_E_STATE;      // (0x100: k_adam's echo of the sealed flag in the gradient message)
     // A hand-off timed out: the launch did not have the card's CUs to itself (a co-tenant, a partitioned or CU-masked GPU) or a stage
     // stalled.  The fault is reported (the caller decides: the launcher ends the job) and THIS context leaves the pipelined path: a
     // caller that carries on trains through the chain + GEMM backward instead of paying a 0.3-s timeout in every step.  Data-parallel
@@ -1393,11 +1427,12 @@ int eonerf_device_status(eonerf_ctx* ctx, void* stream) {
 int eonerf_range_status(eonerf_ctx* ctx, void* stream) {
     if (!ctx) return EONERF_E_ARG;
     if (ctx->prec != EONERF_F16X3) return EONERF_OK;
-    int flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, ctx->dev_status + RANGE_WORD, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    static_assert(RANGE_STICKY_WORD == RANGE_WORD + 1, "both words in one copy");
+    int flag[2] = {0, 0};      // [0] operands of the calls since the last check, [1] the weights of the last re-pack (stays up until they change)
+    HIP_TRY(hipMemcpyAsync(flag, ctx->dev_status + RANGE_WORD, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (!flag) return EONERF_OK;
-    HIP_TRY(hipMemsetAsync(ctx->dev_status + RANGE_WORD, 0, sizeof(int), (hipStream_t)stream));
+    if (!flag[0] && !flag[1]) return EONERF_OK;
+    if (flag[0]) HIP_TRY(hipMemsetAsync(ctx->dev_status + RANGE_WORD, 0, sizeof(int), (hipStream_t)stream));
     return EONERF_E_RANGE;
 }
 

@@ -463,18 +463,22 @@ EO_DEV Sl<PH3> split_pair(float a0, float a1) {
 // (no ReLU masks in this precision: inference only.  The `bits` / mask words carry the RANGE check instead: |v| > 65504 rounds to an
 //  infinite hi half -- and lo = v - inf = -inf, a NaN operand that the next ReLU would silently turn into 0.  A running maximum of the
 //  post-ReLU values of an m-tile in the slice word (one v_max3_f32 per slice), compared with 65504 once per m-tile (mask_commit) into a
-//  wave-uniform flag that k_mlp_fwd looks at once per sample tile and eonerf_range_status reports.)
+//  wave-uniform flag that k_mlp_fwd looks at once per sample tile and eonerf_range_status reports.
+//  A NaN accumulator must not vanish: `!(x <= 0)` keeps it through the ReLU (a plain x > 0 ? x : 0 turns it into 0), and the running maximum
+//  is taken on the BIT patterns (post-ReLU values are >= 0, where unsigned order = float order; a NaN of either sign, sign bit masked, sorts
+//  above +inf) -- fmaxf would drop it.)
 EO_DEV Sl<PH3> relu_slice(PH3, const f32x16& acc, int s, uint32_t& bits) {
-    const float a0 = acc[2 * s] > 0.f ? acc[2 * s] : 0.f, a1 = acc[2 * s + 1] > 0.f ? acc[2 * s + 1] : 0.f;
-    const float m = s == 0 ? fmaxf(a0, a1) : fmaxf(__builtin_bit_cast(float, bits), fmaxf(a0, a1));
-    bits = __builtin_bit_cast(uint32_t, m);
+    const float a0 = !(acc[2 * s] <= 0.f) ? acc[2 * s] : 0.f, a1 = !(acc[2 * s + 1] <= 0.f) ? acc[2 * s + 1] : 0.f;
+    const uint32_t b0 = __builtin_bit_cast(uint32_t, a0) & 0x7fffffffu, b1 = __builtin_bit_cast(uint32_t, a1) & 0x7fffffffu;
+    const uint32_t m01 = b0 > b1 ? b0 : b1;
+    bits = s == 0 ? m01 : (bits > m01 ? bits : m01);
     return split_pair(a0, a1);
 }
 EO_DEV Sl<PH3> relu_only_slice(PH3, const f32x16& acc, int s) { uint32_t b; return relu_slice(PH3(), acc, s, b); }
 // once per m-tile: the tile's maximum against fp16's largest finite value, into a WAVE-UNIFORM word (scalar registers: the kernel has
 // no vector register to spare for state that lives across a sample tile)
 EO_DEV void mask_commit(PH3, int, uint32_t bits, uint32_t& m) {
-    m |= __builtin_amdgcn_ballot_w64(__builtin_bit_cast(float, bits) > 65504.f) != 0ull ? 1u : 0u;
+    m |= __builtin_amdgcn_ballot_w64(bits > 0x477FE000u) != 0ull ? 1u : 0u;      // bits of 65504.f; inf and NaN patterns lie above
 }
 EO_DEV Sl<PH3> pack_slice(PH3, const f32x16& acc, int s) { return split_pair(acc[2 * s], acc[2 * s + 1]); }
 EO_DEV void put_slice(PH3, F16Pair* arr, int mt, int s, const Sl<PH3>& v) {      // same place as the bf16 policy, in both halves

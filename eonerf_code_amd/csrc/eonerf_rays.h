@@ -8,6 +8,17 @@ constexpr int RR_DEPTH = 0, RR_ALB = 1, RR_TS = 4, RR_TB = 5, RR_WSUM = 6, RR_AM
 
 struct AmbientW { const float *w1, *b1, *w2, *b2; };   // ambient_mlp: [128][27], [128], [3][128], [3]  (fp32)
 
+// Content digest of what the camera sampler consumes of a ray -- words 0..6 of its table row (origin, direction, near) and its image
+// index -- summed over the rays (order independent).  eonerf_presample leaves it beside its samples; the backward of the forward that
+// consumed them recomputes it from the buffers as they are THEN and raises the context's status word on a mismatch (a caller refilled
+// the ray buffer in place between the two calls: the samples belong to the old rays).
+__host__ __device__ inline unsigned long long ray_word_digest(uint32_t word, uint32_t index) {
+    uint32_t h = word ^ (0x9E3779B9u * (index + 1u));
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (unsigned long long)h * 0x9E3779B97F4A7C15ull + (unsigned long long)word;
+}
+constexpr int EO_STATUS_PRESAMPLE_STALE = 1 << 9;      // bit of the context's status word (eonerf_device_status -> EONERF_E_STATE)
+
 struct SampleArgs {
     const float* rays;        // [R][11] fp32: o3 d3 near far sun3  (datasets/satellite.py:23-26)
     const int64_t* img_idx;   // [R] or nullptr
@@ -31,6 +42,7 @@ struct SampleArgs {
     int* simg;
     // optional flattened outputs of satnerf_sampling (sat_rendering.py:82-84): ray_indices, t_starts, t_ends
     int64_t* o_ray; float *o_ts, *o_te;
+    unsigned long long* digest;   // eonerf_presample: += the digest of every ray the emit kernel reads (zeroed by the caller), or nullptr
 };
 
 struct ShadeArgs {
@@ -79,6 +91,8 @@ struct ShadeBwdArgs {
     // scalar goes to *loss (same fixed-order ticket sum, scratch as in eo_launch_loss): one launch for train_eonerf.py:139-143 + the head
     // of :160.  Needs (n_rays + 255) / 256 <= LOSS_MAX_BLOCKS
     int loss_kind; const float *loss_out, *loss_gt; float *loss, *loss_scratch;
+    // the forward of this backward consumed an eonerf_presample record: chk_sum += the digest of the rays as they are now (SampleArgs::digest)
+    const float* chk_rays; unsigned long long* chk_sum;
 };
 
 struct CompositeBwdArgs {
@@ -96,6 +110,8 @@ struct CompositeBwdArgs {
     // (origin = o + depth * d, sat_rendering.py:90) -- formerly a launch of its own (k_sun_depth_grad)
     const int *sun_offsets, *sun_counts;
     const float* sun_g_pos;                    // [3][p_pad] or nullptr
+    // camera compositing backward: the digest the presampling sampler left against the one k_shade_bwd has just summed (nullptr: no check)
+    const unsigned long long *chk_a, *chk_b; int* chk_status;
 };
 
 struct AmbientBwdArgs {

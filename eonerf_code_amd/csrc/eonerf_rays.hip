@@ -226,6 +226,16 @@ __global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
         if (ray < a.n_rays && lane == 0) { a.offsets[ray] = off_scan; a.counts[ray] = cnt[ray]; }
     }
     if (ray >= a.n_rays) return;
+    if (a.digest) {      // (eonerf_presample only) lanes 0..7: the seven table words the camera sampler reads and the image index
+        unsigned long long d = 0ull;
+        if (lane < 8) {
+            const uint32_t w = lane < 7 ? __float_as_uint(a.rays[(size_t)ray * 11 + lane]) : (a.img_idx ? (uint32_t)a.img_idx[ray] : 0u);
+            d = ray_word_digest(w, 8u * (uint32_t)ray + (uint32_t)lane);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (lane == 0) atomicAdd(a.digest, d);
+    }
     const RayGeom g = ray_geom(a, ray);
     const bool retry = SCAN ? retry_scan : (a.retry && (*a.flags & 1));
     float u[SPL];

@@ -23,6 +23,19 @@ __global__ __launch_bounds__(256) void k_shade_bwd(ShadeBwdArgs a) {
         for (int i = threadIdx.x; i < a.lds_images * 6; i += 256) s_dT[i] = 0.f;
         __syncthreads();
     }
+    if (a.chk_sum) {      // digest of the rays as they are now (see ray_word_digest): one atomic per wave
+        unsigned long long d = 0ull;
+        if (ray < a.n_rays) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t w = q < 7 ? __float_as_uint(a.chk_rays[(size_t)ray * 11 + q]) : (uint32_t)a.img_idx[ray];
+                d += ray_word_digest(w, 8u * (uint32_t)ray + (uint32_t)q);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.chk_sum, d);
+    }
     float loss_part = 0.f;
     if (ray < a.n_rays) {
         const float* r = a.ray_rec + (size_t)ray * RAY_REC;
@@ -135,6 +148,8 @@ __global__ __launch_bounds__(256) void k_sun_composite_bwd(CompositeBwdArgs a) {
 template <int SPL>
 __global__ __launch_bounds__(256) void k_cam_composite_bwd(CompositeBwdArgs a) {
     const int lane = threadIdx.x & 63, ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    // presampled forward: the rays the sampler read are not the rays of this backward -> sticky status bit (k_adam skips the update)
+    if (a.chk_a && blockIdx.x == 0 && threadIdx.x == 0 && *a.chk_a != *a.chk_b) atomicOr(a.chk_status, EO_STATUS_PRESAMPLE_STALE);
     if (ray >= a.n_rays) return;
     const int off = a.offsets[ray], n = a.counts[ray];
     const float* g = a.g_ray + (size_t)ray * RAY_REC;

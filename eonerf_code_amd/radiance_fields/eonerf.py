@@ -91,6 +91,7 @@ class _RenderingFn(torch.autograd.Function):
                                             1 if depth_only else 0, _ptr(albedo), _ptr(depth), _ptr(beta), _ptr(tsc), _ptr(ambient),
                                             _ptr(entropy), _ptr(ws), ws.numel(), _stream()))
         ctx.field, ctx.depth_only, ctx.ws, ctx.n_rays = field, depth_only, ws, n_rays
+        ctx.ns = field._n_samples                                  # the workspace is carved for THIS step size (include/eonerf_hip.h)
         ctx.save_for_backward(table, img)
         if depth_only:
             return depth
@@ -104,6 +105,7 @@ class _RenderingFn(torch.autograd.Function):
             raise RuntimeError("EONerfMLP.rendering: backward through the same call twice (the op's workspace is released after the first)")
         table, img = ctx.saved_tensors
         L = _lib.lib()
+        field.set_n_samples(ctx.ns)                                # a render at another step size may have run since the forward
         flat = field.flat_params()
         d_flat = torch.zeros_like(flat)
         gs = [None if t is None else t.contiguous().float() for t in g]

@@ -53,6 +53,7 @@ class FusedTrainer:
         self.keep_message = keep_message
         self.tail_events = None      # a list: reduce_and_update() appends an event pair around the exchange + update (bench.py, N > 1)
         self.presample_events = []   # ... and one around the next step's sampler when it was enqueued under that exchange
+        self._hint = None            # (rays, img_idx, their version counters) of the batch eonerf_presample last ran on
         self.exchange_async = os.environ.get("EONERF_EXCHANGE", "side") == "async"      # A/B: all_reduce(async_op=True) instead of a side stream
         self.presample = os.environ.get("EONERF_PRESAMPLE", "1") != "0"          # next step's sampler under the gradient exchange (N > 1)
         self.fused_loss = os.environ.get("EONERF_FUSED_LOSS", "1") != "0"      # (A/B and test switch: 0 = eonerf_train_loss + eonerf_render_backward)
@@ -144,6 +145,11 @@ class FusedTrainer:
         else:
             u_cam, u_retry, u_sun = noise
         self.field.set_n_samples(self.n_samples_per_ray)      # (another caller of the module may have rendered at another step size)
+        hint, self._hint = self._hint, None
+        if hint is not None and (hint[0] is not rays or hint[1] is not img_idx or hint[2] != rays._version or hint[3] != img_idx._version):
+            # the presampled record is not for THESE tensors as they are now (other batch, or the same buffers refilled in place): drop it,
+            # the forward samples itself.  (What torch cannot see -- a raw-pointer write -- the library's device-side digest catches.)
+            _lib.check(self.L.eonerf_presample_cancel(self.ctx))
         self._render_forward(rays, img_idx, n, flags, (u_cam, u_retry, u_sun))
         if aux_loss is not None:
             loss = self.loss_grad(self.out[:n], pixels.contiguous(), epoch_idx, self.d_out)
@@ -220,6 +226,10 @@ class FusedTrainer:
         ws = self._workspace(n, flags)
         _lib.check(self.L.eonerf_presample(self.ctx, _ptr(rays), _ptr(img_idx), _ptr(self.zsteps), n, flags, _ptr(self.n_samples),
                                            _ptr(ws), ws.numel(), _stream()))
+        # the library matches the record to its forward by POINTER; the contents are ours to vouch for: remember the tensors' version
+        # counters (an in-place refill of a reused staging tensor bumps them) and keep the tensors alive (a freed batch re-allocated at the
+        # same address would pass the pointer test)
+        self._hint = (rays, img_idx, rays._version, img_idx._version)
 
     def _reduce(self, st, next_batch=None):
         """The gradient all-reduce on a SIDE stream: it starts when the last gradient kernel of the backward has

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define EONERF_VERSION 501
+#define EONERF_VERSION 502
 
 enum { EONERF_OK = 0, EONERF_E_ARG = -1, EONERF_E_WORKSPACE = -2, EONERF_E_STATE = -3, EONERF_E_UNSUPPORTED = -4, EONERF_E_DEVICE = -5, EONERF_E_RANGE = -6 };
 
@@ -185,6 +185,14 @@ int eonerf_render_forward(eonerf_ctx* ctx, const float* flat_params, const float
  * The workspace must be free: the backward that last used it has been enqueued on `stream`. */
 int eonerf_presample(eonerf_ctx* ctx, const float* rays, const int64_t* img_idx, const float* zsteps, int n_rays, int flags,
                      int* n_samples_dev, void* workspace, size_t workspace_bytes, void* stream);
+/* The record is matched to its forward by pointer identity, so the CONTENTS of rays / img_idx must not change between the two calls.  Two
+ * guards (version 502): a caller that knows it refilled a buffer calls eonerf_presample_cancel (the next forward samples itself; the
+ * Python trainer does this when a hinted tensor's version counter moved); and the library checks on the device: the presampling sampler
+ * sums a digest of the ray words it reads (origin, direction, near, image index), the backward of the forward that consumed the record
+ * sums it again from the same buffers, and a mismatch raises bit 9 of the context's sticky status word -- eonerf_adam_step skips that
+ * step's update (its samples belonged to other rays) and the next eonerf_device_status returns EONERF_E_STATE (not EONERF_E_DEVICE: the
+ * pipelined path is not left). */
+int eonerf_presample_cancel(eonerf_ctx* ctx);
 
 /* Autograd of the call above (loss.backward(), train_eonerf.py:160): d_out[R,21] -> gradient of every parameter,
  * ACCUMULATED into d_flat_params (same layout as the flat parameter buffer).  `workspace` must be the one a

@@ -36,7 +36,7 @@ def g8_sd(g):
 
 def test_library_loaded_and_versions():
     from eonerf_code_amd import _lib
-    assert _lib.lib().eonerf_version() == 501
+    assert _lib.lib().eonerf_version() == 502
     assert torch.cuda.is_available()
 
 

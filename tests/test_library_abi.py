@@ -18,7 +18,7 @@ def test_header_symbols_exported():
         assert hasattr(L, name), name
     assert declared == set(_lib.SYMBOLS)
     L.eonerf_version.restype = ctypes.c_int
-    assert L.eonerf_version() == 501
+    assert L.eonerf_version() == 502
     L.eonerf_strerror.restype = ctypes.c_char_p
     assert b"workspace" in L.eonerf_strerror(-2)
 

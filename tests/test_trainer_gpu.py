@@ -408,6 +408,54 @@ def test_presampled_forward_is_the_forward_and_misuse_is_loud(precision, epoch):
     assert l1 == l1 and l2 == l2
 
 
+def test_refilled_ray_buffer_cannot_be_consumed_silently():
+    """VERDICT r5 #7 / ADVICE r5: eonerf_presample's record is matched to its forward by pointer identity.  A staging tensor refilled IN
+    PLACE between the two calls (a) through torch: the trainer sees the version counters move, cancels the record and the forward samples the
+    new rays -- bit for bit a forward that was never presampled; (b) behind torch's back (a raw write, `.data.copy_`): the device-side
+    digest (sampler vs backward) differs, the status word is raised, the update of that step is SKIPPED and check_device_status raises the
+    call-sequence error -- the context stays on the pipelined path."""
+    from eonerf_code_amd import _lib
+    rays, img, pix, _ = _batch()
+    rays2, img2, pix2, _ = _batch(seed=95)
+    epoch = 3
+
+    def fresh():
+        f, tr, _ = _make(seed=91, precision="bf16")
+        tr.set_noise_seed(11)
+        return f, tr
+
+    # (a) in-place refill through torch
+    _, a = fresh()
+    stage_r, stage_i = rays.clone(), img.clone()
+    a._presample(stage_r, stage_i, epoch)
+    stage_r.copy_(rays2); stage_i.copy_(img2)
+    a.forward_backward(stage_r, stage_i, pix2, epoch)
+    out_a, n_a = a.out[:R].clone(), int(a.n_samples.item())
+    _, b = fresh()
+    b._presample(rays, img, epoch)            # (spends the same Philox call number)
+    b.forward_backward(rays2, img2, pix2, epoch)
+    assert n_a == int(b.n_samples.item()) and torch.equal(out_a, b.out[:R])
+    a.reduce_and_update(); a.check_device_status()
+
+    # (b) refill the torch layer cannot see
+    f, c = fresh()
+    stage_r, stage_i = rays.clone(), img.clone()
+    c._presample(stage_r, stage_i, epoch)
+    stage_r.data.copy_(rays2)                 # `.data` has a version counter of its own: stage_r._version does not move
+    before = f.flat_params().clone()
+    c.step(stage_r, stage_i, pix2, epoch)
+    with pytest.raises(RuntimeError, match="refilled"):
+        c.check_device_status()
+    assert torch.equal(before, f.flat_params())                      # the flagged step was not applied
+    assert c.L.eonerf_device_status(c.ctx, None) == 0                # read and cleared; no fall-back off the pipelined path:
+    c.step(rays, img, pix, epoch); c.check_device_status()           # the next step is an ordinary one
+    assert not torch.equal(before, f.flat_params())
+    # unchanged contents pass the digest
+    _, d = fresh()
+    d._presample(rays, img, epoch)
+    d.step(rays, img, pix, epoch); d.check_device_status()
+
+
 @pytest.mark.parametrize("epoch", [0, 3])
 def test_auxiliary_prior_terms_through_the_fused_step_match_the_oracle_autograd(epoch):
     """train_eonerf.py:145-155: metrics.depth_loss_L2 on the rendered depth (any epoch) and metrics.shadow_loss_L2 on the geometric shadows
