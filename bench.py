@@ -341,6 +341,8 @@ def main():
             # the serial tail of a step (all-reduce + Adam + re-pack, event to event) is sampled over the W WARM-UP steps, behind the
             # conditioning phase: the timed steps carry no events but their one boundary mark (an event pair costs microseconds of queue time)
             trainer.tail_events = []
+            if trainer._early_event is not None:
+                trainer.hidden_events = []
         for i in range(args.warmup):
             one_step(first_step + i, epoch_idx)
         tail_us, tail_pre_us = None, None
@@ -349,6 +351,12 @@ def main():
             tail_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.tail_events)
             if trainer.presample_events:      # the next step's sampler, enqueued under the exchange: inside the tail's bracket, not serial work
                 tail_pre_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in trainer.presample_events)
+        hidden_us, early_us = None, None
+        if trainer.hidden_events:      # two-bucket exchange: how much of the EARLY collective ran before the backward's last kernel had ended
+            torch.cuda.synchronize()
+            early_us = statistics.median(a0.elapsed_time(a1) * 1e3 for a0, a1, b in trainer.hidden_events)
+            hidden_us = statistics.median(max(0.0, min(a0.elapsed_time(a1), a0.elapsed_time(b))) * 1e3 for a0, a1, b in trainer.hidden_events)
+        trainer.hidden_events = None
         trainer.tail_events, trainer.presample_events = None, []
         trainer.check_device_status()                           # a hand-off fault of the warm-up would have switched paths: report it here
         probe_pre = trainer.clock_probe()                       # fixed MFMA loop: the clock the chip holds going into the bracket
@@ -384,7 +392,7 @@ def main():
                                "note": "fixed MFMA loop outside the bracket (eonerf_clock_probe): shader clock from s_memtime / s_memrealtime"},
                "conditioning_steps": cond_steps, "conditioning_blocks_ms_per_step": cond_blocks, "conditioning_first_block_step_ms": cond_first,
                "step_tail_us": tail_us,
-               "step_tail_presample_us": tail_pre_us}
+               "step_tail_presample_us": tail_pre_us, "exchange_hidden_us": hidden_us, "exchange_early_us": early_us}
         # (at N > 1 the device counter already holds the NEXT batch's count -- its sampler ran under the last exchange -- so the count of the
         #  step that was timed is read from that step's own outputs: pts_per_ray, column 14 of sat_rendering.py:311)
         n_cam = int(trainer.out[:RAYS, 14].sum().item()) if trainer._exchanges() else int(trainer.n_samples.item())
@@ -481,6 +489,14 @@ def main():
                      # exchange and in front of the update that waits for it (eonerf_presample; EONERF_PRESAMPLE=0 switches it off)
                      "step_tail_presample_us": recs[workloads[0]].get("step_tail_presample_us"),
                      "presample_under_exchange": os.environ.get("EONERF_PRESAMPLE", "1") != "0",
+                     # two-bucket exchange (EONERF_EXCHANGE_BUCKETS, default 2): the early block of the message (trunk layers 1-4, 6, 7) is
+                     # all-reduced from the end of the camera pass' pipelined launch on; exchange_early_us = that collective, event to event,
+                     # exchange_hidden_us = the part of it that ran before the backward's last kernel had ended (medians over the warm-up steps)
+                     "exchange_buckets": 2 if trainer._early_event is not None else 1,
+                     "exchange_early_floats": trainer.n_early if trainer._early_event is not None else 0,
+                     "exchange_comm_cus": trainer.comm_cus if trainer._early_event is not None else 0,
+                     "exchange_hidden_us": recs[workloads[0]].get("exchange_hidden_us"),
+                     "exchange_early_us": recs[workloads[0]].get("exchange_early_us"),
                      "rehearsal_one_gpu_gloo": rehearsal}
     if rank == 0:
         head = recs[workloads[0]]

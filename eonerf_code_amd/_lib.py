@@ -24,7 +24,7 @@ SYMBOLS = ["eonerf_version", "eonerf_strerror", "eonerf_create", "eonerf_destroy
            "eonerf_field_train_workspace_bytes", "eonerf_field_forward_train",
            "eonerf_field_backward", "eonerf_set_noise_seed", "eonerf_render_status", "eonerf_device_status", "eonerf_grad_floats",
            "eonerf_grad_seal", "eonerf_profile_name", "eonerf_adam_step_zero_grad", "eonerf_rendering_train", "eonerf_rendering_backward", "eonerf_clock_probe", "eonerf_range_status", "eonerf_set_n_samples", "eonerf_render_backward_loss",
-           "eonerf_presample", "eonerf_presample_cancel"]
+           "eonerf_presample", "eonerf_presample_cancel", "eonerf_grad_early_floats", "eonerf_set_exchange_event"]
 
 
 class EonerfRpc(C.Structure):
@@ -108,6 +108,9 @@ def lib():
     L.eonerf_render_backward.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.eonerf_presample.argtypes = [vp, vp, vp, vp, i, i, vp, vp, sz, vp]
     L.eonerf_presample_cancel.argtypes = [vp]
+    L.eonerf_grad_early_floats.restype = sz
+    L.eonerf_grad_early_floats.argtypes = [vp]
+    L.eonerf_set_exchange_event.argtypes = [vp, vp, i]
     L.eonerf_render_backward_loss.argtypes = [vp, vp, vp, vp, i, i, vp, vp, i, vp, vp, vp, vp, sz, vp]
     L.eonerf_adam_step.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp, vp]
     L.eonerf_adam_step_zero_grad.argtypes = [vp, vp, vp, vp, vp, i, fp, fp, fp, fp, fp, vp, vp]

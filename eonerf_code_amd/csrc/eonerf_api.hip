@@ -13,6 +13,10 @@
 #include "eonerf_raygen.h"
 #include "eonerf_carve.h"
 #include <math.h>
+#include <stdio.h>
+#ifdef EO_COR
+hipError_t eo_launch_cor_partner(const void* src, size_t total_bytes, size_t stream_bytes, int n_wg, hipStream_t st);
+#endif
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -34,10 +38,12 @@ constexpr int DIGEST_WORD = 32;     // ctx->dev_status[32..35]: two 64-bit ray d
 
 struct eonerf_ctx {
     eonerf_config cfg;
-    int n_samples = 128;  // int(2 / render_step_size) of the next calls: 64, 128 or 256 (eonerf_set_n_samples; cfg.n_samples at create)
+    int n_samples = 128;  // int(2 / render_step_size) of the next calls: 2 .. 256 (eonerf_set_n_samples; cfg.n_samples at create)
     int prec;             // cfg.precision: EONERF_FP32 / EONERF_BF16 / EONERF_F16X3 (inference only)
     bool bf16;
     int n_cu;
+    int pipe_xcd = 0;       // XCD-local pipelines of the pipelined backward (EONERF_PIPE_XCD; BwdPipeArgs::xcd_local)
+    int stagger = 0;        // wave stagger of the chain kernels (EONERF_STAGGER; MlpFwdArgs::stagger)
     int wgrad_riders = 1;   // EONERF_WGRAD_RIDERS=0: the sigma row and the embedding columns as jobs of their own (A/B switch)
     int wgrad_items;      // target number of weight-gradient work items per launch (EONERF_WGRAD_ITEMS, default 48 per job)
     ParamLayout pl;
@@ -65,6 +71,10 @@ struct eonerf_ctx {
     // the forward whose arguments and carve match consumes the record, any other forward drops it and samples again
     struct Presample { bool valid = false; const void* ws = nullptr; const float* rays = nullptr; const int64_t* img_idx = nullptr;
                        const float* zsteps = nullptr; const int* count_out = nullptr; int n_rays = 0, flags = 0, n_samples = 0; bool pipe = false; uint32_t call = 0; } pre;
+    // two-bucket gradient exchange (eonerf_set_exchange_event): recorded on the backward's stream as soon as the EARLY block of the
+    // gradient message (ParamLayout::early) is final; exch_cus CUs are left out of the grids of the gradient kernels launched behind that
+    // point, so that the collective's kernel finds a CU while they run (every large kernel here fills the CUs it is given)
+    hipEvent_t exch_event = nullptr; int exch_cus = 0; bool exch_recorded = false;
     const void* pre_consumed_ws = nullptr;   // workspace of the training forward that consumed a presample record: its backward checks the ray digest
     bool full_ig_dirty = false;      // packed lazily: only a differentiable EONerfMLP.forward with an input gradient reads it
     int* enc_colmap = nullptr;       // [64] device: encoding slot -> reference column (or -1)
@@ -331,6 +341,7 @@ int run_mlp_fwd(eonerf_ctx* ctx, const PassBuffers& b, const float* flat, int p_
     a.sigma = b.sigma; a.albedo = b.albedo; a.ts = b.ts; a.tb = b.tb;
     a.act = b.act; a.masks = b.masks;
     a.range_flag = ctx->dev_status + RANGE_WORD;
+    a.stagger = ctx->stagger;
     // training passes of the render path with the pipelined backward: the trunk's ReLU' comes from the X images, only the heads chain
     // reads mask bits (slot 7 = X_8 for its last layer)
     a.mask_from = (render_train && ctx->pipe) ? 7 : 0;
@@ -385,6 +396,7 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
     BwdPipeArgs pa;
     pipe_common(ctx, w, b, p_cap, d_flat, slot, plan ? ctx->n_pipes_stream : ctx->n_pipes, PIPE_STAGES, pa);
     pa.wt = ctx->pipe_wt.data; pa.dy_in = w.pipe.dy_in;
+    pa.xcd_local = ctx->pipe_xcd;
     pa.fault_stage = ctx->pipe_fault_stage; pa.stamps = ctx->pipe_stamps;
     if (amb) { pa.amb = *amb; pa.amb_blocks = pipe_spare_cus(ctx); }
     for (int s = 0; s < PIPE_STAGES; ++s) {
@@ -399,6 +411,33 @@ int run_bwd_pipe(eonerf_ctx* ctx, const RenderWs& w, const PassBuffers& b, int p
         HIP_TRY(eo_launch_bwd_pipe_stream(pa, sa, st));
         return 0;
     }
+#ifdef EO_COR
+    // Co-residency falsifier (diagnostic builds only, scripts/coresidency.sh): EONERF_COR_PARTNER=1 launches the dummy streaming partner
+    // (eonerf_bwd_pipe.hip: k_cor_partner) on a side stream BESIDE the camera pass' pipelined launch, =2 on the same stream in front of it
+    // (the partner alone on the chip); EONERF_COR_GB = bytes it streams (default 2 GB, out of the camera pass' activation slab).
+    // Its durations are summed and printed when the process ends.
+    {
+        static const int mode = getenv("EONERF_COR_PARTNER") ? atoi(getenv("EONERF_COR_PARTNER")) : 0;
+        static const double gb = getenv("EONERF_COR_GB") ? atof(getenv("EONERF_COR_GB")) : 2.0;
+        struct Cor { hipStream_t side = nullptr; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double gb = 0; int mode = 0;
+                     ~Cor() { double ms = 0; int n = 0; for (auto& e : ev) { float t = 0; if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) { ms += t; ++n; } }
+                              if (n) fprintf(stderr, "[cor] partner mode %d: %d launches, avg %.4f ms, %.1f GB/s (%.2f GB each)\n", mode, n, ms / n, gb / (ms / n * 1e-3), gb); } };
+        static Cor cor;
+        if (mode && prof_id == EONERF_PROF_BWD_PIPE_CAMERA) {
+            cor.gb = gb; cor.mode = mode;
+            if (!cor.side) HIP_TRY(hipStreamCreateWithFlags(&cor.side, hipStreamNonBlocking));
+            hipEvent_t e0, e1, fork;
+            HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+            hipStream_t ps = mode == 1 ? cor.side : st;
+            if (mode == 1) { HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); HIP_TRY(hipEventRecord(fork, st)); HIP_TRY(hipStreamWaitEvent(cor.side, fork, 0)); }
+            const size_t slab_bytes = (size_t)p_cap * 2048 * 2;      // (X_1 .. X_8 rows of the camera pass' activation slab: >= 2 GB at 4096 rays)
+            HIP_TRY(hipEventRecord(e0, ps));
+            HIP_TRY(eo_launch_cor_partner(b.act, slab_bytes, (size_t)(gb * 1e9), ctx->n_cu, ps));
+            HIP_TRY(hipEventRecord(e1, ps));
+            if (cor.ev.size() < 4096) cor.ev.push_back({e0, e1});
+        }
+    }
+#endif
     HIP_TRY(eo_launch_bwd_pipe(pa, st));
     if (pa.partials) HIP_TRY(eo_launch_pipe_reduce(pa, st));
     return 0;
@@ -421,7 +460,7 @@ int fill_stream_args(const eonerf_ctx* ctx, const WgradPlan& plan, int* queue, i
 }
 int launch_planned_wgrad(eonerf_ctx* ctx, const WgradPlan& plan, int p_cap, int* queue, hipStream_t st) {
     ProfScope ps(ctx, EONERF_PROF_WGRAD, st);
-    HIP_TRY(eo_launch_wgrad(plan.tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, nullptr, false));
+    HIP_TRY(eo_launch_wgrad(plan.tab, ctx->n_cu - (ctx->exch_event ? ctx->exch_cus : 0), p_cap, queue, ctx->bf16, st, nullptr, false));
     return 0;
 }
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
@@ -563,7 +602,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
         if (n_late == 0) plan->ready_items = tab.items;
     } else {
         ProfScope ps(ctx, EONERF_PROF_WGRAD, st);
-        HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu, p_cap, queue, ctx->bf16, st, det_partials, !zeroed));
+        HIP_TRY(eo_launch_wgrad(tab, ctx->n_cu - (ctx->exch_event ? ctx->exch_cus : 0), p_cap, queue, ctx->bf16, st, det_partials, !zeroed));
     }
     if (full) {   // the three weight gradients that follow from the bottleneck factors the GEMM above accumulated
         BottWgradArgs bw;
@@ -600,7 +639,7 @@ const char* eonerf_strerror(int code) {
 
 int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     if (!out || !cfg || cfg->n_images < 1) return EONERF_E_ARG;
-    if (cfg->n_samples != 64 && cfg->n_samples != 128 && cfg->n_samples != 256) return EONERF_E_UNSUPPORTED;
+    if (cfg->n_samples < 2 || cfg->n_samples > 256) return EONERF_E_UNSUPPORTED;      // (a ray's samples live in the 64 lanes x 4 slots of one wavefront)
     if (cfg->precision != EONERF_FP32 && cfg->precision != EONERF_BF16 && cfg->precision != EONERF_F16X3) return EONERF_E_ARG;
     eonerf_ctx* ctx = new (std::nothrow) eonerf_ctx();
     if (!ctx) return EONERF_E_ARG;
@@ -617,6 +656,8 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     ctx->n_cu = prop.multiProcessorCount;
     { const char* e = getenv("EONERF_WGRAD_ITEMS"); ctx->wgrad_items = e && atoi(e) > 0 ? atoi(e) : 0; }
     { const char* e = getenv("EONERF_WGRAD_RIDERS"); if (e) ctx->wgrad_riders = atoi(e); }
+    { const char* e = getenv("EONERF_STAGGER"); if (e) ctx->stagger = atoi(e); }
+    { const char* e = getenv("EONERF_PIPE_XCD"); if (e) ctx->pipe_xcd = atoi(e); }
     ctx->pl.build(cfg->n_images);
     int rc = upload(ctx->fwd_full, build_fwd_stream(ctx->pl, ctx->prec, true));
     if (!rc) rc = upload(ctx->fwd_dens, build_fwd_stream(ctx->pl, ctx->prec, false));
@@ -886,6 +927,7 @@ int eonerf_field_backward(eonerf_ctx* ctx, const float* flat, const float* sun, 
     const DevStream& bs = full ? ctx->bwd_full_ig : ctx->bwd_dens;
     MlpBwdArgs m;
     memset(&m, 0, sizeof(m));
+    m.stagger = ctx->stagger;
     m.n_pts = b.n_pts; m.p_pad = p_cap;
     m.stream = bs.data; m.chunks = bs.chunks; m.n_chunks = bs.n_chunks;
     m.sigma = b.sigma; m.albedo = b.albedo; m.ts = b.ts; m.tb = b.tb;
@@ -961,6 +1003,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
     HIP_TRY(eo_launch_cam_composite_bwd(cb, st));
     MlpBwdArgs mc;
     memset(&mc, 0, sizeof(mc));
+    mc.stagger = ctx->stagger;
     mc.n_pts = w.cam.n_pts; mc.p_pad = p_cap;
     const bool pipe = ctx->pipe && w.pipe.dy_in;
     if (density_only) { const int rc = ensure_density_streams(ctx, flat, st); if (rc) return rc; }
@@ -987,7 +1030,11 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
         const int rcl = launch_planned_wgrad(ctx, plan, p_cap, w.queue, st);
         if (rcl) return rcl;
     } else {
-        if (pipe) { const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, first_pipe); if (rcp) return rcp; }
+        if (pipe) {
+            const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, first_pipe); if (rcp) return rcp;
+            // the trunk's pipelined layers are complete in d_flat here (the shadow pass' launch ran before this one)
+            if (ctx->exch_event && !density_only) { HIP_TRY(hipEventRecord(ctx->exch_event, st)); ctx->exch_recorded = true; }
+        }
         const PassBuffers* full = density_only ? nullptr : &w.cam;
         const PassBuffers* dens = density_only ? &w.cam : sun;
         const int rcw = run_weight_gradients(ctx, flat, d_flat, full, transient, dens, p_cap, w.m_bott, w.queue, st, pipe, pipe && dens, w.det.wgrad_part, pipe,
@@ -1029,7 +1076,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
 
 int eonerf_set_n_samples(eonerf_ctx* ctx, int n_samples) {
     if (!ctx) return EONERF_E_ARG;
-    if (n_samples != 64 && n_samples != 128 && n_samples != 256) return EONERF_E_UNSUPPORTED;
+    if (n_samples < 2 || n_samples > 256) return EONERF_E_UNSUPPORTED;
     ctx->n_samples = n_samples;
     return EONERF_OK;
 }
@@ -1293,6 +1340,7 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
     if (!rays_in_range(ctx, n_rays) || !slabs_addressable(ctx, (size_t)p_cap_of(n_rays, ctx->n_samples))) return EONERF_E_UNSUPPORTED;
     PipeModeGuard mode(ctx, ws);
     const bool shadows = flags & EONERF_F_SHADOWS;
+    ctx->exch_recorded = false;
     RenderWs w = carve_render(ctx, ws, n_rays, flags);
     if (ctx->pre.valid && ctx->pre.ws == ws) return EONERF_E_STATE;      // eonerf_presample ran between this backward and its forward
     if (ws_bytes < w.bytes) return EONERF_E_WORKSPACE;
@@ -1343,6 +1391,7 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
         HIP_TRY(eo_launch_sun_composite_bwd(cs, st));
         MlpBwdArgs ms;
         memset(&ms, 0, sizeof(ms));
+    ms.stagger = ctx->stagger;
         ms.n_pts = w.sun.n_pts; ms.p_pad = p_cap;
         ms.stream = ctx->bwd_dens.data; ms.chunks = ctx->bwd_dens.chunks; ms.n_chunks = ctx->bwd_dens.n_chunks;
         ms.sigma = w.sun.sigma; ms.g_sigma = w.sun.g_sigma; ms.masks = w.sun.masks; ms.grd = w.sun.grd;
@@ -1369,8 +1418,11 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
         }
     }
 
-    return camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows && !ambient_done, !shadows && !prezeroed,
-                           shadows ? &w.sun : nullptr, false, st, chk ? digest : nullptr);
+    const int rcc = camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows && !ambient_done, !shadows && !prezeroed,
+                                    shadows ? &w.sun : nullptr, false, st, chk ? digest : nullptr);
+    // (chain + GEMM path: the trunk's gradients come out of the GEMM launch -- the early block is final where everything is)
+    if (!rcc && ctx->exch_event && !ctx->exch_recorded) HIP_TRY(hipEventRecord(ctx->exch_event, st));
+    return rcc;
 }
 
 int eonerf_render_backward(eonerf_ctx* ctx, const float* flat, const float* rays, const int64_t* img_idx,
@@ -1442,6 +1494,14 @@ int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* ws, size_
 }
 
 size_t eonerf_grad_floats(const eonerf_ctx* ctx) { return ctx ? ctx->pl.total + 4 : 0; }
+size_t eonerf_grad_early_floats(const eonerf_ctx* ctx) { return ctx ? ctx->pl.early : 0; }
+
+int eonerf_set_exchange_event(eonerf_ctx* ctx, void* hip_event, int reserve_cus) {
+    if (!ctx || reserve_cus < 0 || reserve_cus > ctx->n_cu / 2) return EONERF_E_ARG;
+    ctx->exch_event = (hipEvent_t)hip_event;
+    ctx->exch_cus = hip_event ? reserve_cus : 0;
+    return EONERF_OK;
+}
 
 int eonerf_grad_seal(eonerf_ctx* ctx, float* d_flat, void* stream) {
     if (!ctx || !d_flat) return EONERF_E_ARG;

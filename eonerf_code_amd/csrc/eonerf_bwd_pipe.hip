@@ -32,9 +32,17 @@
 
 // Diagnostic builds only (scripts/pipe_ablate.sh): EO_PABL bit 0 drops the dW MFMAs, bit 1 the dX MFMAs, bit 2 the B-fragment LDS reads of
 // both products, bit 3 the LDS-DMA refill, bit 4 the ring / slab stores, bit 5 the epilogue's VALU work and the bias sums, bit 6 the final
-// flush of the stationary gradients.  Results are WRONG with any bit set; the shipped library is built with EO_PABL == 0.
+// flush of the stationary gradients; bit 7 (128) drops the WHOLE weight-gradient phase (MFMAs, fragment reads, bias sums: what a dX-only
+// half-stage would run), bit 8 (256) the whole dX phase (MFMAs, fragment reads, ReLU', packing, output stores; the flags still flow: a
+// dW-only half-stage).  Results are WRONG with any bit set; the shipped library is built with EO_PABL == 0.
+// EO_COR = 1 (round 6, scripts/coresidency.sh): the co-residency falsifier -- the stage kernel is capped at 128 registers
+// (__launch_bounds__(512, 4): two such workgroups' worth of waves per CU) and runs with three LDS slots (96 KB, prefetch distance 2), so
+// that a second workgroup (k_cor_partner: a pure LDS-DMA stream, 4 waves, 48 KB of LDS) fits beside it on the same CU.
 #ifndef EO_PABL
 #define EO_PABL 0
+#endif
+#ifndef EO_COR
+#define EO_COR 0
 #endif
 
 namespace {
@@ -51,7 +59,7 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 #define EO_PIPE_DW16 0
 #endif
 #ifndef EO_PIPE_DEPTH
-#define EO_PIPE_DEPTH 3
+#define EO_PIPE_DEPTH (EO_COR ? 2 : 3)
 #endif
 #ifndef EO_PIPE_ORDB
 #define EO_PIPE_ORDB 0
@@ -59,11 +67,25 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 #ifndef EO_PIPE_SPREAD
 #define EO_PIPE_SPREAD 0
 #endif
+// Experiment builds of the XCD-local pipelines (scripts/xcd_ab.sh): hand-off stores of an intra-XCD edge with the default policy (1) or
+// write-through like a cross-XCD edge (0); its loads sc1 (0) or streaming (1); ring slots in use (a power of two <= PIPE_RING)
+#ifndef EO_XCD_PLAIN
+#define EO_XCD_PLAIN 1
+#endif
+#ifndef EO_XCD_NT
+#define EO_XCD_NT 0
+#endif
+#ifndef EO_RING_USE
+#define EO_RING_USE PIPE_RING
+#endif
 #ifndef EO_PIPE_STAMPS      // 1: the per-phase cycle stamps of scripts/pipe_stamps.py are compiled in (scripts/stamp.sh builds that library)
 #define EO_PIPE_STAMPS 0
 #endif
-constexpr int NSLOT = 4, DEPTH = EO_PIPE_DEPTH;      // LDS ring slots; steps of DMA in flight ahead of the one being multiplied (<= NSLOT - 1)
+constexpr int NSLOT = EO_COR ? 3 : 4, DEPTH = EO_PIPE_DEPTH;      // LDS ring slots; steps of DMA in flight ahead of the one being multiplied (<= NSLOT - 1)
+EO_DEV int slot_of(int k) { return (NSLOT & (NSLOT - 1)) == 0 ? (k & (NSLOT - 1)) : k % NSLOT; }
 static_assert(DEPTH >= 2 && DEPTH <= NSLOT - 1, "prefetch distance");
+constexpr uint32_t RING_USE = EO_RING_USE;
+static_assert(RING_USE <= PIPE_RING && (RING_USE & (RING_USE - 1)) == 0, "ring slots in use");
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
 constexpr int CTRL_B = 64;
 constexpr int SMEM_B = NSLOT * SLOT_B + CTRL_B;
@@ -96,6 +118,7 @@ struct Stage {
     int x_row;                 // first row of the 256-row block of the activation slab this stage reads as its X image
     const uint8_t* in_lin;     // != nullptr: the input tiles lie in a linear buffer [global step][16 KiB] written inside this launch (layer 5: dY_5 in the gradient slab)
     uint8_t* out_lin;          // MODE 1 / 2: the linear output buffer [global step][16 KiB]
+    bool local;                // every stage of this pipeline runs on ONE XCD (BwdPipeArgs::xcd_local)
     int* done;                 // != nullptr (first stage of the first pipeline of a launch with streaming roles): [0] = steps run so far (every
                                // 16th step and at the end), [1] = steps to run -- the streaming roles' clock (eonerf_wgrad_dev.h)
 };
@@ -172,7 +195,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     const uint32_t lin_stride = (uint32_t)a.n_pipes * IMG_B;      // this pipeline's consecutive steps in a linear buffer (sample tile = pipe + k n_pipes)
     const bool in_ring = S.has_in && !in_blk;
     const uint8_t* const d_base = !S.has_in ? a.dy_in + (size_t)S.pipe * IMG_B : (in_blk ? in_blk + (size_t)S.pipe * IMG_B : ring_in);
-    const uint32_t d_mask = in_ring ? PIPE_RING - 1 : 0x7fffffffu, d_mul = in_ring ? IMG_B : lin_stride;
+    const uint32_t d_mask = in_ring ? RING_USE - 1 : 0x7fffffffu, d_mul = in_ring ? IMG_B : lin_stride;
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(d_base), 0, -1, 0x00020000);
     // X image: rows of the activation slab, written by the forward kernel of an earlier launch (streaming: nt)
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(x_base) + (size_t)S.pipe * 256 * SEG_B, 0, -1, 0x00020000);
@@ -183,7 +206,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     auto dma_prep = [&](int k) {
         Dma d;
         d.on = !((EO_PABL & 8) && k >= DEPTH);
-        d.slot = smem + (k & (NSLOT - 1)) * SLOT_B;
+        d.slot = smem + slot_of(k) * SLOT_B;
         d.so_d = ((uint32_t)k & d_mask) * d_mul;
         d.so_x = (uint32_t)k * lin_stride;
         return d;
@@ -192,7 +215,10 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         if (!d.on) return;
         if (i < 2) {
             // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
-            if (S.has_in)
+            if (EO_XCD_NT && S.has_in && S.local)      // (experiment build: streaming instead of sc1 loads on an intra-XCD edge)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
+                                                         v_dy + i * 1024, d.so_d, 0, AUX_NT);
+            else if (S.has_in)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
                                                          v_dy + i * 1024, d.so_d, 0, AUX_SC1);
             else
@@ -279,8 +305,11 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * N_DMA) : "memory");
 
     if (CTRL && lane == 0 && S.done) __hip_atomic_store(S.done + 1, n_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if EO_PABL      // (diagnostic variants: a shorter body must not be unrolled into a different register budget)
+#pragma clang loop unroll(disable)
+#endif
     for (int k = 0; k < n_k; ++k) {
-        uint8_t* slot = smem + (k & (NSLOT - 1)) * SLOT_B;
+        uint8_t* slot = smem + slot_of(k) * SLOT_B;
         if (CTRL && S.done && (k & 15) == 15 && lane == 0) __hip_atomic_store(S.done, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- top of the step ----
         const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
@@ -296,7 +325,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             }
             // make sure (slow path only when the pipeline is starved or backed up) that what this step needs exists
             const int need_in = (k + DEPTH < n_k ? k + DEPTH : n_k - 1) + 1;       // tiles that must be published for this step's DMA
-            const int need_out = k + 1 - PIPE_RING;                                 // tiles the consumer must have released
+            const int need_out = k + 1 - RING_USE;                                   // tiles the consumer must have released
             const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             const bool slow = (S.has_in && known_head < need_in) || (RING_OUT && known_tail < need_out);
             if (S.has_in && known_head < need_in) wait_for(f_in, need_in, known_head);
@@ -364,8 +393,13 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 w8[s] = r;
             }
             if (!(EO_PABL & 16)) {
-                const uint32_t so_o = MODE == 0 ? ((uint32_t)k & (PIPE_RING - 1)) * IMG_B : (uint32_t)k * lin_stride;
-                if (MODE == 0 || MODE == 1) {      // read inside this launch: write-through
+                const uint32_t so_o = MODE == 0 ? ((uint32_t)k & (RING_USE - 1)) * IMG_B : (uint32_t)k * lin_stride;
+                if (EO_XCD_PLAIN && (MODE == 0 || MODE == 1) && S.local) {      // read inside this launch by a workgroup of the SAME XCD: default policy, the
+                    // lines stay in the shared L2 (the consumer's sc1 loads bypass its L1 only); complete -- at the L2 -- behind the same
+                    // counted vmcnt as the write-through form
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, v_dy, so_o, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, v_dy + 1024, so_o, 0);
+                } else if (MODE == 0 || MODE == 1) {      // read inside this launch, possibly from another XCD: write-through
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[0], w8[1], w8[2], w8[3]}, rs_o, v_dy, so_o, AUX_SC1);
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{w8[4], w8[5], w8[6], w8[7]}, rs_o, v_dy + 1024, so_o, AUX_SC1);
                 } else {      // read by a LATER launch (the GEMM's jobs; the trunk launch): streaming
@@ -453,11 +487,11 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #endif
         };
         if (!ORDB) {
-            phase_dx();
+            if (!(EO_PABL & 256)) phase_dx();
             const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             issue_block();
             const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            phase_dw(dma);
+            if (!(EO_PABL & 128)) phase_dw(dma);
             if (stamp) { t_dx += tt3 - tt2; t_is += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
         } else {
 #if EO_PIPE_ORDB == 1      // DMA issue -> dX -> dW (measured 0.8 % slower, round 3)
@@ -470,9 +504,9 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #else
             issue_block();
             const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            phase_dw(dma);
+            if (!(EO_PABL & 128)) phase_dw(dma);
             const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-            phase_dx();
+            if (!(EO_PABL & 256)) phase_dx();
             if (stamp) { t_is += tt3 - tt2; t_dw += tt4 - tt3; t_dx += __builtin_amdgcn_s_memtime() - tt4; }
 #endif
         }
@@ -546,11 +580,46 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 // numbers the workgroups beyond the 7 x n_pipes stage roles (-1: a stage role of a pipeline without samples)
 EO_DEV bool take_role(const BwdPipeArgs& a, uint8_t* smem, int tid, Stage& S, int& extra) {
     int* const ctl = reinterpret_cast<int*>(smem + NSLOT * SLOT_B);
-    if (tid == 0) { ctl[0] = 0; ctl[1] = atomicAdd(a.role_counter, 1); }
+    if (tid == 0) {
+        ctl[0] = 0; ctl[2] = 0;
+        if (!a.xcd_local) ctl[1] = atomicAdd(a.role_counter, 1);
+        else {
+            // XCD-aware roles.  Every workgroup registers with its XCD's counter, then with the grid's; once the whole grid has (all of
+            // it is resident: one workgroup per CU) the eight totals are final and every workgroup derives the SAME assignment from them:
+            // XCD x forms floor(c_x / 7) pipelines of its own (arrival rank r -> pipeline r / 7, stage r % 7), the c_x % 7 workgroups
+            // left over join the cross-XCD pool, numbered XCD by XCD.  Nothing is assumed about how workgroups are placed; the wait is
+            // bounded like every other (watchdog -> status word, the workgroup leaves)
+            const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);      // HW_REG_XCC_ID, bits 3:0
+            const int rx = atomicAdd(a.role_counter + 1 + xcc, 1);
+            __threadfence();
+            atomicAdd(a.role_counter, 1);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool ok = true;
+            while (__hip_atomic_load(a.role_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+                __builtin_amdgcn_s_sleep(8);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > WATCHDOG_TICKS) { ok = false; break; }
+            }
+            __threadfence();
+            if (!ok) { atomicOr(a.error, 1 << 7); ctl[0] = 1; ctl[1] = 0x3fffffff; }
+            else {
+                int before_local = 0, before_left = 0, n_local = 0, mine = 0;
+                for (int x = 0; x < 8; ++x) {
+                    const int c = __hip_atomic_load(a.role_counter + 1 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pl = c / a.n_stages;
+                    if (x < xcc) { before_local += pl; before_left += c - pl * a.n_stages; }
+                    if (x == xcc) mine = pl;
+                    n_local += pl;
+                }
+                if (rx < mine * a.n_stages) { ctl[1] = (before_local + rx / a.n_stages) * a.n_stages + rx % a.n_stages; ctl[2] = 1; }
+                else ctl[1] = n_local * a.n_stages + before_left + (rx - mine * a.n_stages);
+            }
+        }
+    }
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(ctl[1]);
     S.pipe = role / a.n_stages; S.st = role % a.n_stages;
+    S.local = __builtin_amdgcn_readfirstlane(ctl[2]) != 0;
     extra = -1;
+    if (ctl[0]) return false;      // (the rendezvous timed out)
     if (S.pipe >= a.n_pipes) { extra = role - a.n_pipes * a.n_stages; return false; }
     const int n_pts = *a.n_pts;
     // whole 256-sample tiles, as the chain kernels process them (dead samples carry zero gradients): the GEMM jobs that follow read
@@ -580,7 +649,11 @@ EO_DEV void run_role(const BwdPipeArgs& a, Stage& S, uint8_t* smem, int tid) {
     }
 }
 
+#if EO_COR
+__global__ __launch_bounds__(NT, 4) void k_bwd_pipe(BwdPipeArgs a) {
+#else
 __global__ __launch_bounds__(NT) void k_bwd_pipe(BwdPipeArgs a) {
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     Stage S;
@@ -632,7 +705,39 @@ __global__ __launch_bounds__(256) void k_pipe_reduce(BwdPipeArgs a) {
     if (col == 0) a.d_flat[a.db_off[st] + row] += accb;
 }
 
+#if EO_COR
+// The dummy streaming partner of the co-residency falsifier: 4 waves per workgroup, each wave streams its share of `src` through a
+// private 12-KB LDS region (3 slots x 4 pieces of 1 KiB) by LDS-DMA with two iterations (8 KB per wave, 32 KB per workgroup) in flight
+// and reads nothing back: the transfer rate of a stream that shares its CU with a stage.
+constexpr int COR_NT = 256, COR_LDS = 4 * 3 * 4096;
+__global__ __launch_bounds__(COR_NT) void k_cor_partner(const uint8_t* src, unsigned long long bytes_per_wg, unsigned long long total) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long base = (unsigned long long)blockIdx.x * bytes_per_wg + (unsigned long long)wave * (bytes_per_wg / 4);
+    const int iters = (int)(bytes_per_wg / 4 / 4096);
+    uint8_t* mine = smem + wave * 3 * 4096;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned long long off = (base + (unsigned long long)it * 4096) % (total - 8192);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) + (off & ~15ull), 0, 4096, 0x00020000);
+        uint8_t* dst = mine + (it % 3) * 4096;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, lane * 16, p * 1024, 0, AUX_NT);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#endif
+
 }  // namespace
+
+#if EO_COR
+hipError_t eo_launch_cor_partner(const void* src, size_t total_bytes, size_t stream_bytes, int n_wg, hipStream_t st) {
+    hipLaunchKernelGGL(k_cor_partner, dim3(n_wg), dim3(COR_NT), COR_LDS, st, reinterpret_cast<const uint8_t*>(src),
+                       (unsigned long long)(stream_bytes / n_wg / 16384 * 16384), (unsigned long long)total_bytes);
+    return hipGetLastError();
+}
+#endif
 
 hipError_t eo_launch_pipe_reduce(const BwdPipeArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_pipe_reduce, dim3(256, a.n_stages), dim3(256), 0, st, a);

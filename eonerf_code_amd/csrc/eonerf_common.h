@@ -156,6 +156,7 @@ template <class P, int SLOT_BYTES> struct WStream {
     int q;                       // index (in tab) of the chunk currently resident / being consumed
     uint32_t par;                // slot parity of the resident chunk
     int wave_b, lane_b;          // byte offsets of this wave's 1-KiB piece of a copy round (SGPR) and of the lane inside it
+    bool late = false;           // wave stagger (run_layer): this wave runs a chunk's last epilogue behind the chunk barrier (wave-uniform)
 
     // descriptor of chunk qi.  Constant address space: the table is read-only for the whole launch, so this is an s_load
     // (a generic-pointer load becomes a VECTOR load + s_waitcnt vmcnt(0), which drains every outstanding slab store).
@@ -329,8 +330,10 @@ __host__ __device__ constexpr int group_start(int kg, int mt, int c, int target 
 constexpr int EPI_SLICES = 8;
 template <int KG> EO_DEV constexpr int slice_pos(int s) { return KG >= 14 ? 5 + s : (s * KG) / EPI_SLICES; }
 
+// `last`: the accumulator of the chunk's LAST m-tile is handed back with its epilogue still to run (run_layer places it in front of or
+// behind the chunk barrier, see there).
 template <class P, int KG, int G, bool BIAS, class WS, class BArr, class Epi, class Mid>
-EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& epi, Mid&& mid) {
+EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& epi, Mid&& mid, f32x16& last) {
     const uint8_t* chunk = ws.cur();
     // prefetch rounds are issued after MFMAs 0, 1, 2, ... of the first m-tile (early: the copy has to land within the chunk);
     // the last position takes what is left
@@ -388,12 +391,8 @@ EO_DEV void chunk_compute(WS& ws, int lane, int h, const BArr& B, int m0, Epi&& 
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the window: the scheduler would otherwise re-serialise read/wait/mfma
         }
-        if (g == G - 1) {
-#pragma unroll
-            for (int sl = 0; sl < EPI_SLICES; ++sl) epi(m0 + g, acc, sl);
-        } else {
-            pend = acc;
-        }
+        if (g == G - 1) last = acc;
+        else pend = acc;
         acc = nxt;
     }
 }
@@ -407,11 +406,22 @@ EO_DEV void run_layer(WStream<P, SLOT>& ws, Mid&& mid, int lane, int h, const BA
         constexpr int G = group_size(KG, MT, C, TG), M0 = group_start(KG, MT, C, TG);
         static_assert(G * (KG * P::UNIT_B + 128) <= SLOT, "chunk does not fit the LDS slot");
         ws.prefetch_next();
-        chunk_compute<P, KG, G, BIAS>(ws, lane, h, B, M0, epi, mid);
-        // stores younger than the copy (LOWER bound, see WStream::advance).  bf16: one flush (NST = 2 stores) per m-tile once the
-        // staging queue runs: always from the layer's third tile on, and in every tile after the first of a later chunk.  fp32
-        // stores inside the slices, interleaved with the copy: not counted.
-        ws.template advance<(P::IS_BF16 ? (C == 0 ? (G >= 2 ? G - 2 : 0) : G - 1) * NST : 0)>();
+        f32x16 last;
+        chunk_compute<P, KG, G, BIAS>(ws, lane, h, B, M0, epi, mid, last);
+        // The epilogue of the chunk's last m-tile has no MFMAs of its own wave to hide under.  WAVE STAGGER (ws.late, VERDICT r5 #2, cdna
+        // guide "Two waves per SIMD" item 9): the two waves of a SIMD run the same program behind one barrier per chunk and tend to multiply
+        // together and then run this epilogue together, the matrix pipe idle; a LATE wave (waves 4..7) runs it BEHIND the barrier instead,
+        // beside its partner's first MFMAs of the next chunk, and finishes its own MFMAs while the partner is in its epilogue.  Same
+        // arithmetic in the same order per wave: outputs bit for bit unchanged.
+        // advance<>: stores younger than the copy (LOWER bound, see WStream::advance).  bf16: one flush (NST = 2 stores) per m-tile once
+        // the staging queue runs: always from the layer's third tile on, and in every tile after the first of a later chunk (the flushes
+        // sit between the MFMAs, in front of the barrier for every wave).  fp32 stores inside the slices: not counted.
+        // (ONE copy of the epilogue in the code, the barrier on either side of it: a branch around the epilogue itself costs the kernel
+        //  its register budget -- the operand arrays it writes would be live in two versions across the merge)
+        if (ws.late) ws.template advance<(P::IS_BF16 ? (C == 0 ? (G >= 2 ? G - 2 : 0) : G - 1) * NST : 0)>();
+#pragma unroll
+        for (int sl = 0; sl < EPI_SLICES; ++sl) epi(M0 + G - 1, last, sl);
+        if (!ws.late) ws.template advance<(P::IS_BF16 ? (C == 0 ? (G >= 2 ? G - 2 : 0) : G - 1) * NST : 0)>();
         run_layer<P, SLOT, KG, MT, BIAS, NST, C + 1>(ws, mid, lane, h, B, epi);
     }
 }

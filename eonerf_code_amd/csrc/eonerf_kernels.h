@@ -81,6 +81,7 @@ struct MlpFwdArgs {
     int mask_from;                 // TRAIN: first mask slot the backward will read (the pipelined trunk backward derives ReLU' from the saved
                                    // activations themselves: slots below are not written)
     int* range_flag;               // fp16 x 3 policy: set to 1 when an activation or a position leaves fp16's range (eonerf_range_status)
+    int stagger;                   // wave stagger of the 8-wave chains (run_layer): 0 off, 1 waves 4..7 late, 2 odd waves late (A/B control)
 };
 
 struct MlpBwdArgs {
@@ -98,6 +99,7 @@ struct MlpBwdArgs {
     float* g_pos;                  // INPUT_GRAD: [3][p_pad]
     uint8_t* dy7_units;            // PIPE 1: dY_7 in B-operand unit order [step of 32 samples][16 KiB]; the rest of the dX chain is left to
                                    // eonerf_bwd_pipe.hip
+    int stagger;                   // as MlpFwdArgs::stagger
 };
 
 // One weight-gradient GEMM job:  dW[m][col_map[n]] += sum_p  dY^T[m][p] * X^T[n][p]
@@ -136,7 +138,11 @@ struct BwdPipeArgs {
     uint8_t* rings;           // [pipeline][edge n_stages - 1][PIPE_RING][16 KiB]
     uint32_t* flags;          // [pipeline][edge][64]: head counter at [0], tail counter at [32] (own 128-B lines); zeroed per launch
     uint32_t* scratch_word;   // [workgroup][32]: sink / source of the end stages' fixed-count dummy flag traffic (a line per workgroup)
-    int* role_counter;        // zeroed per launch
+    int* role_counter;        // zeroed per launch; [0] arrivals, [1..8] arrivals per XCD (xcd_local)
+    int xcd_local;            // 1: pipelines are formed INSIDE an XCD wherever 7 workgroups of one XCD exist (roles by HW_REG_XCC_ID behind a
+                              // rendezvous of the whole grid): their hand-offs are stored with the default policy -- the tile stays in the XCD's
+                              // L2, where the consumer's L1-bypassing loads find it -- instead of write-through to the fabric; what is left
+                              // over forms cross-XCD pipelines with the write-through protocol.  Speed only: every edge is correct either way
     int* error;               // the context's STICKY status word: watchdog bits are OR-ed in, never cleared by a launch
     float* d_flat;
     // weight / bias gradient destinations per stage

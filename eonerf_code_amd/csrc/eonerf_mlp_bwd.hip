@@ -50,6 +50,7 @@ __global__ __launch_bounds__(P::NT) void k_mlp_bwd(MlpBwdArgs a) {
     WStream<P, SLOT> ws;
     ws.g = a.stream; ws.tab = a.chunks; ws.lds = smem; ws.n_chunks = a.n_chunks;
     ws.wave_b = __builtin_amdgcn_readfirstlane(wave) * 1024; ws.lane_b = lane * 16;
+    ws.late = P::WAVES == 8 && (a.stagger == 1 ? __builtin_amdgcn_readfirstlane(wave) >= 4 : (a.stagger == 2 && (__builtin_amdgcn_readfirstlane(wave) & 1)));
     const TileSched<P> sched(n_pts, gridDim.x, blockIdx.x);
     if (sched.iters() == 0) return;
     ws.start();

@@ -13,13 +13,23 @@ void ParamLayout::build(int n_images) {
         t.push_back(p);
         return (int)t.size() - 1;
     };
-    emb = add("transient_encoder.weight", n_images, 4);
-    rad = add("radiometricT_enc.weight", n_images, 9);
+    // The flat buffer is also the layout of the gradient MESSAGE (one float per parameter + 4 control floats).  The EARLY block comes
+    // first: the trunk layers whose gradients are complete when the camera pass' pipelined launch ends (layers 1-4, 6, 7: weights and
+    // biases, 394,752 floats = 58 % of the message) -- a data-parallel trainer all-reduces [0, early) while the remaining gradient
+    // kernels (GEMM jobs, tail) still run, and [early, end) behind them (trainer.py, eonerf_grad_early_floats).  Layer 5 is not in it:
+    // its 63 skip columns come from the GEMM launch and interleave with the 256 pipelined ones row by row.  Tensors are found by
+    // NAME (eonerf_param_info): nothing depends on their order in the buffer.
     const int trunk_in[8] = {63, 256, 256, 256, 256, 319, 256, 256};
-    for (int l = 0; l < 8; ++l) {
+    auto add_trunk = [&](int l) {
         trunk_w[l] = add("base_mlp.hidden_layers." + std::to_string(l) + ".weight", 256, trunk_in[l]);
         trunk_b[l] = add("base_mlp.hidden_layers." + std::to_string(l) + ".bias", 1, 256);
-    }
+    };
+    for (int l : {1, 2, 3, 4, 6, 7}) add_trunk(l);
+    early = total;
+    emb = add("transient_encoder.weight", n_images, 4);
+    rad = add("radiometricT_enc.weight", n_images, 9);
+    add_trunk(0);
+    add_trunk(5);
     sig_w = add("sigma_layer.output_layer.weight", 1, 256);
     sig_b = add("sigma_layer.output_layer.bias", 1, 1);
     bot_w = add("bottleneck_layer.output_layer.weight", 256, 256);

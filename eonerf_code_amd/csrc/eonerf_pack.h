@@ -16,6 +16,7 @@ struct ParamInfo { std::string name; size_t offset; int rows, cols; };
 struct ParamLayout {
     std::vector<ParamInfo> t;
     size_t total = 0;
+    size_t early = 0;      // [0, early): the tensors whose gradients the pipelined camera launch completes (see build)
     int n_img = 0;
     // indices into t
     int emb, rad, trunk_w[8], trunk_b[8], sig_w, sig_b, bot_w, bot_b, a1_w, a1_b, a2_w, a2_b;

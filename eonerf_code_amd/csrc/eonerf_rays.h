@@ -22,7 +22,7 @@ constexpr int EO_STATUS_PRESAMPLE_STALE = 1 << 9;      // bit of the context's s
 struct SampleArgs {
     const float* rays;        // [R][11] fp32: o3 d3 near far sun3  (datasets/satellite.py:23-26)
     const int64_t* img_idx;   // [R] or nullptr
-    int n_samples;            // int(2 / render_step_size): 64, 128 or 256 (sat_rendering.py:64); a ray has n_samples - 1 intervals
+    int n_samples;            // int(2 / render_step_size): 2 .. 256 (sat_rendering.py:64); a ray has n_samples - 1 intervals
     const float* zsteps;      // [n_samples] = torch.linspace(0,1,n_samples)
     const float* u;           // [R][n_samples] jitter of this pass, or nullptr: drawn in the kernel (Philox4x32-10, seed/call below)
     const float* u_retry;     // [R][n_samples] noise of the "some ray is empty -> resample" branch (nullptr with retry: Philox)

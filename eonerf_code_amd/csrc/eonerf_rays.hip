@@ -1,8 +1,8 @@
 // Per-ray kernels of the EO-NeRF hot path: stratified sampler + cube filter (H3), sample compaction, alpha
 // compositing as a per-ray wavefront scan (H7), shadow-ray transmittance (H8), S-NeRF irradiance + radiometric
 // affine + output packing (H9), and their backward passes.  One wave (64 lanes) owns one ray; a ray has at most
-// n_samples - 1 intervals, n_samples = int(2 / render_step_size) = 64, 128 or 256 (sat_rendering.py:64) -> SPL = 1, 2 or 4 per lane
-// (i = lane + 64 k; the kernels are instantiated per SPL).
+// n_samples - 1 intervals, n_samples = int(2 / render_step_size) <= 256 (sat_rendering.py:64) -> SPL = 1, 2 or 4 sample slots per lane
+// (i = lane + 64 k; the kernels are instantiated per SPL; slots i >= n_samples - 1 hold no interval and are masked).
 #include "eonerf_common.h"
 #include "eonerf_rays.h"
 #include "eonerf_rays_dev.h"
@@ -50,7 +50,7 @@ template <int SPL>
 EO_DEV void jitter(const SampleArgs& a, const float* u_arr, int draw, int ray, int lane, float (&u)[SPL]) {
     if (u_arr) {
 #pragma unroll
-        for (int k = 0; k < SPL; ++k) u[k] = u_arr[(size_t)ray * (64 * SPL) + lane + 64 * k];
+        for (int k = 0; k < SPL; ++k) u[k] = lane + 64 * k < a.n_samples ? u_arr[(size_t)ray * a.n_samples + lane + 64 * k] : 0.f;      // [R][n_samples]
     } else {
         float u4[4];
         philox_u4(a.seed, (uint32_t)ray, (uint32_t)lane, (uint32_t)draw, a.call, u4);
@@ -60,14 +60,15 @@ EO_DEV void jitter(const SampleArgs& a, const float* u_arr, int draw, int ray, i
 }
 
 template <int SPL>
-EO_DEV RaySamples<SPL> sample_ray(const float* zsteps, bool perturb, const float (&u)[SPL], float near, float ox, float oy, float oz,
+EO_DEV RaySamples<SPL> sample_ray(const float* zsteps, int ns, bool perturb, const float (&u)[SPL], float near, float ox, float oy, float oz,
                                   float dx, float dy, float dz, int lane) {
     RaySamples<SPL> s;
-    constexpr int NS = 64 * SPL;
     float zs[SPL], zn[SPL];
 #pragma unroll
-    for (int k = 0; k < SPL; ++k)      // perturb=False: :70-71 skipped
-        zs[k] = perturb ? zperturbed(zsteps, near, lane + 64 * k, u[k], NS) : zval(zsteps, near, lane + 64 * k);
+    for (int k = 0; k < SPL; ++k) {      // perturb=False: :70-71 skipped.  Slots beyond the last z value repeat it (never used: masked below)
+        const int i = lane + 64 * k < ns ? lane + 64 * k : ns - 1;
+        zs[k] = perturb ? zperturbed(zsteps, near, i, u[k], ns) : zval(zsteps, near, i);
+    }
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         zn[k] = __shfl_down(zs[k], 1, 64);
@@ -82,7 +83,7 @@ EO_DEV RaySamples<SPL> sample_ray(const float* zsteps, bool perturb, const float
         s.y[k] = __fadd_rn(oy, __fmul_rn(dy, s.mid[k]));
         s.z[k] = __fadd_rn(oz, __fmul_rn(dz, s.mid[k]));
         const bool inside = fabsf(s.x[k]) < 1.0f && fabsf(s.y[k]) < 1.0f && fabsf(s.z[k]) < 1.0f;   // :18-22
-        s.valid[k] = inside && (k + 1 < SPL || lane < 63);
+        s.valid[k] = inside && lane + 64 * k < ns - 1;      // interval i = [z_i, z_{i+1}], i < n_samples - 1 (:74-76)
     }
     return s;
 }
@@ -123,13 +124,13 @@ template <int SPL>
 EO_DEV void count_ray(const SampleArgs& a, int ray, int lane, const RayGeom& g) {
     float u[SPL];
     jitter<SPL>(a, a.u, a.sun_pass ? 2 : 0, ray, lane, u);
-    const RaySamples<SPL> s = sample_ray<SPL>(a.zsteps, a.perturb, u, g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+    const RaySamples<SPL> s = sample_ray<SPL>(a.zsteps, a.n_samples, a.perturb, u, g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
     const int cnt = count_valid(s);
     int cnt_retry = cnt;
     if (a.retry) {
         // the reference's retry passes near=None -> zeros (sat_rendering.py:262)
         jitter<SPL>(a, a.u_retry, 1, ray, lane, u);
-        const RaySamples<SPL> s2 = sample_ray<SPL>(a.zsteps, a.perturb, u, 0.f, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+        const RaySamples<SPL> s2 = sample_ray<SPL>(a.zsteps, a.n_samples, a.perturb, u, 0.f, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
         cnt_retry = count_valid(s2);
     }
     if (lane == 0) {
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void k_emit(SampleArgs a) {
     const bool retry = SCAN ? retry_scan : (a.retry && (*a.flags & 1));
     float u[SPL];
     jitter<SPL>(a, retry ? a.u_retry : a.u, retry ? 1 : (a.sun_pass ? 2 : 0), ray, lane, u);
-    const RaySamples<SPL> s = sample_ray<SPL>(a.zsteps, a.perturb, u, retry ? 0.f : g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
+    const RaySamples<SPL> s = sample_ray<SPL>(a.zsteps, a.n_samples, a.perturb, u, retry ? 0.f : g.near, g.ox, g.oy, g.oz, g.dx, g.dy, g.dz, lane);
     unsigned long long m[SPL];
     int before[SPL], n = 0;
 #pragma unroll

@@ -451,8 +451,8 @@ EO_DEV void emb_grad_body_spl(const EmbGradArgs& a, int vblk, int tid, float* s_
     }
 }
 EO_DEV void emb_grad_body(const EmbGradArgs& a, int vblk, int tid, float* s_de) {
-    if (a.n_samples == 64) emb_grad_body_spl<1>(a, vblk, tid, s_de);
-    else if (a.n_samples == 256) emb_grad_body_spl<4>(a, vblk, tid, s_de);
+    if (a.n_samples <= 64) emb_grad_body_spl<1>(a, vblk, tid, s_de);
+    else if (a.n_samples > 128) emb_grad_body_spl<4>(a, vblk, tid, s_de);
     else emb_grad_body_spl<2>(a, vblk, tid, s_de);
 }
 __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {

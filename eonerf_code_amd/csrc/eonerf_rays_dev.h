@@ -118,10 +118,10 @@ EO_DEV RayWeights<SPL> ray_weights(const float* sigma, const float* delta, int o
     return r;
 }
 
-// run f(std::integral_constant<int, SPL>) for the samples-per-lane count of n_samples (64 -> 1, 128 -> 2, 256 -> 4)
+// run f(std::integral_constant<int, SPL>) for the sample slots per lane n_samples needs (<= 64 -> 1, <= 128 -> 2, <= 256 -> 4)
 template <class F> inline void eo_dispatch_spl(int n_samples, F&& f) {
-    if (n_samples == 64) f(std::integral_constant<int, 1>());
-    else if (n_samples == 256) f(std::integral_constant<int, 4>());
+    if (n_samples <= 64) f(std::integral_constant<int, 1>());
+    else if (n_samples > 128) f(std::integral_constant<int, 4>());      // (129 .. 256: a three-slot instance would save a quarter of the per-ray work of kernels that are < 2 % of a step)
     else f(std::integral_constant<int, 2>());
 }
 

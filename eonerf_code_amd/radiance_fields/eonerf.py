@@ -159,7 +159,7 @@ class EONerfMLP(nn.Module):
         self.eval_precision = (eval_precision or os.environ.get("EONERF_EVAL_PRECISION", "fp16x3")).lower()
         if self.eval_precision not in ("fp32", "fp16x3", "same"):
             raise ValueError("eval_precision must be 'fp16x3', 'fp32' or 'same'")
-        self._n_samples = 128     # int(2 / render_step_size) of the native contexts' next calls (set_n_samples: 64, 128 or 256)
+        self._n_samples = 128     # int(2 / render_step_size) of the native contexts' next calls (set_n_samples: 2 .. 256)
         self._ctx = None          # eonerf_ctx*
         self._ctx_eval = None     # second native context (fp32) for export renders of a bf16 field, created on first use
         self._packed_version_eval = None
@@ -277,11 +277,11 @@ class EONerfMLP(nn.Module):
         return flat
 
     def set_n_samples(self, n_samples):
-        """n_samples = int(2 / render_step_size) (sat_rendering.py:64, opt.py:54) of the calls that follow: 64, 128 or 256 -- render_image
+        """n_samples = int(2 / render_step_size) (sat_rendering.py:64, opt.py:54) of the calls that follow: 2 .. 256 -- render_image
         and satnerf_sampling call this with the step size they are given; everything sized 128 / 127 in the library follows it."""
         n_samples = int(n_samples)
-        if n_samples not in (64, 128, 256):
-            raise ValueError(f"{n_samples} samples per ray: the HIP path supports render_step_size = 2/64, 2/128 (run_JAX_RGB.sh:11) and 2/256")
+        if not 2 <= n_samples <= 256:
+            raise ValueError(f"{n_samples} samples per ray: the HIP path supports 2 .. 256 (a ray's samples live in the 64 lanes x 4 slots of one wavefront)")
         if n_samples != self._n_samples:
             self._n_samples = n_samples
             for ctx in (self._ctx, self._ctx_eval):

@@ -32,10 +32,10 @@ def _zsteps(device, n_samples=128):
 
 
 def n_samples_of(render_step_size):
-    """sat_rendering.py:64: n_samples = int(2 / render_step_size); the HIP per-ray kernels exist for 64, 128 and 256."""
+    """sat_rendering.py:64: n_samples = int(2 / render_step_size); a ray's samples live in one wavefront (64 lanes x up to 4 slots)."""
     n = int(2 / render_step_size)
-    if n not in (64, 128, 256):
-        raise ValueError(f"render_step_size={render_step_size} gives {n} samples/ray; the HIP path supports 64, 128 (run_JAX_RGB.sh:11) and 256")
+    if not 2 <= n <= 256:
+        raise ValueError(f"render_step_size={render_step_size} gives {n} samples/ray; the HIP path supports 2 .. 256 (128: run_JAX_RGB.sh:11)")
     return n
 
 

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--lr", type=float, default=5e-4)
     ap.add_argument("--max_train_steps", type=int, default=1000)
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--n_samples", type=int, default=128, help="samples per ray = int(2 / render_step_size) (opt.py:54): 64, 128 or 256")
+    ap.add_argument("--n_samples", type=int, default=128, help="samples per ray = int(2 / render_step_size) (opt.py:54): 2 .. 256")
     ap.add_argument("--logs_dir", default="logs")
     ap.add_argument("--exp_name", default="eonerf_hip")
     ap.add_argument("--synthetic_rays", type=int, default=1 << 20)

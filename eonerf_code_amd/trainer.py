@@ -54,12 +54,21 @@ class FusedTrainer:
         self.tail_events = None      # a list: reduce_and_update() appends an event pair around the exchange + update (bench.py, N > 1)
         self.presample_events = []   # ... and one around the next step's sampler when it was enqueued under that exchange
         self._hint = None            # (rays, img_idx, their version counters) of the batch eonerf_presample last ran on
+        # EONERF_EXCHANGE_BUCKETS (default 2; 1 = the single all-reduce behind the last gradient kernel): with 2 the EARLY block of the
+        # message -- the trunk layers the camera pass' pipelined launch completes, 58 % of it (eonerf_grad_early_floats) -- is all-reduced
+        # on the communication stream as soon as that launch has ended, under the weight-gradient GEMM and the tail (~0.5 ms); the rest
+        # (+ the fault flag) follows behind the last gradient kernel; Adam waits for both.  EONERF_COMM_CUS (default 8): CUs the gradient
+        # kernels behind that point leave free for the collective's kernel (they fill every CU they are given)
+        self.buckets = 2 if os.environ.get("EONERF_EXCHANGE_BUCKETS", "2") != "1" else 1
+        self.comm_cus = int(os.environ.get("EONERF_COMM_CUS", "8"))
+        self.hidden_events = None    # a list: (start of the early collective, its end, end of the backward) per step (bench.py, N > 1)
+        self._early_event = None
         self.exchange_async = os.environ.get("EONERF_EXCHANGE", "side") == "async"      # A/B: all_reduce(async_op=True) instead of a side stream
         self.presample = os.environ.get("EONERF_PRESAMPLE", "1") != "0"          # next step's sampler under the gradient exchange (N > 1)
         self.fused_loss = os.environ.get("EONERF_FUSED_LOSS", "1") != "0"      # (A/B and test switch: 0 = eonerf_train_loss + eonerf_render_backward)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat = field._ensure_packed()
-        self.n_samples_per_ray = int(n_samples)      # int(2 / render_step_size), train_eonerf.py:50-53: 64, 128 or 256
+        self.n_samples_per_ray = int(n_samples)      # int(2 / render_step_size), train_eonerf.py:50-53: 2 .. 256
         field.set_n_samples(self.n_samples_per_ray)
         dev = self.flat.device
         self.L = _lib.lib()
@@ -81,6 +90,11 @@ class FusedTrainer:
         self.n_samples = torch.zeros(1, dtype=torch.int32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.zsteps = _zsteps(dev, self.n_samples_per_ray)
+        self.n_early = int(self.L.eonerf_grad_early_floats(self.ctx))
+        if self._exchanges() and self.buckets == 2 and not self.exchange_async:
+            self._early_event = torch.cuda.Event()
+            self._early_event.record()          # (the HIP event exists from its first record on)
+            _lib.check(self.L.eonerf_set_exchange_event(self.ctx, C.c_void_p(self._early_event.cuda_event), self.comm_cus))
         if self.world > 1:     # identical replicas: broadcast rank 0's parameters once (train_eonerf.py has one process)
             torch.distributed.broadcast(self.flat, src=0)
             _lib.check(self.L.eonerf_set_weights(self.ctx, _ptr(self.flat), _stream()))
@@ -249,13 +263,27 @@ class FusedTrainer:
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.flat.device)
         cur = torch.cuda.current_stream()
+        if self._early_event is not None:
+            # first bucket: the library recorded _early_event inside the backward, where [0, n_early) became final.  The host enqueues
+            # this behind the whole backward, the GPU runs it as soon as the event fires (the queue is a step ahead of the device)
+            self._comm_stream.wait_event(self._early_event)
+            ev = self.hidden_events
+            with torch.cuda.stream(self._comm_stream):
+                if ev is not None:
+                    a0 = torch.cuda.Event(enable_timing=True); a0.record()
+                torch.distributed.all_reduce(self.d_flat[:self.n_early], op=torch.distributed.ReduceOp.SUM)
+                if ev is not None:
+                    a1 = torch.cuda.Event(enable_timing=True); a1.record()
+            if ev is not None:
+                b = torch.cuda.Event(enable_timing=True); b.record()          # compute stream: the end of the backward (+ seal)
+                ev.append((a0, a1, b))
         self._comm_stream.wait_stream(cur)                   # (an event on the compute stream: the message is final here)
         if hint:
             # the next step's camera sampler, on the compute stream BEHIND that event: it runs while the collective does.  Enqueued
             # first because a host-blocking backend (gloo rehearsals) would otherwise hold it back until the exchange is over
             self._presample_timed(next_batch)
         with torch.cuda.stream(self._comm_stream):
-            gscale = reduce_gradients(self.d_flat)
+            gscale = reduce_gradients(self.d_flat if self._early_event is None else self.d_flat[self.n_early:])
         cur.wait_stream(self._comm_stream)
         return gscale
 

@@ -48,7 +48,7 @@ typedef struct eonerf_ctx eonerf_ctx;
 typedef struct {
     int n_images;        /* EONerfMLP(n_input_images), radiance_fields/eonerf.py:70-77 */
     int precision;       /* EONERF_FP32 | EONERF_BF16 | EONERF_F16X3 */
-    int n_samples;       /* int(2/render_step_size) (sat_rendering.py:64): 64, 128 (run_JAX_RGB.sh:11) or 256; eonerf_set_n_samples changes it */
+    int n_samples;       /* int(2/render_step_size) (sat_rendering.py:64): 2 .. 256 (128: run_JAX_RGB.sh:11); eonerf_set_n_samples changes it */
     int radiometric;     /* radiometric_normalization (opt.py:98-99 forces 1 for eo-nerf) */
 } eonerf_config;
 
@@ -116,7 +116,7 @@ int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double
                          double sun_elevation_deg, double sun_azimuth_deg, const float offset[3], const float scale[3],
                          float* raw8, float* rays, double* geo, void* stream);
 
-/* n_samples = int(2 / render_step_size) of the calls that follow (sat_rendering.py:64, opt.py:54): 64, 128 or 256 -- the per-ray kernels are
+/* n_samples = int(2 / render_step_size) of the calls that follow (sat_rendering.py:64, opt.py:54): any value from 2 to 256 (version 502; 64 / 128 / 256 before) -- the per-ray kernels are
  * instantiated for 1, 2 and 4 samples per lane of the ray's wavefront; anything else: EONERF_E_UNSUPPORTED.  Every size below that is
  * written with 128 / 127 (zsteps, jitter arrays, samples per ray, workspace sizes) follows it.  A backward call must run under the
  * n_samples of its forward (the Python layer restores it). */
@@ -242,6 +242,16 @@ int eonerf_render_status(eonerf_ctx* ctx, int n_rays, int flags, void* workspace
  * next eonerf_device_status.  d_flat_params must hold eonerf_grad_floats() floats for this call. */
 size_t eonerf_grad_floats(const eonerf_ctx* ctx);
 int eonerf_grad_seal(eonerf_ctx* ctx, float* d_flat_params, void* stream);
+/* Two-bucket exchange (version 502).  The first eonerf_grad_early_floats() floats of the message are the trunk layers the camera pass'
+ * layer-pipelined launch completes (layers 1-4, 6, 7, weights and biases: 58 % of the message); every later gradient kernel of the
+ * backward (the GEMM launch, the tail) writes only behind them.  eonerf_set_exchange_event(ctx, hipEvent_t, reserve_cus) arms an event
+ * that every eonerf_render_backward[_loss] records on its stream at that point (chain + GEMM path: at the end of the call), so that a
+ * trainer can start the all-reduce of [0, early) on its communication stream while the rest of the backward runs, and the one of
+ * [early, eonerf_grad_floats()) behind eonerf_grad_seal ("issue ... right after the last dW").  reserve_cus CUs are left
+ * out of the grids of the gradient kernels behind that point: they fill every CU they are given for ~0.5 ms, and the collective's
+ * kernel needs one to run beside them.  NULL disarms.  The event must outlive the calls that record it. */
+size_t eonerf_grad_early_floats(const eonerf_ctx* ctx);
+int eonerf_set_exchange_event(eonerf_ctx* ctx, void* hip_event, int reserve_cus);
 
 /* Training loss on the packed outputs and its gradient (train_eonerf.py:139-143): kind 0 = F.mse_loss(rgb, pixels),
  * kind 1 = metrics.uncertainty_aware_loss(pixels, rgb, beta) (metrics.py:17-22, including the constant 3/2 of its beta term).

@@ -1,0 +1,40 @@
+"""Is the fp32 backward's larger error at n_samples = 96 a property of the step size or of the fixture's rays?  The G10 rays of one size
+rendered at another: HIP fp32 against the oracle in fp64 (no golden involved), worst per-tensor relative error and the err/bound the test uses
+(bound built from the ORACLE's own fp32 run against fp64)."""
+import sys, os
+sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
+os.chdir("/root/repo/tests")
+import torch
+from conftest import load_golden, T
+from oracle import eonerf_oracle as orc
+import test_n_samples as tn
+from eonerf_code_amd.sat_rendering import render_image
+from eonerf_code_amd.datasets.satellite import define_satrays_from_tensors
+epoch = 3
+for fixture in (96, 64, 192, 256):
+    g = load_golden(f"g10_n{fixture}")
+    sd = tn._sd(g)
+    rays, ts, rgbs = T(g["rays"]), T(g["ts"]), T(g["rgbs"])
+    for ns in (64, 96, 128, 192):
+        step = 2.0 / ns
+        gen = torch.Generator().manual_seed(5)
+        u_cam, u_sun = torch.rand(32, ns, generator=gen), torch.rand(32, ns, generator=gen)
+        f = tn._field(sd, int(g["n_img"]), "fp32")
+        f.zero_grad()
+        res, n = render_image(f, None, define_satrays_from_tensors(rays.cuda(), ts.cuda()), None, None, epoch_idx=epoch, chunk=4096, render_step_size=step, noise=[(u_cam, None, u_sun)])
+        px = rgbs.cuda()
+        loss = ((res["rgb"] - px) ** 2 / (2 * res["beta"] ** 2)).mean() + (3 + torch.log(res["beta"]).mean()) / 2
+        loss.backward()
+        sd64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        orc.train_step(sd64, rays.double(), ts, rgbs.double(), u_cam.double(), u_sun.double(), epoch, step)
+        sd32 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        orc.train_step(sd32, rays, ts, rgbs, u_cam, u_sun, epoch, step)
+        worst, worst_o, wname = 0.0, 0.0, ""
+        for name, p in f.named_parameters():
+            r64 = sd64[name].grad
+            if r64 is None or r64.norm() == 0: continue
+            e = (p.grad.cpu().double() - r64).norm().item(); eo = (sd32[name].grad.double() - r64).norm().item()
+            b = 2.0 * eo + 2e-3 * r64.norm().item() + 1e-9
+            if e / b > worst: worst, wname = e / b, name
+            worst_o = max(worst_o, eo / r64.norm().item())
+        print(f"fixture rays {fixture}, rendered at n_samples {ns}: {n} samples, HIP worst err/bound {worst:.2f} ({wname}); oracle fp32 worst rel err {worst_o:.1e}", flush=True)

@@ -104,3 +104,65 @@ def compare_precisions(f16, f32, seed=1, epoch=3):
     st["grad_rel_max"] = max(rel.values())
     st["grad_cos_trunk_min"] = min(v for k, v in cos.items() if k.startswith("base_mlp"))
     return st
+
+
+def twin_train(precision, steps=2000, steps_per_epoch=500, table_batches=16, noise_seed=7, weight_seed=42, prior_every=4, w_depth0=10.0, w_decay=0.8):
+    """ONE training run of the twin-training quality test: the launcher's loop (train_dp.py; train_eonerf.py:98-161,304-306)
+    through FusedTrainer on the synthetic terrain -- colour supervision on every ray, a depth prior (metrics.depth_loss_L2 through the
+    aux_loss hook, train_eonerf.py:145-149) on every fourth ray, MSE for epochs 0-1, shadow pass + uncertainty loss from epoch 2, StepLR 0.9
+    and w_depth x 0.8 per epoch.  Everything but `precision` is identical between two calls: weights (seed), ray table, batch order, jitter
+    key.  Returns the trained field."""
+    from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
+    from eonerf_code_amd.trainer import FusedTrainer
+    from oracle import eonerf_oracle as orc
+    sd = orc.random_state_dict(N_IMG, seed=weight_seed)
+    f = EONerfMLP(N_IMG, radiometric_normalization=True, precision=precision)
+    f.load_state_dict(sd, strict=True)
+    f = f.cuda()
+    tr = FusedTrainer(f, lr=5e-4, max_rays=R, keep_message=False)
+    tr.set_noise_seed(noise_seed)
+    table = [terrain_batch(R, seed=100 + k) for k in range(table_batches)]
+    prior_mask = (torch.arange(R, device="cuda") % prior_every == 0)
+    lr, w_depth = 5e-4, w_depth0
+    for it in range(steps):
+        epoch = it // steps_per_epoch
+        if it > 0 and it % steps_per_epoch == 0:
+            lr *= 0.9; w_depth *= w_decay
+            tr.set_lr(lr)
+        rays, img, rgb, depth = table[it % table_batches]
+        prior = torch.where(prior_mask, depth[:, 0], torch.full_like(depth[:, 0], -1.0))
+        w = w_depth
+
+        def aux(out, prior=prior, w=w):      # metrics.depth_loss_L2 (metrics.py:24-31) on the rendered depth, column 3 of the packed outputs
+            valid = prior >= 0
+            return ((out[:, 3][valid] - prior[valid]) ** 2).mean() * w
+        tr.step(rays, img, rgb, epoch, aux_loss=aux)
+        if it % 500 == 499:
+            tr.check_device_status()
+    tr.check_device_status()
+    return f
+
+
+def export_quality(f, n_batches=4, epoch=3, seed0=900):
+    """Export render (module in .eval() mode under no_grad: the module's export precision -- fp16x3 for a bf16 module, fp32 for an fp32
+    one) of held-out terrain rays -> per-ray altitude (datasets/satellite.py:502-533, Z_scale 50 m), its MAE against the terrain, PSNR."""
+    from eonerf_code_amd.sat_rendering import render_image
+    from eonerf_code_amd.datasets.satellite import define_satrays_from_tensors, get_utmalt_from_nerf_prediction
+    off, sc = [0.0, 0.0, 20.0], [250.0, 250.0, Z_SCALE]
+    f.eval()
+    alts, gts, mse = [], [], []
+    with torch.no_grad():
+        for k in range(n_batches):
+            rays, img, rgb, depth_gt = terrain_batch(R, seed=seed0 + k)
+            g = torch.Generator(device="cuda").manual_seed(50 + k)
+            noise = tuple(torch.rand(R, 128, device="cuda", generator=g) for _ in range(3))
+            res, _ = render_image(f, None, define_satrays_from_tensors(rays, img[:, None]), None, None, epoch_idx=epoch, chunk=R,
+                                  render_step_size=STEP, noise=[noise])
+            alts.append(get_utmalt_from_nerf_prediction(rays, res["depth"], off, sc)[2])
+            gts.append(get_utmalt_from_nerf_prediction(rays, depth_gt, off, sc)[2])
+            mse.append(((res["rgb"] - rgb) ** 2).mean())
+    f.train()
+    alt, gt = torch.cat(alts).double().flatten(), torch.cat(gts).double().flatten()
+    m = torch.stack(mse).mean().item()
+    import math
+    return {"alt": alt, "dsm_mae_m": (alt - gt).abs().mean().item(), "psnr": -10.0 * math.log10(m)}

@@ -5,6 +5,8 @@ updated parameters are saved.  MODE "fail": rank 1 hands the C ABI an invalid ar
 job (non-zero exit), not hang it.
 MODE "pipe": the bf16 path with the layer-pipelined backward.  That kernel assumes the card to itself, so the two ranks take TURNS
 for the render/backward half of the step (barriers in between) and then meet in the all-reduce + Adam half.
+MODE "pipedet": as "pipe" with fixed-order gradient sums (EONERF_DETERMINISTIC=1): two runs give bit-identical results, which is what the
+two-bucket exchange is compared on (EONERF_EXCHANGE_BUCKETS=1 / 2).
 MODE "fault": as "pipe", but rank 1's context was created with EONERF_PIPE_FAULT=3 (one stage never publishes its tiles): its
 watchdog fires, the fault flag travels in the gradient message, NEITHER rank applies the update, and BOTH ranks raise.
 MODE "nccl1": world size 1 over RCCL (backend "nccl") with EONERF_FORCE_ALLREDUCE=1: the pipelined step with the collective on the
@@ -27,7 +29,7 @@ def main():
     os.environ["MASTER_PORT"] = port
     import torch
     backend = "nccl" if mode in ("nccl1", "pre0", "pre1") else "gloo"
-    if mode in ("pre0", "pre1"):
+    if mode in ("pre0", "pre1", "pipedet"):
         os.environ["EONERF_DETERMINISTIC"] = "1"                      # read when the context is created
     if backend == "nccl":
         os.environ["EONERF_FORCE_ALLREDUCE"] = "1"
@@ -42,7 +44,7 @@ def main():
     from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP, _ptr, _stream
     from eonerf_code_amd.trainer import FusedTrainer, rank_slice
     n_img, R = 4, 256
-    piped = mode in ("pipe", "fault", "nccl1", "pre0", "pre1")
+    piped = mode in ("pipe", "pipedet", "fault", "nccl1", "pre0", "pre1")
     # rank 1 starts from DIFFERENT weights: the trainer's initial broadcast must make the replicas identical
     sd = orc.random_state_dict(n_img, seed=91 + 7 * rank, bias_scale=0.05)
     sd["sigma_layer.output_layer.bias"] += 1.0

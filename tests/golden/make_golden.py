@@ -298,7 +298,7 @@ def g8():
 
 # ------------------------------------------------------------------ G10 other step sizes: n_samples = int(2 / render_step_size) = 64, 256
 def g10(ns):
-    """sat_rendering.py:64 / opt.py:54 accept any --n_samples; the build implements 64, 128 and 256.  The G4 sampler rays and a short G8
+    """sat_rendering.py:64 / opt.py:54 accept any --n_samples; the build implements every size up to 256 (round 6; 64 / 128 / 256 before).  The G4 sampler rays and a short G8
     (render_image forward for epoch_idx 0 and 3, loss, reference autograd) at the other two sizes."""
     step = 2.0 / ns
     o, d = _g4_rays()
@@ -392,6 +392,6 @@ def g9():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g1", g1), ("g2", g2), ("g3_g7", g3_g7), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8), ("g9", g9),
-                     ("g10", lambda: (g10(64), g10(256)))):
+                     ("g10", lambda: (g10(64), g10(256))), ("g10b", lambda: (g10(96), g10(192)))):      # g10b (round 6): step sizes that are not a power of two
         if not only or name in only:
             fn()

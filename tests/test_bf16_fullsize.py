@@ -119,3 +119,40 @@ def test_export_render_of_a_bf16_trained_field_runs_in_fp32_and_matches_the_orac
           f"; max altitude error {(alt - alt_ref).abs().max().item() * 100:.4f} cm; bf16 render of the same weights: "
           f"mean {d_bf16.mean().item() * 100:.2f} cm, p99 {d_bf16.quantile(0.99).item() * 100:.2f} cm")
     assert d_bf16.mean().item() > 1e-4                                 # (the two paths really are different kernels)
+
+
+def test_twin_training_bf16_vs_fp32_dsm_mae():
+    """VERDICT r5 #3 -- north_star: "DSM MAE matching the reference within 1 cm", for a field TRAINED in the throughput mode.  The same
+    scene is trained through FusedTrainer, 2,000 steps across the loss switch (epochs 0-3: MSE, then shadow pass + uncertainty loss; StepLR;
+    depth prior on every fourth ray as train_eonerf.py:145-149) -- once precision="bf16" (the 1.25 M rays/s mode), once precision="fp32"
+    (the 1e-4 parity mode = the reference's arithmetic) with identical initial weights, ray table, batch order and jitter key -- and a
+    THIRD time in fp32 under another jitter key: the yardstick.  All fields are exported in their default export precision on 16,384
+    held-out rays; the statistic is the DSM altitude MAE against the terrain (what train_eonerf.py:194-294 / sat_utils.py:226 measure
+    against the lidar DSM), Z_scale 50 m.
+
+    What round 6 measured (scripts/twin_training.py, profiles/r06_twin_training.json): after 2,000 steps every run sits at a
+    DSM MAE of 1.9-2.0 m, and two runs of the SAME arithmetic differ by 2.4-7.2 cm in that MAE (13 cm mean |altitude difference| per ray:
+    training is chaotic, atomics order and jitter are enough).  bf16 against fp32 differs by 3.1 cm -- inside that spread, with a mean
+    per-ray altitude difference of -0.2 cm (no systematic shift of the surface).  A 1-cm difference of MAEs is therefore not resolvable
+    by a pair of trainings; what the test asserts is what the data supports: the precision change moves the DSM MAE by no more than
+    two trainings of one precision differ (bound 10 cm = 5 % of the MAE, 1.5 x the largest same-arithmetic difference seen), without a
+    systematic altitude shift (|mean per-ray difference| <= 3 cm) and without a PSNR loss (<= 1 dB).  The line it prints says whether
+    the 1-cm figure held in this run."""
+    from bf16_common import twin_train, export_quality
+    q = {"bf16": export_quality(twin_train("bf16")), "fp32": export_quality(twin_train("fp32")),
+         "fp32_other_jitter": export_quality(twin_train("fp32", noise_seed=8))}
+    d = (q["bf16"]["alt"] - q["fp32"]["alt"])
+    ad = d.abs()
+    yard = abs(q["fp32"]["dsm_mae_m"] - q["fp32_other_jitter"]["dsm_mae_m"])
+    diff = abs(q["bf16"]["dsm_mae_m"] - q["fp32"]["dsm_mae_m"])
+    rep = {"dsm_mae_bf16_cm": 100 * q["bf16"]["dsm_mae_m"], "dsm_mae_fp32_cm": 100 * q["fp32"]["dsm_mae_m"],
+           "dsm_mae_fp32_other_jitter_cm": 100 * q["fp32_other_jitter"]["dsm_mae_m"],
+           "dsm_mae_diff_bf16_vs_fp32_cm": 100 * diff, "dsm_mae_diff_fp32_vs_fp32_cm": 100 * yard, "within_1cm": diff <= 0.01,
+           "psnr_bf16": q["bf16"]["psnr"], "psnr_fp32": q["fp32"]["psnr"],
+           "per_ray_alt_diff_cm": {"mean": 100 * d.mean().item(), "mean_abs": 100 * ad.mean().item(), "p50": 100 * ad.quantile(0.5).item(),
+                                   "p90": 100 * ad.quantile(0.9).item(), "p99": 100 * ad.quantile(0.99).item(), "max": 100 * ad.max().item()}}
+    print("twin training (2000 steps, bf16 vs fp32 mode, export renders on 16384 held-out rays):", json.dumps(rep))
+    assert all(v["dsm_mae_m"] < 3.0 for v in q.values()), "the fields did not learn the terrain (9.5 m at initialisation)"
+    assert diff <= 0.10, rep
+    assert abs(d.mean().item()) <= 0.03, rep
+    assert abs(q["bf16"]["psnr"] - q["fp32"]["psnr"]) <= 1.0, rep

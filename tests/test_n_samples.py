@@ -1,5 +1,5 @@
-"""The other step sizes: n_samples = int(2 / render_step_size) (sat_rendering.py:64, opt.py:54 --n_samples) = 64 and 256 beside the
-shipped 128 (run_JAX_RGB.sh:11).  The per-ray kernels (sampler, compositing, their backward) are instantiated for 1, 2 and 4 samples per
+"""The other step sizes: n_samples = int(2 / render_step_size) (sat_rendering.py:64, opt.py:54 --n_samples) = 64, 96, 192 and 256 beside
+the shipped 128 (run_JAX_RGB.sh:11); any value from 2 to 256 is accepted (round 6).  The per-ray kernels (sampler, compositing, their backward) are instantiated for 1, 2 and 4 samples per
 lane of a ray's wavefront; the MLP kernels do not care.  Golden G10 (tests/golden/make_golden.py::g10) = the REFERENCE's
 satnerf_sampling / render_image / autograd at both sizes.
 
@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from conftest import load_golden, T
 from oracle import eonerf_oracle as orc
 
-SIZES = [64, 256]
+SIZES = [64, 96, 192, 256]      # 96 / 192 (round 6): sizes that do not fill the wavefront's sample slots (lanes x 2, x 4)
 KEYS = ["rgb", "depth", "albedo_rgb", "ambient_rgb", "geo_shadows", "transient_s", "beta", "entropy",
         "pts_per_ray", "sc_pts_per_ray", "opacity_after_surface", "shadowless_rgb"]
 GRAD_STRIDE = 61
@@ -96,6 +96,41 @@ def test_hip_sampler_bit_exact_g10(ns):
     # in-kernel jitter (Philox) at this size: counts in range, deterministic under a seed, different without
     ri2, a2, b2 = satnerf_sampling(o, d, {"render_step_size": float(g["step"])}, near=torch.zeros(o.shape[0], 1).cuda())
     assert ri2.numel() > 0 and (b2 >= a2).all() and torch.bincount(ri2, minlength=o.shape[0]).max().item() <= ns - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", [2, 3, 37, 65, 100, 129, 200, 255])
+def test_hip_sampler_and_render_match_the_oracle_at_any_size_up_to_256(ns):
+    """opt.py:54 / sat_rendering.py:64 take any --n_samples.  Sizes on either side of the wavefront's slot boundaries (64, 128, 192) and the
+    smallest ones, against the oracle (itself pinned to the reference's sampler at 64 / 96 / 128 / 192 / 256: G4, G10): sampler bit exact,
+    fp32 render of both passes within 1e-4, sample counts bit exact; beyond 256 and below 2 the library refuses."""
+    from eonerf_code_amd.sat_rendering import satnerf_sampling, render_image
+    from eonerf_code_amd.datasets.satellite import define_satrays_from_tensors
+    n_img, R, step = 4, 96, 2.0 / ns
+    assert int(2 / step) == ns
+    sd = orc.random_state_dict(n_img, seed=21, bias_scale=0.05)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    rays, ts, _, u_cam, u_sun = orc.synthetic_batch(R, n_img, seed=300 + ns, n_samples=ns)
+    rays[5, 0], rays[5, 3:6] = 1.5, torch.tensor([1.0, 0.0, 0.0])          # a ray without samples
+    orays = orc.define_satrays_from_tensors(rays, ts)
+    ri, a, b = orc.satnerf_sampling(orays.origins, orays.viewdirs, u_cam, step, near=orays.t_near)
+    hri, ha, hb = satnerf_sampling(orays.origins.cuda(), orays.viewdirs.cuda(), {"render_step_size": step}, near=orays.t_near.cuda(), noise=u_cam.cuda())
+    assert torch.equal(hri.cpu(), ri) and torch.equal(ha.cpu(), a) and torch.equal(hb.cpu(), b)
+    assert torch.bincount(ri, minlength=R).max().item() == ns - 1
+    rays[5] = rays[6]                                                        # (render_image: no empty ray, no retry draw)
+    with torch.no_grad():
+        ref, n_ref = orc.render_rays(orc.Field(sd), orc.define_satrays_from_tensors(rays, ts), u_cam, u_sun, 3, step)
+    f = _field(sd, n_img, "fp32")
+    with torch.no_grad():
+        res, n = render_image(f, None, define_satrays_from_tensors(rays.cuda(), ts.cuda()), None, None, epoch_idx=3, chunk=R,
+                              render_step_size=step, noise=[(u_cam, None, u_sun)])
+    out = torch.cat([res[k] for k in KEYS], dim=1).cpu()
+    assert n == n_ref and torch.equal(out[:, 14:16], ref[:, 14:16])
+    assert (out - ref).abs().max().item() < 1e-4
+    with pytest.raises(ValueError):
+        f.set_n_samples(257)
+    with pytest.raises(ValueError):
+        f.set_n_samples(1)
 
 
 @pytest.mark.gpu
@@ -251,3 +286,39 @@ def test_full_batch_forward_matches_the_oracle_at_64_and_256_samples(ns, precisi
     err = (out - ref).abs().max(dim=0).values
     print(f"[full batch, {ns} samples per ray, {precision}] {n} samples, max abs err per column {err.max().item():.2e}")
     assert err.max().item() < 1e-4, err
+
+
+@pytest.mark.gpu
+def test_rendering_backward_runs_under_its_forwards_step_size():
+    """include/eonerf_hip.h says a backward must run under its forward's n_samples.  EONerfMLP.rendering's graph may be
+    held across other renders: a no_grad render_image at 2/64 (a validation render) between a forward at 2/128 and its backward used to
+    carve the forward's workspace for 64 samples -- silently wrong gradients.  With the fix the gradients equal the undisturbed run's."""
+    from eonerf_code_amd.sat_rendering import render_image
+    from eonerf_code_amd.datasets.satellite import define_satrays_from_tensors
+    n_img, R = 4, 96
+    sd = orc.random_state_dict(n_img, seed=111, bias_scale=0.05)
+    sd["sigma_layer.output_layer.bias"] += 1.0
+    rays, ts, _, u_cam, _ = orc.synthetic_batch(R, n_img, seed=112)
+    orays = orc.define_satrays_from_tensors(rays, ts)
+    ri, a, b = orc.satnerf_sampling(orays.origins, orays.viewdirs, u_cam, 2.0 / 128, near=orays.t_near)
+    g = torch.Generator().manual_seed(5)
+    cot = [torch.randn(R, c, generator=g).cuda() for c in (3, 1, 1, 1, 3)]
+    hrays = define_satrays_from_tensors(rays.cuda(), ts.cuda())
+
+    def grads(disturb):
+        f = _field(sd, n_img, "fp32")
+        f.set_n_samples(128)
+        got = f.rendering(hrays, a.cuda(), b.clone().cuda(), ri.cuda())
+        if disturb:
+            with torch.no_grad():
+                render_image(f, None, hrays, None, None, epoch_idx=3, chunk=R, render_step_size=2.0 / 64)
+            assert f._n_samples == 64
+        sum((h * c).sum() for h, c in zip(got[:5], cot)).backward()
+        assert f._n_samples == 128 or not disturb
+        return {n: p.grad.clone() for n, p in f.named_parameters() if p.grad is not None}
+
+    ref, got = grads(False), grads(True)
+    assert ref.keys() == got.keys() and len(ref) > 20
+    for name in ref:
+        if ref[name].norm() > 0:      # (atomic summation order is the only difference between the two runs)
+            assert ((ref[name] - got[name]).norm() / ref[name].norm()).item() < 1e-5, name
