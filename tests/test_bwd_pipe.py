@@ -14,16 +14,17 @@ pytestmark = pytest.mark.gpu
 N_IMG = 19
 
 
-def _field(pipe, seed=7, fault=None):
-    """pipe: the layer-pipelined trunk backward (the heads stay in the heads chain + GEMM jobs)."""
+def _field(pipe, seed=7, fault=None, xcd=False):
+    """pipe: the layer-pipelined trunk backward (the heads stay in the heads chain + GEMM jobs); xcd: its XCD-local layout (EONERF_PIPE_XCD)."""
     from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP
     sd = orc.random_state_dict(N_IMG, seed=seed, bias_scale=0.05)
     sd["sigma_layer.output_layer.bias"] += 1.0
     f = EONerfMLP(N_IMG, radiometric_normalization=True, precision="bf16")
     f.load_state_dict(sd, strict=True)
     f = f.cuda()
-    old = {k: os.environ.get(k) for k in ("EONERF_PIPE", "EONERF_PIPE_FAULT")}
+    old = {k: os.environ.get(k) for k in ("EONERF_PIPE", "EONERF_PIPE_FAULT", "EONERF_PIPE_XCD")}
     os.environ["EONERF_PIPE"] = "1" if pipe else "0"
+    os.environ["EONERF_PIPE_XCD"] = "1" if xcd else "0"
     if fault is not None:
         os.environ["EONERF_PIPE_FAULT"] = str(fault)
     try:
@@ -59,6 +60,20 @@ def test_pipelined_backward_matches_chain_plus_gemm(R, epoch):
     assert abs(l0 - l1) <= 1e-6 * abs(l0)             # the loss itself is an atomic sum over rays
     assert torch.isfinite(g1).all()
     for (name, p), a, b in zip(f_old.named_parameters(), f_old.grad_views(g0), f_new.grad_views(g1)):
+        assert (a - b).norm().item() <= 1e-4 * a.norm().item() + 1e-10, (name, (a - b).norm().item(), a.norm().item())
+
+
+@pytest.mark.parametrize("R,epoch", [(4096, 3), (300, 0)])
+def test_xcd_local_pipelines_give_the_same_gradients(R, epoch):
+    """EONERF_PIPE_XCD=1 (round 6, off by default: measured neutral, profiles/r06_xcd_local_pipelines.txt): roles by HW_REG_XCC_ID behind a
+    rendezvous of the grid, pipelines formed inside an XCD hand their tiles over with default-policy stores (they stay in the XCD's L2),
+    the left-over workgroups form cross-XCD pipelines with the write-through protocol.  Placement and hand-off policy only: the same
+    gradients as the default layout (summation order of the per-pipeline partial sums differs: 1e-4 per tensor)."""
+    f_a, f_b = _field(True), _field(True, xcd=True)
+    l0, g0, _ = _grads(f_a, R, epoch)
+    l1, g1, _ = _grads(f_b, R, epoch)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0) and torch.isfinite(g1).all()
+    for (name, p), a, b in zip(f_a.named_parameters(), f_a.grad_views(g0), f_b.grad_views(g1)):
         assert (a - b).norm().item() <= 1e-4 * a.norm().item() + 1e-10, (name, (a - b).norm().item(), a.norm().item())
 
 
