@@ -435,6 +435,11 @@ def main():
                                  "survey_8d_3xF_measured_samples": s8d / sec / 1e12 / peak,
                                  "executed_mfma_flop": executed / sec / 1e12 / peak}
         rec["step_tflops_per_gpu"] = s8d / sec / 1e12
+        # the co-limit: bytes the step moves across the L2's fabric side (HBM + Infinity Cache; profiles/traffic.json, measured on the build
+        # named in roofline.traffic_source) over THIS run's step time, against the 8 TB/s HBM peak; 6.2-6.9 TB/s is what a pure stream reaches
+        tot = TRAFFIC.get(("rgb_" if wl == "rgb" else "full_") + args.precision, {}).get("step_total")
+        rec["step_hbm_frac"] = {"fabric_bytes_per_step": tot, "gbps": tot / sec / 1e9, "frac_of_8TBps": tot / sec / 1e9 / PEAK_HBM_GBPS,
+                                "source": TRAFFIC.get("_source")} if tot else None
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
             kd = kernels[dom]
@@ -443,6 +448,8 @@ def main():
                                "frac": kd["frac_mfma"], "frac_mfma": kd["frac_mfma"],
                                "algorithmic_flop_per_launch": kd["algorithmic_flop_per_launch"], "avg_launch_ms": kd["avg_ms"],
                                "traffic": TRAFFIC.get(key, {}).get(dom),
+                               # (a profile constant, not measured by this run: which build and rocprofv3 pass it comes from)
+                               "traffic_source": TRAFFIC.get("_source"),
                                "hbm": {"achieved_gbps": kd["hbm_gbps"], "peak_gbps": PEAK_HBM_GBPS, "frac": kd["hbm_gbps"] / PEAK_HBM_GBPS,
                                        "design_bytes_per_launch": kd["design_hbm_bytes_per_launch"],
                                        "note": "bytes the design stashes/re-reads, not SURVEY 8(d)'s compulsory 148 B/ray"}}
@@ -513,7 +520,7 @@ def main():
                     "conditioning_first_block_step_ms": f["conditioning_first_block_step_ms"],
                     "camera_samples_per_step": f["camera_samples_per_step"], "sun_samples_per_step": f["sun_samples_per_step"],
                     "roofline": f.get("roofline"), "kernels": f.get("kernels"), "step_mfma_frac": f["step_mfma_frac"],
-                    "final_loss": f["final_loss"]}
+                    "step_hbm_frac": f.get("step_hbm_frac"), "final_loss": f["final_loss"]}
 
         result = {
             "metric": "train rays/sec on JAX_068 (4096 rays x 128 samples)", "value": head["rays_per_s"], "unit": "rays/s",
@@ -530,6 +537,7 @@ def main():
             "roofline": head.get("roofline"),
             "kernels": head.get("kernels"),
             "step_mfma_frac": head["step_mfma_frac"],
+            "step_hbm_frac": head.get("step_hbm_frac"),
         }
         for wl in workloads[1:]:
             result[wl] = nested(wl)

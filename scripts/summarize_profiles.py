@@ -108,5 +108,13 @@ traffic["_note"] = ("bytes per launch (per step for kernels launched twice a ste
                     "request counters (gfx950: FETCH_SIZE reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section; Infinity-Cache "
                     "hits are counted, so the ring hand-offs of the pipelined backward appear here although they never reach HBM); separate "
                     "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `bench.py --steps 4 --warmup 2 --workload <wl>`; " + TAG)
+# which build the counters describe: the commit the profiled snapshot was taken from (the profile run is started from a clean tree)
+import subprocess
+try:
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(DST), capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "eonerf_code_amd", "bench.py"], cwd=os.path.dirname(DST), capture_output=True, text=True).stdout.strip())
+except OSError:
+    head, dirty = "unknown", False
+traffic["_source"] = {"profile_set": TAG, "commit": head + ("+uncommitted" if dirty else ""), "files": [f"profiles/{TAG}_pmc_hbm_traffic_full.csv", f"profiles/{TAG}_pmc_hbm_traffic_rgb.csv"]}
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
