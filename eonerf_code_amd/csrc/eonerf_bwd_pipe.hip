@@ -78,6 +78,15 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 #ifndef EO_RING_USE
 #define EO_RING_USE PIPE_RING
 #endif
+// EO_PIPE_EARLY_TR (round 6): bit 0 -- the transposed A-fragment reads of the dW phase are issued in FRONT of the step's DMA issue block
+// (their LDS latency runs under the block instead of in front of the first dW MFMA); bit 1 -- the ReLU' reads of the dX phase are issued
+// three MFMAs before the end of its chain instead of behind it.
+#ifndef EO_PIPE_EARLY_TR
+#define EO_PIPE_EARLY_TR 0
+#endif
+#ifndef EO_PIPE_XM_AT      // (bit 1: behind which MFMA of the dX chain the ReLU' reads are issued)
+#define EO_PIPE_XM_AT 14
+#endif
 #ifndef EO_PIPE_STAMPS      // 1: the per-phase cycle stamps of scripts/pipe_stamps.py are compiled in (scripts/stamp.sh builds that library)
 #define EO_PIPE_STAMPS 0
 #endif
@@ -359,6 +368,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         //      multiply at the same time and then both idle the matrix pipe at the same time) ----
         auto phase_dx = [&]() {        // dX = W^T dY (16 MFMAs, B units of the dY image 3 reads ahead), ReLU', pack, hand on
             f32x16 acc = zero_acc();
+            u32x2 xm[4] = {};
             {
                 const uint8_t* bp = slot + lane * 16;
                 // operand window: WIN reads ahead of the MFMA that consumes them
@@ -370,10 +380,20 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 for (int kg = 0; kg < 16; ++kg) {
                     if (!(EO_PABL & 2)) acc = P::mma(wt[kg], fr[kg % WIN], acc);
                     if (!(EO_PABL & 4) && kg + WIN < 16) fr[kg % WIN] = lds_unit<P>(bp + (kg + WIN) * 1024);
+                    if ((EO_PIPE_EARLY_TR & 2) && kg == EO_PIPE_XM_AT)      // the last B unit has been requested: the window's registers free up from here on
+                        asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                                     "ds_read_b64_tr_b16 %1, %5\n\t"
+                                     "ds_read_b64_tr_b16 %2, %6\n\t"
+                                     "ds_read_b64_tr_b16 %3, %7"
+                                     : "=&v"(xm[0]), "=&v"(xm[1]), "=&v"(xm[2]), "=&v"(xm[3])
+                                     : "v"((uint32_t)(uintptr_t)(slot + xm_off[0])), "v"((uint32_t)(uintptr_t)(slot + xm_off[1])),
+                                       "v"((uint32_t)(uintptr_t)(slot + xm_off[2])), "v"((uint32_t)(uintptr_t)(slot + xm_off[3])) : "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            u32x2 xm[4] = {};
+            if (EO_PIPE_EARLY_TR & 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xm[0]), "+v"(xm[1]), "+v"(xm[2]), "+v"(xm[3]) :: "memory");
+            else
             asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
                          "ds_read_b64_tr_b16 %1, %5\n\t"
                          "ds_read_b64_tr_b16 %2, %6\n\t"
@@ -408,6 +428,20 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 }
             }
         };
+#if !EO_PIPE_DW16
+        u32x2 ta[2][2] = {};
+        auto dw_prefetch = [&]() {
+            if (!(EO_PIPE_EARLY_TR & 1) || (EO_PABL & 128)) return;
+            const uint32_t ra = (uint32_t)(uintptr_t)(slot + tr_off);
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                         "ds_read_b64_tr_b16 %1, %4 offset:64\n\t"
+                         "ds_read_b64_tr_b16 %2, %4 offset:256\n\t"
+                         "ds_read_b64_tr_b16 %3, %4 offset:320"
+                         : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]) : "v"(ra) : "memory");
+        };
+#else
+        auto dw_prefetch = [&]() {};
+#endif
         auto phase_dw = [&](const Dma& dma) {        // dW += dY X^T over the 32 samples of the step, db += row sums; the next DMA pieces in between
 #if EO_PIPE_DW16
             // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
@@ -447,8 +481,10 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #else
             // A fragments = the dY image read TRANSPOSED (inline asm: for the intrinsic the wait-count pass assumes aliasing with the
             // LDS-DMA in flight and drains it)
-            u32x2 ta[2][2];
             const uint32_t ra = (uint32_t)(uintptr_t)(slot + tr_off);
+            if (EO_PIPE_EARLY_TR & 1)      // issued by dw_prefetch() in front of the DMA issue block
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0][0]), "+v"(ta[0][1]), "+v"(ta[1][0]), "+v"(ta[1][1]) :: "memory");
+            else
             asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
                          "ds_read_b64_tr_b16 %1, %4 offset:64\n\t"
                          "ds_read_b64_tr_b16 %2, %4 offset:256\n\t"
@@ -489,6 +525,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         if (!ORDB) {
             if (!(EO_PABL & 256)) phase_dx();
             const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            dw_prefetch();
             issue_block();
             const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             if (!(EO_PABL & 128)) phase_dw(dma);
@@ -502,6 +539,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             phase_dw(dma);
             if (stamp) { t_is += tt3 - tt2; t_dx += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
 #else
+            dw_prefetch();
             issue_block();
             const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             if (!(EO_PABL & 128)) phase_dw(dma);

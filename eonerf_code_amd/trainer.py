@@ -160,7 +160,8 @@ class FusedTrainer:
             u_cam, u_retry, u_sun = noise
         self.field.set_n_samples(self.n_samples_per_ray)      # (another caller of the module may have rendered at another step size)
         hint, self._hint = self._hint, None
-        if hint is not None and (hint[0] is not rays or hint[1] is not img_idx or hint[2] != rays._version or hint[3] != img_idx._version):
+        if hint is not None and (hint[0].data_ptr() != rays.data_ptr() or hint[1].data_ptr() != img_idx.data_ptr() or hint[0].shape != rays.shape
+                                 or hint[2] != rays._version or hint[3] != img_idx._version):
             # the presampled record is not for THESE tensors as they are now (other batch, or the same buffers refilled in place): drop it,
             # the forward samples itself.  (What torch cannot see -- a raw-pointer write -- the library's device-side digest catches.)
             _lib.check(self.L.eonerf_presample_cancel(self.ctx))
@@ -241,8 +242,9 @@ class FusedTrainer:
         _lib.check(self.L.eonerf_presample(self.ctx, _ptr(rays), _ptr(img_idx), _ptr(self.zsteps), n, flags, _ptr(self.n_samples),
                                            _ptr(ws), ws.numel(), _stream()))
         # the library matches the record to its forward by POINTER; the contents are ours to vouch for: remember the tensors' version
-        # counters (an in-place refill of a reused staging tensor bumps them) and keep the tensors alive (a freed batch re-allocated at the
-        # same address would pass the pointer test)
+        # counters (an in-place refill of a reused staging tensor bumps them; views of one table share their base's counter, so another
+        # slice object over the same rows compares equal) and keep the tensors alive (a freed batch re-allocated at the same address would
+        # pass the pointer test)
         self._hint = (rays, img_idx, rays._version, img_idx._version)
 
     def _reduce(self, st, next_batch=None):
