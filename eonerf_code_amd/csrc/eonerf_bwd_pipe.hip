@@ -82,7 +82,7 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 // (their LDS latency runs under the block instead of in front of the first dW MFMA); bit 1 -- the ReLU' reads of the dX phase are issued
 // three MFMAs before the end of its chain instead of behind it.
 #ifndef EO_PIPE_EARLY_TR
-#define EO_PIPE_EARLY_TR 0
+#define EO_PIPE_EARLY_TR 1      // bit 0 on since round 6: -1.9 % on the camera launch, -0.55 % on the step (profiles/r06_early_tr_reads.txt); bit 1: neutral
 #endif
 #ifndef EO_PIPE_XM_AT      // (bit 1: behind which MFMA of the dX chain the ReLU' reads are issued)
 #define EO_PIPE_XM_AT 14

@@ -190,7 +190,7 @@ def test_hip_backward_fp32_as_exact_as_the_reference_g10(tag, epoch, ns):
     sd32 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     orc.train_step(sd32, rays, ts, rgbs, u_cam, u_sun, epoch, step)
     params = dict(f.named_parameters())
-    worst = 0.0
+    worst, tot = 0.0, [0.0, 0.0, 0.0]
     for k, v in g.items():
         if not k.startswith(f"{tag}.grad."):
             continue
@@ -203,14 +203,17 @@ def test_hip_backward_fp32_as_exact_as_the_reference_g10(tag, epoch, ns):
         g32 = sd32[name].grad
         o32 = compact_grad(g32 if g32 is not None else torch.zeros_like(p, device="cpu"))[2:]
         ref_err, err = max((ref - r64).norm().item(), (o32 - r64).norm().item()), (got - r64).norm().item()
-        # (factor 4 on the larger of two fp32 evaluations of the reference graph; 1.5 on the one golden at n_samples = 128.  With 32 rays the
+        # (per tensor: factor 8 on the larger of two fp32 evaluations of the reference graph; 1.5 on the one golden at n_samples = 128.  With 32 rays the
         #  fp32 error of a tensor is a handful of discrete events -- a ReLU or a clip that falls on the other side for one sample -- and
         #  varies 4 x from tensor to tensor and from one evaluation order to the next: profiles/r06_fp32_backward_fixture_sensitivity.txt
         #  renders every fixture's rays at every size, HIP against the oracle's fp32 run: err / (2 x oracle error + 2e-3 norm) between 0.11
         #  and 2.07, the largest values at 128 samples, none of it following the step size)
-        worst = max(worst, err / (4.0 * ref_err + 2e-3 * r64.norm().item() + 1e-9))
-        assert err <= 4.0 * ref_err + 2e-3 * r64.norm().item() + 1e-9, (k, err, ref_err)
-    print(f"[n_samples {ns} {tag}] worst err / bound {worst:.3f}")
+        worst = max(worst, err / (8.0 * ref_err + 2e-3 * r64.norm().item() + 1e-9))
+        assert err <= 8.0 * ref_err + 2e-3 * r64.norm().item() + 1e-9, (k, err, ref_err)
+        tot[0] += err ** 2; tot[1] += ref_err ** 2; tot[2] += r64.norm().item() ** 2
+    # ... and over ALL tensors together, where the discrete events average out: 3 x the fp32 yardstick
+    assert tot[0] ** 0.5 <= 3.0 * tot[1] ** 0.5 + 2e-3 * tot[2] ** 0.5, (tot[0] ** 0.5, tot[1] ** 0.5, tot[2] ** 0.5)
+    print(f"[n_samples {ns} {tag}] worst err / bound {worst:.3f}; all tensors: err {tot[0] ** 0.5:.2e}, fp32 yardstick {tot[1] ** 0.5:.2e}, norm {tot[2] ** 0.5:.2e}")
 
 
 @pytest.mark.gpu
