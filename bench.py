@@ -54,6 +54,8 @@ F_DEN = 2 * MAC_DENS                  #               982,528 FLOP per shadow-ra
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0
+# the library's defaults (eonerf_api.hip): the shadow pass' encoding products ride in the input-gradient tail's launch unless switched off
+ENC_PAIR = os.environ.get("EONERF_ENC_PAIR", "1") != "0" and os.environ.get("EONERF_DETERMINISTIC", "0") == "0"
 # HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/README.md)
 TRAFFIC = {}
 try:
@@ -222,8 +224,14 @@ def kernel_model(wl, piped, n_cam, n_sun, elt):
             byts["bwd_pipe_sun"] = (256 + 7 * 256 + 2 * 256) * elt * n_sun
             flop["ig_tail_sun"] = 2.0 * enc_dw * n_sun                            # d enc = W_0^T dY_0 + W_5skip^T dY_5
             byts["ig_tail_sun"] = (2 * 256 * elt + 24) * n_sun
-            flop["wgrad_gemm"] += 2.0 * (MAC_DENS - trunk_dw) * n_sun             # layer 0, skip columns, sigma row of the sun pass
-            byts["wgrad_gemm"] += (2 * 320 + 257) * elt * n_sun
+            if ENC_PAIR:      # (round 6) the same launch also forms dW_0 / dW_5skip of the pass from the tiles it has in LDS (eonerf_enc_pair.hip)
+                flop["ig_tail_sun"] += 2.0 * enc_dw * n_sun
+                byts["ig_tail_sun"] += 64 * elt * n_sun
+                flop["wgrad_gemm"] += 2.0 * (MAC_DENS - trunk_dw - enc_dw) * n_sun    # what is left to the GEMM launch: the sigma row
+                byts["wgrad_gemm"] += 257 * elt * n_sun
+            else:
+                flop["wgrad_gemm"] += 2.0 * (MAC_DENS - trunk_dw) * n_sun             # layer 0, skip columns, sigma row of the sun pass
+                byts["wgrad_gemm"] += (2 * 320 + 257) * elt * n_sun
     else:
         flop["bwd_chain_camera"] = 2.0 * (MAC_BWD - dead) * n_cam
         byts["bwd_chain_camera"] = ((2180 if wl == "rgb" else 2694) * elt + masks * 32) * n_cam

@@ -42,6 +42,7 @@ struct eonerf_ctx {
     int prec;             // cfg.precision: EONERF_FP32 / EONERF_BF16 / EONERF_F16X3 (inference only)
     bool bf16;
     int n_cu;
+    int enc_pair = 1;       // the shadow pass' encoding products and input-gradient tail in one kernel (eonerf_enc_pair.hip; EONERF_ENC_PAIR=0: ig_tail + two GEMM jobs)
     int pipe_xcd = 0;       // XCD-local pipelines of the pipelined backward (EONERF_PIPE_XCD; BwdPipeArgs::xcd_local)
     int stagger = 0;        // wave stagger of the chain kernels (EONERF_STAGGER; MlpFwdArgs::stagger)
     int wgrad_riders = 1;   // EONERF_WGRAD_RIDERS=0: the sigma row and the embedding columns as jobs of their own (A/B switch)
@@ -466,7 +467,7 @@ int launch_planned_wgrad(eonerf_ctx* ctx, const WgradPlan& plan, int p_cap, int*
 int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, const PassBuffers* full, bool transient,
                          const PassBuffers* dens, int p_cap, float* m_bott, int* queue, hipStream_t st, bool full_trunk_done = false,
                          bool dens_trunk_done = false, float* det_partials = nullptr, bool zeroed = false, BottWgradArgs* defer_bott = nullptr,
-                         WgradPlan* plan = nullptr) {
+                         WgradPlan* plan = nullptr, bool dens_enc_done = false) {
     // defer_bott != nullptr: the products that follow from the bottleneck factors are NOT launched here; their arguments are handed back
     // (the render path runs them in one launch with the embedding and ambient-head gradients, eo_launch_step_tail)
     const ParamLayout& pl = ctx->pl;
@@ -499,22 +500,25 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
     };
     // pipelined: the 256 x 256 products of layers 1..7 (and their biases) were accumulated by the layer-pipelined trunk backward;
     // what is left are the two 256 x 64 products against the encoding (layer 0, skip columns of layer 5) and the sigma row
-    auto trunk_jobs = [&](const PassBuffers& b, bool pipelined, bool sigma_job, bool written_late) {
+    auto trunk_jobs = [&](const PassBuffers& b, bool pipelined, bool sigma_job, bool written_late, bool enc_jobs) {
         // (pipelined: dY_0 and dY_5 lie in their slab tiles in unit order -- written once by the stages of layers 1 and 6)
+        // (enc_jobs = false: the two products against the encoding were formed by eo_launch_enc_pair, with the pass' input-gradient tail)
+        if (enc_jobs) {
         add(b, GRD_ROW_Y0, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[0]), 63, dptr(pl.trunk_b[0]), ctx->enc_colmap, 4, 2, 2, 1);
         tab.j[tab.n - 1].a_units = pipelined; late[tab.n - 1] = written_late;
+        }
         for (int l = 1; l < 8; ++l) {
             const int in_ld = l == 5 ? 319 : 256;
             if (!pipelined)
                 add(b, GRD_ROW_Y0 + 256 * l, 256, ACT_ROW_X1 + 256 * (l - 1), 256, dptr(pl.trunk_w[l]), in_ld, dptr(pl.trunk_b[l]), nullptr, 2, 4, 4, 2);
-            if (l == 5)   // skip columns 256..318 <- encoding slots
+            if (l == 5 && enc_jobs)   // skip columns 256..318 <- encoding slots
                 { add(b, GRD_ROW_Y0 + 256 * 5, 256, ACT_ROW_ENC, 64, dptr(pl.trunk_w[5]) + 256, 319, nullptr, ctx->enc_colmap, 4, 2, 2, 1); tab.j[tab.n - 1].a_units = pipelined; late[tab.n - 1] = written_late; }
         }
         if (sigma_job) add(b, GRD_ROW_SIG, 1, ACT_ROW_X1 + 256 * 7, 256, dptr(pl.sig_w), 256, dptr(pl.sig_b), nullptr, 1, 8, 1, 1);
     };
     if (full) {
         const PassBuffers& c = *full;
-        trunk_jobs(c, full_trunk_done, !riders, plan != nullptr);
+        trunk_jobs(c, full_trunk_done, !riders, plan != nullptr, true);
         // bottleneck factors M_a = dA1^T X8 (and M_t = dT1^T X8) + the bias gradients db_A1 (db_T1), finished by eo_launch_bott_wgrad
         // below into THREE weight gradients: the bottleneck layer's and the two head layers' that read the bottleneck output (which is
         // therefore never saved by the forward, nor read back here: see BottWgradArgs)
@@ -545,7 +549,7 @@ int run_weight_gradients(eonerf_ctx* ctx, const float* flat, float* d_flat, cons
             split_at(1, dptr(pl.tbe_w), 128, dptr(pl.tbe_b));
         }
     }
-    if (dens) trunk_jobs(*dens, dens_trunk_done, true, false);
+    if (dens) trunk_jobs(*dens, dens_trunk_done, true, false, !dens_enc_done);
     if (plan) {      // late jobs to the end of the table (stable), the riders' job index follows
         WgradJob ordered[WGRAD_MAX_JOBS];
         int k = 0, aux_job = tab.aux.job;
@@ -658,6 +662,7 @@ int eonerf_create(eonerf_ctx** out, const eonerf_config* cfg) {
     { const char* e = getenv("EONERF_WGRAD_RIDERS"); if (e) ctx->wgrad_riders = atoi(e); }
     { const char* e = getenv("EONERF_STAGGER"); if (e) ctx->stagger = atoi(e); }
     { const char* e = getenv("EONERF_PIPE_XCD"); if (e) ctx->pipe_xcd = atoi(e); }
+    { const char* e = getenv("EONERF_ENC_PAIR"); if (e) ctx->enc_pair = atoi(e); }
     ctx->pl.build(cfg->n_images);
     int rc = upload(ctx->fwd_full, build_fwd_stream(ctx->pl, ctx->prec, true));
     if (!rc) rc = upload(ctx->fwd_dens, build_fwd_stream(ctx->pl, ctx->prec, false));
@@ -985,7 +990,7 @@ int eonerf_generate_rays(const eonerf_rpc* rpc, const double* cols, const double
 // density_only: the pass was a density-only one (render_depth): its gradient flows through the sigma row alone.
 static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat, const float* rays, const int64_t* img_idx, int n_rays, int p_cap,
                            float* d_flat, bool transient, bool ambient, bool first_pipe, const PassBuffers* sun, bool density_only, hipStream_t st,
-                           const unsigned long long* digest = nullptr) {
+                           const unsigned long long* digest = nullptr, bool sun_enc_done = false) {
     const ParamLayout& pl = ctx->pl;
     const int tile = ctx->bf16 ? PBf16::TILE : PF32::TILE;
     const int grid = std::min(ctx->n_cu, p_cap / tile);
@@ -1023,7 +1028,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
         // the GEMM's job table first: the pipelined launch hands its ready items to streaming workgroups (PipeStreamArgs), the GEMM launch
         // behind it takes the rest of the SAME queue (zeroed with the backward's sync block)
         WgradPlan plan;
-        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, sun, p_cap, w.m_bott, w.queue, st, true, sun != nullptr, nullptr, true, &bott, &plan);
+        const int rcw = run_weight_gradients(ctx, flat, d_flat, &w.cam, transient, sun, p_cap, w.m_bott, w.queue, st, true, sun != nullptr, nullptr, true, &bott, &plan, sun_enc_done);
         if (rcw) return rcw;
         const int rcp = run_bwd_pipe(ctx, w, w.cam, p_cap, d_flat, EONERF_PROF_BWD_PIPE_CAMERA, st, 1, first_pipe, nullptr, &plan);
         if (rcp) return rcp;
@@ -1038,7 +1043,7 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
         const PassBuffers* full = density_only ? nullptr : &w.cam;
         const PassBuffers* dens = density_only ? &w.cam : sun;
         const int rcw = run_weight_gradients(ctx, flat, d_flat, full, transient, dens, p_cap, w.m_bott, w.queue, st, pipe, pipe && dens, w.det.wgrad_part, pipe,
-                                             (full && !ctx->deterministic) ? &bott : nullptr);
+                                             (full && !ctx->deterministic) ? &bott : nullptr, nullptr, sun_enc_done && !density_only);
         if (rcw) return rcw;
     }
     if (density_only) return EONERF_OK;
@@ -1381,7 +1386,7 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
     memset(&cb, 0, sizeof(cb));
     cb.n_samples = ctx->n_samples;
     cb.rays = rays; cb.p_pad = p_cap; cb.n_rays = n_rays; cb.ray_rec = w.ray_rec; cb.g_ray = w.g_ray;
-    bool ambient_done = false;
+    bool ambient_done = false, sun_enc_done = false;
 
     // ---- shadow pass backwards: d geo -> d sigma_sun -> (chain, input grad) -> d pos -> d depth -----------
     if (shadows) {
@@ -1408,10 +1413,21 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
             ambient_done = pipe_spare_cus(ctx) > 0;
             const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, EONERF_PROF_BWD_PIPE_SUN, st, 0, !prezeroed, ambient_done ? &ag : nullptr);
             if (rcp) return rcp;
+            if (ctx->enc_pair && !ctx->deterministic && !w.det.wgrad_part) {
+                // ONE pass over the dY_0 / dY_5 tiles the launch above left: d sigma / d position (needed now: it flows into the camera pass)
+                // and the pass' two weight-gradient products against the encoding (otherwise two jobs of the GEMM launch at the end)
+                EncPairArgs ea;
+                ea.n_pts = w.sun.n_pts; ea.p_pad = p_cap; ea.grd = w.sun.grd; ea.act = w.sun.act; ea.wt = ctx->ig_tail_wt.data;
+                ea.px = w.sun.px; ea.py = w.sun.py; ea.pz = w.sun.pz; ea.g_pos = w.sun.g_pos;
+                ea.dw0 = dptr(pl.trunk_w[0]); ea.db0 = dptr(pl.trunk_b[0]); ea.dw5s = dptr(pl.trunk_w[5]) + 256; ea.col_map = ctx->enc_colmap;
+                { ProfScope ps(ctx, EONERF_PROF_IG_TAIL_SUN, st); HIP_TRY(eo_launch_enc_pair(ea, ctx->n_cu, st)); }
+                sun_enc_done = true;
+            } else {
             IgTailArgs ta;
             ta.n_pts = w.sun.n_pts; ta.p_pad = p_cap; ta.grd = w.sun.grd; ta.wt = ctx->ig_tail_wt.data;
             ta.px = w.sun.px; ta.py = w.sun.py; ta.pz = w.sun.pz; ta.g_pos = w.sun.g_pos;
             { ProfScope ps(ctx, EONERF_PROF_IG_TAIL_SUN, st); HIP_TRY(eo_launch_ig_tail(ta, ctx->n_cu, st)); }
+            }
         } else {
             ProfScope ps(ctx, EONERF_PROF_BWD_CHAIN_SUN, st);
             HIP_TRY(eo_launch_mlp_bwd(ms, ctx->bf16, false, true, false, grid, st));
@@ -1419,7 +1435,7 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
     }
 
     const int rcc = camera_backward(ctx, w, flat, rays, img_idx, n_rays, p_cap, d_flat, shadows || !(flags & EONERF_F_RGB_LOSS), shadows && !ambient_done, !shadows && !prezeroed,
-                                    shadows ? &w.sun : nullptr, false, st, chk ? digest : nullptr);
+                                    shadows ? &w.sun : nullptr, false, st, chk ? digest : nullptr, sun_enc_done);
     // (chain + GEMM path: the trunk's gradients come out of the GEMM launch -- the early block is final where everything is)
     if (!rcc && ctx->exch_event && !ctx->exch_recorded) HIP_TRY(hipEventRecord(ctx->exch_event, st));
     return rcc;

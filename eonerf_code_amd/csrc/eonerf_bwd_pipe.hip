@@ -87,6 +87,11 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 #ifndef EO_PIPE_XM_AT      // (bit 1: behind which MFMA of the dX chain the ReLU' reads are issued)
 #define EO_PIPE_XM_AT 14
 #endif
+// EO_PIPE_DMA03 = 1 (round 6 experiment): the LDS-DMA pieces of a step are all issued by waves 0-3 (eight each: their own and their SIMD
+// partner's), waves 4-7 -- the critical path of a step (profiles/r06_pipe_stamps_ablation.txt) -- issue none.
+#ifndef EO_PIPE_DMA03
+#define EO_PIPE_DMA03 0
+#endif
 #ifndef EO_PIPE_STAMPS      // 1: the per-phase cycle stamps of scripts/pipe_stamps.py are compiled in (scripts/stamp.sh builds that library)
 #define EO_PIPE_STAMPS 0
 #endif
@@ -109,7 +114,7 @@ EO_DEV int wg_swz16(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 16
 // second order (waves 4..7): N_DMA pieces .. 2 payload stores
 constexpr int NST = 2;
 template <bool CTRL, bool ORDB> struct Cnt {
-    static constexpr int ND = N_DMA;
+    static constexpr int ND = EO_PIPE_DMA03 ? (ORDB ? 0 : 2 * N_DMA) : N_DMA;      // pieces THIS wave issues per step
     static constexpr int C = (CTRL ? 4 : 0) + NST + ND;
     // top of step s: the stores of step s-2 are complete (=> publishable), hence also the polls of step s-2 and the DMA of step s.
     // First order: the pieces of step s-2 and all of step s-1 are younger than those stores; second order: only step s-1
@@ -187,10 +192,11 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     const uint8_t* const in_blk = S.in_lin;
 
     // per-lane DMA source offsets of the X image: wave w stages rows 32w..32w+31, 16 rows per piece, chunks XOR-swizzled
-    int x_voff[2];
+    constexpr int NDW = Cnt<CTRL, ORDB>::ND;      // (EO_PIPE_DMA03: waves 0-3 also stage the rows / units of waves 4-7)
+    int x_voff[NDW > 4 ? 4 : 2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 32 * wave + 16 * j + (lane >> 2);
+    for (int j = 0; j < (NDW > 4 ? 4 : 2); ++j) {
+        const int row = 32 * (wave + 4 * (j >> 1)) + 16 * (j & 1) + (lane >> 2);
         x_voff[j] = row * SEG_B + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
     }
     // DMA of this pipeline's k-th step (clamped by the caller) into LDS slot k & 3: N_DMA pieces of 1 KiB per wave, issued in a
@@ -220,8 +226,10 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         d.so_x = (uint32_t)k * lin_stride;
         return d;
     };
-    auto dma_piece = [&](const Dma& d, int i) {      // i: compile-time constant at every call site
+    auto dma_piece = [&](const Dma& d, int i4) {      // i4: compile-time constant at every call site; pieces 4..7: the partner wave's share
         if (!d.on) return;
+        const int i = i4 & 3, vwave = wave + 4 * (i4 >> 2), v_dy = lane * 16 + (2 * vwave) * 1024, wave = vwave;
+        const int* x_voff_ = x_voff + 2 * (i4 >> 2);
         if (i < 2) {
             // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
             if (EO_XCD_NT && S.has_in && S.local)      // (experiment build: streaming instead of sc1 loads on an intra-XCD edge)
@@ -235,13 +243,13 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                                                          v_dy + i * 1024, d.so_d, 0, AUX_NT);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(d.slot + IMG_B + (32 * wave + 16 * (i - 2)) * SEG_B), 16,
-                                                     x_voff[i - 2], d.so_x, 0, AUX_NT);
+                                                     x_voff_[i - 2], d.so_x, 0, AUX_NT);
         }
     };
     auto issue = [&](int k) {      // all pieces in one block (prologue)
         const Dma d = dma_prep(k);
 #pragma unroll
-        for (int i = 0; i < N_DMA; ++i) dma_piece(d, i);
+        for (int i = 0; i < NDW; ++i) dma_piece(d, i);
     };
 
     // ---- per-lane LDS read offsets ----
@@ -311,7 +319,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     for (int d = 0; d < DEPTH; ++d) issue(d < n_k ? d : n_k - 1);
     // step 0 only: nothing but the other two prologue steps is younger than its pieces (the loop's counted wait assumes the
     // steady state, where two whole steps of stores and pieces are)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * N_DMA) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * NDW) : "memory");
 
     if (CTRL && lane == 0 && S.done) __hip_atomic_store(S.done + 1, n_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if EO_PABL      // (diagnostic variants: a shorter body must not be unrolled into a different register budget)
@@ -519,7 +527,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         auto issue_block = [&]() {
 #if !EO_PIPE_SPREAD
 #pragma unroll
-            for (int i = 0; i < N_DMA; ++i) dma_piece(dma, i);
+            for (int i = 0; i < NDW; ++i) dma_piece(dma, i);
 #endif
         };
         if (!ORDB) {

@@ -166,6 +166,19 @@ struct IgTailArgs {
     float* g_pos;             // [3][p_pad]
 };
 hipError_t eo_launch_ig_tail(const IgTailArgs& a, int n_wg, hipStream_t st);
+// the same tail AND the shadow pass' two weight-gradient products against the encoding in one pass over dY_0 / dY_5 (eonerf_enc_pair.hip)
+struct EncPairArgs {
+    const int* n_pts; int p_pad;
+    const void* grd;          // gradient slab: the dY_0 / dY_5 tiles in unit order (written by the pipelined launch)
+    const void* act;          // activation slab: the 64 encoding rows of the pass
+    const uint8_t* wt;        // as IgTailArgs::wt
+    const float *px, *py, *pz;
+    float* g_pos;             // [3][p_pad]
+    float *dw0, *db0;         // layer 0: [256][63] and [256] inside the flat gradient buffer (accumulated)
+    float* dw5s;              // layer 5: column 256 of [256][319] (its 63 skip columns)
+    const int* col_map;       // [64] encoding slot -> reference column, -1 = padding slot
+};
+hipError_t eo_launch_enc_pair(const EncPairArgs& a, int n_wg, hipStream_t st);
 size_t eo_bwd_pipe_lds_bytes();
 bool eo_bwd_pipe_fits_a_cu();
 

@@ -29,6 +29,25 @@ def run(sel):
         rel.append(((a - b).norm() / (b.norm() + 1e-30)).item())
     o = torch.cat([res[k] for k in tn.KEYS], dim=1).cpu().double()
     return rel, (o - out64.detach()).abs().max().item(), o[:, 14:16].tolist(), float(loss), float(l64)
+if len(sys.argv) > 2:      # all tensors of the named rays
+    for i in [int(a) for a in sys.argv[2:]]:
+        f = tn._field(sd, int(g["n_img"]), "fp32")
+        f.zero_grad()
+        sel = slice(i, i + 1)
+        res, n = render_image(f, None, define_satrays_from_tensors(rays[sel].cuda(), ts[sel].cuda()), None, None, epoch_idx=epoch, chunk=4096, render_step_size=step, noise=[(u_cam[sel], None, u_sun[sel])])
+        loss = ((res["rgb"] - rgbs[sel].cuda()) ** 2 / (2 * res["beta"] ** 2)).mean() + (3 + torch.log(res["beta"]).mean()) / 2
+        loss.backward()
+        sd64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        orc.train_step(sd64, rays[sel].double(), ts[sel], rgbs[sel].double(), u_cam[sel].double(), u_sun[sel].double(), epoch, step)
+        sd32 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        orc.train_step(sd32, rays[sel], ts[sel], rgbs[sel], u_cam[sel], u_sun[sel], epoch, step)
+        print("ray", i, "out", [round(x, 5) for x in torch.cat([res[k] for k in tn.KEYS], dim=1)[0].tolist()])
+        for nm, p_ in f.named_parameters():
+            b = sd64[nm].grad
+            if b is None or b.norm() == 0: continue
+            a = p_.grad.cpu().double(); o = sd32[nm].grad.double()
+            print(f"   {nm:48s} HIP rel err {((a - b).norm() / b.norm()).item():.1e}   oracle fp32 rel err {((o - b).norm() / b.norm()).item():.1e}   norm {b.norm().item():.2e}")
+    sys.exit(0)
 print("all rays:", run(slice(0, 32))[:2])
 for i in range(32):
     rel, fe, cnt, l, l64 = run(slice(i, i + 1))

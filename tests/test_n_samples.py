@@ -189,6 +189,27 @@ def test_hip_backward_fp32_as_exact_as_the_reference_g10(tag, epoch, ns):
     # another summation order -- lands at).  The yardstick is the larger of the two fp32 errors.
     sd32 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     orc.train_step(sd32, rays, ts, rgbs, u_cam, u_sun, epoch, step)
+    # ... and the CONDITIONING of the gradient itself.  With the shadow pass on, the gradient is not a smooth function of the rendered depth:
+    # d geo / d depth runs through the trunk's input gradient at the shadow ray's samples -- piecewise constant between ReLU boundaries that
+    # the 2^9-frequency encodings put ~1e-6 apart along the ray (round 6, ray 26 of the 96-sample fixture, oracle in fp64: d geo / d depth
+    # 0.986 at the rendered depth, 0.950 at depth - 1e-7, 0.659 at depth + 1e-6; profiles/r06_fp32_backward_fixture_sensitivity.txt).  fp32
+    # resolves a depth of 0.5 to 6e-8, and two correct fp32 forward passes differ by that much.  So the fp64 gradient is also evaluated with
+    # the shadow rays' origins moved by +- 1e-7 along the view direction: what it moves by is the resolution of the QUESTION, and part of
+    # the yardstick.
+    cond = {}
+    if epoch >= 2:
+        orig_cgs = orc.compute_geometric_shadows
+        for eps in (1e-7, -1e-7):
+            orc.compute_geometric_shadows = lambda fld, r, depth, u, st_, _e=eps: orig_cgs(fld, r, depth + _e, u, st_)
+            try:
+                sde = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+                orc.train_step(sde, rays.double(), ts, rgbs.double(), u_cam.double(), u_sun.double(), epoch, step)
+            finally:
+                orc.compute_geometric_shadows = orig_cgs
+            for k_, v_ in sde.items():
+                if v_.is_floating_point() and v_.grad is not None and sd64[k_].grad is not None:
+                    d_ = (compact_grad(v_.grad)[2:] - compact_grad(sd64[k_].grad)[2:]).norm().item()
+                    cond[k_] = max(cond.get(k_, 0.0), d_)
     params = dict(f.named_parameters())
     worst, tot = 0.0, [0.0, 0.0, 0.0]
     for k, v in g.items():
@@ -202,14 +223,11 @@ def test_hip_backward_fp32_as_exact_as_the_reference_g10(tag, epoch, ns):
         r64 = compact_grad(g64 if g64 is not None else torch.zeros_like(p, device="cpu"))[2:]
         g32 = sd32[name].grad
         o32 = compact_grad(g32 if g32 is not None else torch.zeros_like(p, device="cpu"))[2:]
-        ref_err, err = max((ref - r64).norm().item(), (o32 - r64).norm().item()), (got - r64).norm().item()
-        # (per tensor: factor 8 on the larger of two fp32 evaluations of the reference graph; 1.5 on the one golden at n_samples = 128.  With 32 rays the
-        #  fp32 error of a tensor is a handful of discrete events -- a ReLU or a clip that falls on the other side for one sample -- and
-        #  varies 4 x from tensor to tensor and from one evaluation order to the next: profiles/r06_fp32_backward_fixture_sensitivity.txt
-        #  renders every fixture's rays at every size, HIP against the oracle's fp32 run: err / (2 x oracle error + 2e-3 norm) between 0.11
-        #  and 2.07, the largest values at 128 samples, none of it following the step size)
-        worst = max(worst, err / (8.0 * ref_err + 2e-3 * r64.norm().item() + 1e-9))
-        assert err <= 8.0 * ref_err + 2e-3 * r64.norm().item() + 1e-9, (k, err, ref_err)
+        ref_err, err = max((ref - r64).norm().item(), (o32 - r64).norm().item(), cond.get(name, 0.0)), (got - r64).norm().item()
+        # (per tensor: factor 4 on the yardstick = the largest of {reference's fp32 error, oracle's fp32 error, what +- 1e-7 of depth moves};
+        #  1.5 on the one golden at n_samples = 128)
+        worst = max(worst, err / (4.0 * ref_err + 2e-3 * r64.norm().item() + 1e-9))
+        assert err <= 4.0 * ref_err + 2e-3 * r64.norm().item() + 1e-9, (k, err, ref_err)
         tot[0] += err ** 2; tot[1] += ref_err ** 2; tot[2] += r64.norm().item() ** 2
     # ... and over ALL tensors together, where the discrete events average out: 3 x the fp32 yardstick
     assert tot[0] ** 0.5 <= 3.0 * tot[1] ** 0.5 + 2e-3 * tot[2] ** 0.5, (tot[0] ** 0.5, tot[1] ** 0.5, tot[2] ** 0.5)
