@@ -96,6 +96,7 @@ CarveCfg carve_cfg(const eonerf_ctx* ctx) {
     CarveCfg c;
     c.bf16 = ctx->bf16; c.pipe = ctx->pipe; c.deterministic = ctx->deterministic; c.pipe_partials = ctx->pipe_partials;
     c.n_pipes = ctx->n_pipes; c.n_samples = ctx->n_samples;
+    c.enc_part_wgs = (ctx->enc_pair && ctx->pipe && !ctx->deterministic) ? ctx->n_cu : 0;
     return c;
 }
 
@@ -1056,7 +1057,9 @@ static int camera_backward(eonerf_ctx* ctx, const RenderWs& w, const float* flat
         AmbientBwdArgs ag;
         ag.w = ambient_w(ctx, flat); ag.rays = rays; ag.ray_rec = w.ray_rec; ag.g_ray = w.g_ray; ag.amb_save = w.amb_save; ag.n_rays = n_rays;
         ag.d_w1 = dptr(pl.am1_w); ag.d_b1 = dptr(pl.am1_b); ag.d_w2 = dptr(pl.am2_w); ag.d_b2 = dptr(pl.am2_b);
-        return (int)eo_launch_step_tail(&bott, transient ? &eg : nullptr, ambient ? &ag : nullptr, st);
+        EncPartReduceArgs er;
+        er.part = w.enc_part; er.n_wg = ctx->n_cu; er.dw0 = dptr(pl.trunk_w[0]); er.db0 = dptr(pl.trunk_b[0]); er.dw5s = dptr(pl.trunk_w[5]) + 256; er.col_map = ctx->enc_colmap;
+        return (int)eo_launch_step_tail(&bott, transient ? &eg : nullptr, ambient ? &ag : nullptr, st, sun_enc_done ? &er : nullptr);
     }
 
     // ---- embeddings and the per-ray ambient head -----------------------------------------------------------
@@ -1413,13 +1416,13 @@ static int render_backward_impl(eonerf_ctx* ctx, const float* flat, const float*
             ambient_done = pipe_spare_cus(ctx) > 0;
             const int rcp = run_bwd_pipe(ctx, w, w.sun, p_cap, d_flat, EONERF_PROF_BWD_PIPE_SUN, st, 0, !prezeroed, ambient_done ? &ag : nullptr);
             if (rcp) return rcp;
-            if (ctx->enc_pair && !ctx->deterministic && !w.det.wgrad_part) {
+            if (w.enc_part) {
                 // ONE pass over the dY_0 / dY_5 tiles the launch above left: d sigma / d position (needed now: it flows into the camera pass)
                 // and the pass' two weight-gradient products against the encoding (otherwise two jobs of the GEMM launch at the end)
                 EncPairArgs ea;
                 ea.n_pts = w.sun.n_pts; ea.p_pad = p_cap; ea.grd = w.sun.grd; ea.act = w.sun.act; ea.wt = ctx->ig_tail_wt.data;
                 ea.px = w.sun.px; ea.py = w.sun.py; ea.pz = w.sun.pz; ea.g_pos = w.sun.g_pos;
-                ea.dw0 = dptr(pl.trunk_w[0]); ea.db0 = dptr(pl.trunk_b[0]); ea.dw5s = dptr(pl.trunk_w[5]) + 256; ea.col_map = ctx->enc_colmap;
+                ea.part = w.enc_part;
                 { ProfScope ps(ctx, EONERF_PROF_IG_TAIL_SUN, st); HIP_TRY(eo_launch_enc_pair(ea, ctx->n_cu, st)); }
                 sun_enc_done = true;
             } else {

@@ -14,6 +14,7 @@ constexpr int BOTT_SCRATCH_F = 2 * 128 * 256 + 256;       // bottleneck factors 
 struct CarveCfg {          // what the layout depends on besides (n_rays, flags): see eonerf_ctx
     bool bf16 = true, pipe = false, deterministic = false, pipe_partials = false;
     int n_pipes = 0;
+    int enc_part_wgs = 0;  // > 0: workgroups of eonerf_enc_pair.hip, each with a partial of the shadow pass' encoding products (0: ig_tail + GEMM jobs)
     int n_samples = 128;   // int(2 / render_step_size) of the calls this layout serves (eonerf_set_n_samples)
 };
 
@@ -60,6 +61,7 @@ struct RenderWs {
     float* ray_rec; float* g_ray; float* amb_save;
     float* m_bott;        // [2][128][256] fp32: dA1^T X8 and dT1^T X8 (the bottleneck factors), then [256] db_A1 | db_T1 of this call
     int* queue;           // work-item counter of the weight-gradient GEMM (behind them)
+    float* enc_part;      // [enc_part_wgs][ENC_PART_F] partials of eonerf_enc_pair.hip (training with the shadow pass on the pipelined path), or nullptr
     PassBuffers cam, sun;
     size_t bytes;
 };
@@ -131,6 +133,7 @@ inline RenderWs carve_render(const CarveCfg& cfg, void* base, int n_rays, int fl
         w.det.rad_rays = c.take<float>((size_t)n_rays * 6);
         w.det.emb_rays = c.take<float>((size_t)n_rays * 4);
     }
+    w.enc_part = (train && shadows && !od && ctx->pipe && ctx->enc_part_wgs > 0) ? c.take<float>((size_t)ctx->enc_part_wgs * ENC_PART_F) : nullptr;
     // (a density-only training pass -- render_depth under autograd -- may end in the chain kernel's input-gradient variant: room for d position)
     carve_pass(c, w.cam, n_rays, p_cap, !od, train, train && od, ab);
     if (shadows && !od) carve_pass(c, w.sun, n_rays, p_cap, false, train, true, ab); else memset(&w.sun, 0, sizeof(w.sun));

@@ -17,10 +17,17 @@
 //              dW_s (128 accumulator registers, stationary for the launch): A fragments = transposed reads of the unit-order tile (as
 //              eonerf_wgrad.hip's a_units jobs), B fragments = the encoding rows (swizzled like the GEMM's operand tiles): 16 MFMAs per step;
 //              the bias gradient db_0 from the A fragments (as eonerf_bwd_pipe.hip).
-//   End of the launch: fp32 atomic flush of the 2 x 256 x 64 accumulators (encoding slot -> reference column through col_map).
+//   End of the launch: every workgroup stores its 2 x 256 x 64 accumulators as a partial (EncPairArgs::part); k_step_tail sums the partials into
+//   the gradient buffer at the end of the backward (an atomic flush of 256 workgroups into the same 64 + 80 KB took longer than the streaming).
 // One barrier per step.  Not used in deterministic mode (EONERF_DETERMINISTIC: the fixed-order reductions stay with ig_tail + GEMM jobs).
 #include "eonerf_common.h"
 #include "eonerf_kernels.h"
+
+// Diagnostic builds only (scripts/enc_pair_ablate.sh): EO_EP_ABL bit 0 (the atomic flush of the first version) is gone, bit 1 the d enc waves' work (MFMAs + encoder
+// derivative), bit 2 the dW waves' MFMAs and fragment reads, bit 3 the LDS-DMA refill behind the prologue.  Results are WRONG with any bit set.
+#ifndef EO_EP_ABL
+#define EO_EP_ABL 0
+#endif
 
 namespace {
 
@@ -68,6 +75,7 @@ EO_DEV void enc_waves(const EncPairArgs& a, uint8_t* smem, int lane, int wave, i
         const int slot = (t - t0) & (NS - 1), par = (t - t0) & 1;
         asm volatile("s_barrier" ::: "memory");
         if (wave == 0 && t > t0) finish(t - 1, par ^ 1);
+        if (EO_EP_ABL & 2) continue;
         // ---- d enc partial of (source s_src, m-tile mt): 16 MFMAs over the tile's 16 B units ----
         const uint8_t* bp = smem + slot * SLOT_B + s_src * IMG + lane * 16;
         f32x16 acc = zero_acc();
@@ -151,9 +159,11 @@ EO_DEV void dw_waves(const EncPairArgs& a, uint8_t* smem, int lane, int wave, in
         const int slot = (t - t0) & (NS - 1);
         // this wave's share of step t has landed once at most DEPTH - 1 younger steps are outstanding; the barrier publishes every wave's
         // share and retires all reads of the slot refilled next
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_DMA * (DEPTH - 1)) : "memory");
-        issue(t + DEPTH < t1 ? t + DEPTH : t1 - 1, (slot + DEPTH) & (NS - 1));
+        if (EO_EP_ABL & 8) asm volatile("s_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_DMA * (DEPTH - 1)) : "memory");
+        if (!(EO_EP_ABL & 8)) issue(t + DEPTH < t1 ? t + DEPTH : t1 - 1, (slot + DEPTH) & (NS - 1));
         const uint8_t* T = smem + slot * SLOT_B;
+        if (EO_EP_ABL & 4) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             // (inline asm: for the intrinsic the wait-count pass assumes aliasing with the LDS-DMA in flight and drains it)
@@ -185,23 +195,19 @@ EO_DEV void dw_waves(const EncPairArgs& a, uint8_t* smem, int lane, int wave, in
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the clamped tail prefetches)
-    // ---- flush: fp32 atomics, 32 consecutive slots per half-wave instruction; slot -> reference column (or none: the padding slot) ----
-    float* dst = s_src == 0 ? a.dw0 : a.dw5s;
-    const int ld = s_src == 0 ? 63 : 319;
+    // ---- this workgroup's partial: [source][row][slot], one 128-B segment per half-wave instruction; db_0 behind it ----
+    float* part = a.part + (size_t)blockIdx.x * ENC_PART_F + (size_t)s_src * 256 * 64;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cm = a.col_map[32 * j + c];
-        if (cm < 0) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) atomicAdd(dst + (size_t)((4 * mhalf + i) * 32 + acc_row(g, h)) * ld + cm, dw[i][j][g]);
-    }
+            for (int g = 0; g < 16; ++g) part[((4 * mhalf + i) * 32 + acc_row(g, h)) * 64 + 32 * j + c] = dw[i][j][g];
     if (s_src == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float s = dbv[i] + __shfl_xor(dbv[i], 32, 64);
-            if (h == 0) atomicAdd(a.db0 + (4 * mhalf + i) * 32 + c, s);
+            const float sum = dbv[i] + __shfl_xor(dbv[i], 32, 64);
+            if (h == 0) a.part[(size_t)blockIdx.x * ENC_PART_F + 2 * 256 * 64 + (4 * mhalf + i) * 32 + c] = sum;
         }
     }
 }
@@ -212,7 +218,10 @@ __global__ __launch_bounds__(NT) void k_enc_pair(EncPairArgs a) {
     const int n_pts = *a.n_pts;
     const int n_tiles = (n_pts + 255) / 256 * 8;      // whole 256-sample tiles, as the pipelined launch wrote them (dead samples: zero gradients)
     const int t0 = (int)((long long)blockIdx.x * n_tiles / gridDim.x), t1 = (int)((long long)(blockIdx.x + 1) * n_tiles / gridDim.x);
-    if (t0 >= t1) return;      // (uniform per workgroup)
+    if (t0 >= t1) {      // (uniform per workgroup; fewer tiles than workgroups) an all-zero partial
+        for (int i = threadIdx.x; i < ENC_PART_F; i += NT) a.part[(size_t)blockIdx.x * ENC_PART_F + i] = 0.f;
+        return;
+    }
     if (wave < 4) enc_waves(a, smem, lane, wave, t0, t1, n_pts);
     else dw_waves(a, smem, lane, wave, t0, t1);
 }

@@ -174,9 +174,10 @@ struct EncPairArgs {
     const uint8_t* wt;        // as IgTailArgs::wt
     const float *px, *py, *pz;
     float* g_pos;             // [3][p_pad]
-    float *dw0, *db0;         // layer 0: [256][63] and [256] inside the flat gradient buffer (accumulated)
-    float* dw5s;              // layer 5: column 256 of [256][319] (its 63 skip columns)
-    const int* col_map;       // [64] encoding slot -> reference column, -1 = padding slot
+    // The weight-gradient accumulators leave the launch as PARTIALS, one per workgroup (plain 128-B-segment stores): 256 workgroups adding
+    // 2 x 256 x 64 floats each into the same 64 + 80 KB of the gradient buffer with atomics took 0.116 ms of a 0.21-ms launch (the memory-side
+    // atomic units serialise on so small a footprint, scripts/enc_pair_ablate.sh); k_step_tail sums them at the end of the backward.
+    float* part;              // [workgroup][ENC_PART_F]: [source 2][row 256][slot 64] dW | [256] db_0
 };
 hipError_t eo_launch_enc_pair(const EncPairArgs& a, int n_wg, hipStream_t st);
 size_t eo_bwd_pipe_lds_bytes();

@@ -159,7 +159,15 @@ struct RenderingOutArgs { const float* ray_rec; int n_rays; float *albedo, *dept
 // gradients of EONerfMLP.rendering's per-ray outputs (any may be null = zero) -> gradient of the ray record
 struct RenderingOutBwdArgs { const float* ray_rec; int n_rays; const float *g_albedo, *g_depth, *g_beta, *g_ts, *g_ambient; float* g_ray; };
 // bottleneck-factor products | embedding gradient | ambient-head backward in one launch (any of the three may be null)
-hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb, const AmbientBwdArgs* amb, hipStream_t st);
+constexpr int ENC_PART_F = 2 * 256 * 64 + 256;
+// sum over the workgroups' partials -> accumulated into the flat gradient buffer (a role of k_step_tail)
+struct EncPartReduceArgs {
+    const float* part; int n_wg;
+    float *dw0, *db0;         // layer 0: [256][63] and [256] inside the flat gradient buffer
+    float* dw5s;              // layer 5: column 256 of [256][319] (its 63 skip columns)
+    const int* col_map;       // [64] encoding slot -> reference column, -1 = padding slot
+};
+hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb, const AmbientBwdArgs* amb, hipStream_t st, const EncPartReduceArgs* enc = nullptr);
 hipError_t eo_launch_rendering_out_bwd(const RenderingOutBwdArgs& a, hipStream_t st);
 
 hipError_t eo_launch_sampler(const SampleArgs& a, hipStream_t st, bool counted = false);      // counted: cnt_first is filled already (CompositeArgs::count_sun)

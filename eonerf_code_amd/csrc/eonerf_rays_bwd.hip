@@ -465,13 +465,33 @@ __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
 //      sum (~70 us of a 3.4 ms step), in one grid the longest.  Blocks of 512 threads: [0, n_amb) ambient head; then pairs of 256-thread
 //      virtual blocks of the bottleneck products (a pair never straddles the kernel's two branches: 256 is even) and of the embedding
 //      gradient.  n_bott / n_emb / n_amb = 0: that part is absent. ----
-struct StepTailArgs { BottWgradArgs bott; EmbGradArgs emb; AmbientBwdArgs amb; int n_amb, n_bott, n_emb; };
+struct StepTailArgs { BottWgradArgs bott; EmbGradArgs emb; AmbientBwdArgs amb; EncPartReduceArgs enc; int n_amb, n_bott, n_emb, n_enc; };
+// the shadow pass' encoding products (eonerf_enc_pair.hip): sum of the workgroups' partials, one thread per element -> the gradient buffer
+// (every other writer of these elements -- the GEMM launch's camera jobs -- has finished: plain read-modify-write)
+EO_DEV void enc_part_reduce_body(const EncPartReduceArgs& a, int vblk, int tid) {
+    const int e = vblk * 512 + tid;      // element of [source 2][row 256][slot 64] | [256] bias sums
+    if (e >= ENC_PART_F) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 4 <= a.n_wg; w += 4) {
+        s0 += a.part[(size_t)w * ENC_PART_F + e]; s1 += a.part[(size_t)(w + 1) * ENC_PART_F + e];
+        s2 += a.part[(size_t)(w + 2) * ENC_PART_F + e]; s3 += a.part[(size_t)(w + 3) * ENC_PART_F + e];
+    }
+    for (; w < a.n_wg; ++w) s0 += a.part[(size_t)w * ENC_PART_F + e];
+    const float sum = (s0 + s1) + (s2 + s3);
+    if (e >= 2 * 256 * 64) { a.db0[e - 2 * 256 * 64] += sum; return; }
+    const int src = e >> 14, row = (e >> 6) & 255, cm = a.col_map[e & 63];
+    if (cm < 0) return;
+    if (src == 0) a.dw0[row * 63 + cm] += sum; else a.dw5s[row * 319 + cm] += sum;
+}
 __global__ __launch_bounds__(512) void k_step_tail(StepTailArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[AMB_LDS_F];
     static_assert(2 * BOTT_LDS_F <= AMB_LDS_F, "two virtual blocks of the bottleneck products share the ambient staging area");
     int blk = blockIdx.x;
     if (blk < a.n_amb) { ambient_bwd_body(a.amb, blk, a.n_amb, lds); return; }
     blk -= a.n_amb;
+    if (blk < a.n_enc) { enc_part_reduce_body(a.enc, blk, threadIdx.x); return; }
+    blk -= a.n_enc;
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
     if (blk < a.n_bott / 2) {
         float* base = lds + half * BOTT_LDS_F;
@@ -612,7 +632,7 @@ hipError_t eo_launch_ambient_bwd(const AmbientBwdArgs& a, hipStream_t st, bool d
     hipLaunchKernelGGL(k_ambient_bwd, dim3(want < blocks ? want : blocks), dim3(128 * AMB_STREAMS), 0, st, a);
     return hipGetLastError();
 }
-hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb, const AmbientBwdArgs* amb, hipStream_t st) {
+hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb, const AmbientBwdArgs* amb, hipStream_t st, const EncPartReduceArgs* enc) {
     StepTailArgs a;
     memset(&a, 0, sizeof(a));
     if (bott) { a.bott = *bott; a.n_bott = 256 + 128 + (bott->w_t1 ? 128 : 0); }
@@ -626,7 +646,8 @@ hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb
         const int want = (amb->n_rays + AMB_BATCH - 1) / AMB_BATCH;
         a.n_amb = want < 32 ? want : 32;                                      // (block count: see eo_launch_ambient_bwd)
     }
-    const int grid = a.n_amb + a.n_bott / 2 + (a.n_emb + 1) / 2;
+    if (enc) { a.enc = *enc; a.n_enc = (ENC_PART_F + 511) / 512; }
+    const int grid = a.n_amb + a.n_enc + a.n_bott / 2 + (a.n_emb + 1) / 2;
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(k_step_tail, dim3(grid), dim3(512), 0, st, a);
     return hipGetLastError();

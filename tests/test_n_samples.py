@@ -185,7 +185,7 @@ def test_hip_backward_fp32_as_exact_as_the_reference_g10(tag, epoch, ns):
     # ... and a SECOND fp32 evaluation of the reference graph (the oracle in fp32).  The golden's fp32 error against fp64 is ONE draw of a
     # wide distribution: on these fixtures (closed-form filler weights, the 2^9-frequency encodings in the shadow pass' input gradient) two
     # fp32 evaluation orders of the same graph differ from fp64 by anything from 1e-5 to 2e-1 of a tensor's norm (round 6,
-    # scripts/dbg_ns3.py: the reference's own run at 96 samples happened to land at 2e-3 of what the oracle's fp32 run -- same graph,
+    # scripts/fixture_sizes.py: the reference's own run at 96 samples happened to land at 2e-3 of what the oracle's fp32 run -- same graph,
     # another summation order -- lands at).  The yardstick is the larger of the two fp32 errors.
     sd32 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     orc.train_step(sd32, rays, ts, rgbs, u_cam, u_sun, epoch, step)
