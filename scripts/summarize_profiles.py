@@ -16,7 +16,7 @@ DST = os.path.join(REPO, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else RT + "_a"
 SHORT = {"k_mlp_fwd<PBf16, true, 2": "fwd_chain_camera", "k_mlp_fwd<PBf16, true, 1": "fwd_chain_camera", "k_mlp_fwd<PBf16, false, 1": "fwd_chain_sun",
          "k_mlp_bwd<PBf16, true, false, false,": "bwd_chain_camera", "k_mlp_bwd<PBf16, true, false, true,": "bwd_chain_camera",
-         "k_mlp_bwd<PBf16, false, true, false,": "bwd_chain_sun", "k_bwd_pipe": "bwd_pipe", "k_wgrad<PBf16>": "wgrad_gemm", "k_ig_tail": "ig_tail_sun"}
+         "k_mlp_bwd<PBf16, false, true, false,": "bwd_chain_sun", "k_bwd_pipe": "bwd_pipe", "k_wgrad<PBf16>": "wgrad_gemm", "k_ig_tail": "ig_tail_sun", "k_enc_pair": "ig_tail_sun"}
 
 
 def short(name):
