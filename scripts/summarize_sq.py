@@ -9,7 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RT = os.environ.get("RT", "r05")
 SRC = os.path.join(REPO, "gpurun_out", "sq_" + RT)
 TAG = sys.argv[1] if len(sys.argv) > 1 else RT + "_b"
-KEEP = ("k_mlp_fwd", "k_mlp_bwd", "k_bwd_pipe", "k_wgrad", "k_ig_tail")
+KEEP = ("k_mlp_fwd", "k_mlp_bwd", "k_bwd_pipe", "k_wgrad", "k_ig_tail", "k_enc_pair")
 
 
 def load(sub):
