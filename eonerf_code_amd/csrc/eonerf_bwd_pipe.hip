@@ -332,7 +332,8 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTRL ? Cnt<CTRL, ORDB>::TOP_CTRL : Cnt<CTRL, ORDB>::TOP) : "memory");
         const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-        if (CTRL) {
+        const bool half = (EO_PABL & 512) && (k & 1);      // (diagnostic: barrier and flag work on every second step only -- results are garbage, timing only)
+        if (CTRL && !half) {
             // the flag values polled in the previous step have landed behind the counted wait
             asm volatile("" : "+v"(ph), "+v"(pt));
             if (k >= 1) {
@@ -341,7 +342,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 if (RING_OUT && vt > known_tail) known_tail = vt;
             }
             // make sure (slow path only when the pipeline is starved or backed up) that what this step needs exists
-            const int need_in = (k + DEPTH < n_k ? k + DEPTH : n_k - 1) + 1;       // tiles that must be published for this step's DMA
+            const int need_in = (k + DEPTH + ((EO_PABL & 512) ? 1 : 0) < n_k ? k + DEPTH + ((EO_PABL & 512) ? 1 : 0) : n_k - 1) + 1;       // tiles that must be published for this step's DMA
             const int need_out = k + 1 - RING_USE;                                   // tiles the consumer must have released
             const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
             const bool slow = (S.has_in && known_head < need_in) || (RING_OUT && known_tail < need_out);
@@ -349,13 +350,13 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             if (RING_OUT && known_tail < need_out) wait_for(f_out + 32, need_out, known_tail);
             if (stamp && slow) { t_slow += __builtin_amdgcn_s_memtime() - ts0; ++n_slow; }
         }
-        asm volatile("s_barrier" ::: "memory");
+        if (!half) asm volatile("s_barrier" ::: "memory");
         const unsigned long long tt2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
         if (stamp) { t_top += tt1 - tt0; t_bar += tt2 - tt1; }
         // a watchdog fired in this workgroup: every wave leaves behind the same barrier (looked at every 8th step: the LDS round trip
         // costs every wave ~100 cycles, and a stalled pipeline is in no hurry)
         if ((k & 7) == 0 && ctl[0]) return;
-        if (CTRL) {
+        if (CTRL && !half) {
             // behind the barrier: every wave's share of step k has landed (=> the ring slot of tile k can go back) and every
             // wave's stores of step k-2 are complete (=> tiles 0..k-2 are published)
             if (lane == 0) {
