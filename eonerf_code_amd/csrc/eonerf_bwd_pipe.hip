@@ -306,9 +306,10 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     };
 
     // diagnostics: cycle sums of this wave (total loop, slow-path spins, counted wait, barrier, dX phase, dW phase)
-    const bool stamp = EO_PIPE_STAMPS && a.stamps != nullptr;      // (build switch: scripts/stamp.sh; the production loop carries no stamp code)
-    unsigned long long t_slow = 0, t_top = 0, t_bar = 0, t_dx = 0, t_is = 0, t_dw = 0, n_slow = 0;
-    const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    const bool stamp = EO_PIPE_STAMPS && a.stamps != nullptr;
+    auto clk = [&]() -> uint32_t { return (uint32_t)__builtin_amdgcn_s_memtime(); };      // (32-bit sums: 64-bit ones cost the stamp build spilled registers, and a spill's reload drains the DMA queue)      // (build switch: scripts/stamp.sh; the production loop carries no stamp code)
+    uint32_t t_slow = 0, t_top = 0, t_bar = 0, t_dx = 0, t_is = 0, t_dw = 0, n_slow = 0;
+    const uint32_t t_begin = stamp ? clk() : 0;
 
     // ---- prologue: first DEPTH steps in flight ----
     if (CTRL && S.has_in) wait_for(f_in, n_k < DEPTH ? n_k : DEPTH, known_head);
@@ -329,9 +330,9 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         uint8_t* slot = smem + slot_of(k) * SLOT_B;
         if (CTRL && S.done && (k & 15) == 15 && lane == 0) __hip_atomic_store(S.done, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- top of the step ----
-        const unsigned long long tt0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        const uint32_t tt0 = stamp ? clk() : 0;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTRL ? Cnt<CTRL, ORDB>::TOP_CTRL : Cnt<CTRL, ORDB>::TOP) : "memory");
-        const unsigned long long tt1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        const uint32_t tt1 = stamp ? clk() : 0;
         const bool half = (EO_PABL & 512) && (k & 1);      // (diagnostic: barrier and flag work on every second step only -- results are garbage, timing only)
         if (CTRL && !half) {
             // the flag values polled in the previous step have landed behind the counted wait
@@ -344,14 +345,14 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
             // make sure (slow path only when the pipeline is starved or backed up) that what this step needs exists
             const int need_in = (k + DEPTH + ((EO_PABL & 512) ? 1 : 0) < n_k ? k + DEPTH + ((EO_PABL & 512) ? 1 : 0) : n_k - 1) + 1;       // tiles that must be published for this step's DMA
             const int need_out = k + 1 - RING_USE;                                   // tiles the consumer must have released
-            const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const uint32_t ts0 = stamp ? clk() : 0;
             const bool slow = (S.has_in && known_head < need_in) || (RING_OUT && known_tail < need_out);
             if (S.has_in && known_head < need_in) wait_for(f_in, need_in, known_head);
             if (RING_OUT && known_tail < need_out) wait_for(f_out + 32, need_out, known_tail);
-            if (stamp && slow) { t_slow += __builtin_amdgcn_s_memtime() - ts0; ++n_slow; }
+            if (stamp && slow) { t_slow += clk() - ts0; ++n_slow; }
         }
         if (!half) asm volatile("s_barrier" ::: "memory");
-        const unsigned long long tt2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        const uint32_t tt2 = stamp ? clk() : 0;
         if (stamp) { t_top += tt1 - tt0; t_bar += tt2 - tt1; }
         // a watchdog fired in this workgroup: every wave leaves behind the same barrier (looked at every 8th step: the LDS round trip
         // costs every wave ~100 cycles, and a stalled pipeline is in no hurry)
@@ -533,34 +534,34 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         };
         if (!ORDB) {
             if (!(EO_PABL & 256)) phase_dx();
-            const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const uint32_t tt3 = stamp ? clk() : 0;
             dw_prefetch();
             issue_block();
-            const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const uint32_t tt4 = stamp ? clk() : 0;
             if (!(EO_PABL & 128)) phase_dw(dma);
-            if (stamp) { t_dx += tt3 - tt2; t_is += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
+            if (stamp) { t_dx += tt3 - tt2; t_is += tt4 - tt3; t_dw += clk() - tt4; }
         } else {
 #if EO_PIPE_ORDB == 1      // DMA issue -> dX -> dW (measured 0.8 % slower, round 3)
             issue_block();
-            const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const uint32_t tt3 = stamp ? clk() : 0;
             phase_dx();
-            const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const uint32_t tt4 = stamp ? clk() : 0;
             phase_dw(dma);
-            if (stamp) { t_is += tt3 - tt2; t_dx += tt4 - tt3; t_dw += __builtin_amdgcn_s_memtime() - tt4; }
+            if (stamp) { t_is += tt3 - tt2; t_dx += tt4 - tt3; t_dw += clk() - tt4; }
 #else
             dw_prefetch();
             issue_block();
-            const unsigned long long tt3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const uint32_t tt3 = stamp ? clk() : 0;
             if (!(EO_PABL & 128)) phase_dw(dma);
-            const unsigned long long tt4 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+            const uint32_t tt4 = stamp ? clk() : 0;
             if (!(EO_PABL & 256)) phase_dx();
-            if (stamp) { t_is += tt3 - tt2; t_dw += tt4 - tt3; t_dx += __builtin_amdgcn_s_memtime() - tt4; }
+            if (stamp) { t_is += tt3 - tt2; t_dw += tt4 - tt3; t_dx += clk() - tt4; }
 #endif
         }
     }
     if (stamp && lane == 0) {
         unsigned long long* o = a.stamps + ((size_t)(S.pipe * a.n_stages + S.st) * 8 + wave) * 16;
-        o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_slow; o[2] = t_top; o[3] = t_bar; o[4] = t_dx; o[5] = n_slow; o[6] = (unsigned long long)n_k;
+        o[0] = clk() - t_begin; o[1] = t_slow; o[2] = t_top; o[3] = t_bar; o[4] = t_dx; o[5] = n_slow; o[6] = (unsigned long long)n_k;
         o[7] = 0; o[8] = t_is; o[9] = 0; o[10] = t_dw;
     }
     if (CTRL && lane == 0 && S.done) __hip_atomic_store(S.done, n_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
