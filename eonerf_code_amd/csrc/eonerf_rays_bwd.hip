@@ -466,23 +466,26 @@ __global__ __launch_bounds__(256) void k_emb_grad(EmbGradArgs a) {
 //      virtual blocks of the bottleneck products (a pair never straddles the kernel's two branches: 256 is even) and of the embedding
 //      gradient.  n_bott / n_emb / n_amb = 0: that part is absent. ----
 struct StepTailArgs { BottWgradArgs bott; EmbGradArgs emb; AmbientBwdArgs amb; EncPartReduceArgs enc; int n_amb, n_bott, n_emb, n_enc; };
-// the shadow pass' encoding products (eonerf_enc_pair.hip): sum of the workgroups' partials, one thread per element -> the gradient buffer
-// (every other writer of these elements -- the GEMM launch's camera jobs -- has finished: plain read-modify-write)
+// the shadow pass' encoding products (eonerf_enc_pair.hip): sum of the workgroups' partials -> the gradient buffer.  Element e of
+// [source 2][row 256][slot 64] | [256] bias sums is summed by ENC_RED_SPLIT threads (one per residue class of the partial's index), 8 loads in
+// flight each, and added atomically (4 adders per address: no contention to speak of; every other writer of these elements -- the GEMM
+// launch's camera jobs -- has finished).  One thread per element over all 256 partials was 64 dependent HBM round trips: 23 us, the longest role of the launch
+constexpr int ENC_RED_SPLIT = 4;
 EO_DEV void enc_part_reduce_body(const EncPartReduceArgs& a, int vblk, int tid) {
-    const int e = vblk * 512 + tid;      // element of [source 2][row 256][slot 64] | [256] bias sums
+    const int q = vblk % ENC_RED_SPLIT, e = (vblk / ENC_RED_SPLIT) * 512 + tid;
     if (e >= ENC_PART_F) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 4 <= a.n_wg; w += 4) {
-        s0 += a.part[(size_t)w * ENC_PART_F + e]; s1 += a.part[(size_t)(w + 1) * ENC_PART_F + e];
-        s2 += a.part[(size_t)(w + 2) * ENC_PART_F + e]; s3 += a.part[(size_t)(w + 3) * ENC_PART_F + e];
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = q;
+    for (; w + 7 * ENC_RED_SPLIT < a.n_wg; w += 8 * ENC_RED_SPLIT) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += a.part[(size_t)(w + u * ENC_RED_SPLIT) * ENC_PART_F + e];
     }
-    for (; w < a.n_wg; ++w) s0 += a.part[(size_t)w * ENC_PART_F + e];
-    const float sum = (s0 + s1) + (s2 + s3);
-    if (e >= 2 * 256 * 64) { a.db0[e - 2 * 256 * 64] += sum; return; }
+    for (; w < a.n_wg; w += ENC_RED_SPLIT) s[0] += a.part[(size_t)w * ENC_PART_F + e];
+    const float sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    if (e >= 2 * 256 * 64) { atomicAdd(a.db0 + (e - 2 * 256 * 64), sum); return; }
     const int src = e >> 14, row = (e >> 6) & 255, cm = a.col_map[e & 63];
     if (cm < 0) return;
-    if (src == 0) a.dw0[row * 63 + cm] += sum; else a.dw5s[row * 319 + cm] += sum;
+    if (src == 0) atomicAdd(a.dw0 + row * 63 + cm, sum); else atomicAdd(a.dw5s + row * 319 + cm, sum);
 }
 __global__ __launch_bounds__(512) void k_step_tail(StepTailArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[AMB_LDS_F];
@@ -646,7 +649,7 @@ hipError_t eo_launch_step_tail(const BottWgradArgs* bott, const EmbGradArgs* emb
         const int want = (amb->n_rays + AMB_BATCH - 1) / AMB_BATCH;
         a.n_amb = want < 32 ? want : 32;                                      // (block count: see eo_launch_ambient_bwd)
     }
-    if (enc) { a.enc = *enc; a.n_enc = (ENC_PART_F + 511) / 512; }
+    if (enc) { a.enc = *enc; a.n_enc = (ENC_PART_F + 511) / 512 * ENC_RED_SPLIT; }
     const int grid = a.n_amb + a.n_enc + a.n_bott / 2 + (a.n_emb + 1) / 2;
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(k_step_tail, dim3(grid), dim3(512), 0, st, a);
