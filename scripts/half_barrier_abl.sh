@@ -6,7 +6,7 @@ HC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-f
 REST=$(ls build/*.o | grep -v -E 'eonerf_bwd_pipe.o|_v[0-9a-z]*\.o|pipe_abl')
 mk() { $HC $2 -c eonerf_bwd_pipe.hip -o build/pipe_vh$1.o && $HC -shared -o build/libeonerf_vh$1.so $REST build/pipe_vh$1.o || exit 1; }
 mk half "-DEO_PABL=512"
-mk free "-DEO_PABL=1024"
+mk spread "-DEO_PIPE_SPREAD=1"
 cd ../..
 B=$PWD/eonerf_code_amd/csrc/build
 run() {
@@ -21,5 +21,5 @@ except Exception as e:
 for i in 1 2; do
   run "base                      " ""
   run "barrier every 2nd step    " $B/libeonerf_vhhalf.so
-  run "barrier every 32nd step   " $B/libeonerf_vhfree.so
+  run "DMA pieces between MFMAs  " $B/libeonerf_vhspread.so
 done
