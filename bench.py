@@ -431,6 +431,33 @@ def main():
             rec["kernels"] = kernels
             rec["kernel_ms_sum"] = sum(k["avg_ms"] for k in kernels.values())
             rec["kernel_flop_sum"] = sum(k["algorithmic_flop_per_launch"] for k in kernels.values())
+        # ---- N > 1, untimed: the SAME steps with the other order of the gradient exchange (one all-reduce behind the backward against the
+        #      early block from the library's event), alternating -- the A/B only a multi-GPU box can run; nothing of it is in `value` ----
+        if trainer._exchanges() and wl == workloads[0] and os.environ.get("EONERF_BENCH_EXCHANGE_AB", "1") != "0":
+            default_buckets, ab, nxt = trainer.buckets, {"one_bucket": [], "two_buckets": []}, first_step + args.warmup + 2 * args.steps
+            try:
+                for _ in range(2):
+                    for nb in (1, 2):
+                        trainer.set_exchange_buckets(nb)
+                        for i in range(5):
+                            one_step(nxt + i, epoch_idx)
+                        barrier()
+                        t0 = time.perf_counter()
+                        for i in range(args.steps):
+                            one_step(nxt + 5 + i, epoch_idx)
+                        barrier()
+                        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                        if world > 1:
+                            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                        ab["one_bucket" if nb == 1 else "two_buckets"].append(t.item() / args.steps * 1e3)
+                        nxt += 5 + args.steps
+                ab["note"] = f"{args.steps}-step blocks behind the timed region, alternating, max over ranks; the timed steps ran with {default_buckets} bucket(s)"
+            except Exception as e:      # (a diagnostic: it must not cost the line)
+                ab = {"error": repr(e)}
+            finally:
+                trainer.set_exchange_buckets(default_buckets)
+            trainer.check_device_status()
+            rec["exchange_ab_ms_per_step"] = ab
         # ---- whole-step MFMA fraction: FLOPs per step / step time / peak ----
         dead = MAC_TRANSIENT if wl == "rgb" else 0
         pruned = 2.0 * ((MAC_FWD + MAC_BWD - dead + MAC_WGRAD - dead) * n_cam + 3 * MAC_DENS * n_sun)
@@ -510,6 +537,7 @@ def main():
                      "exchange_buckets": 2 if trainer._early_event is not None else 1,
                      "exchange_early_floats": trainer.n_early if trainer._early_event is not None else 0,
                      "exchange_comm_cus": trainer.comm_cus if trainer._early_event is not None else 0,
+                     "exchange_ab_ms_per_step": recs[workloads[0]].get("exchange_ab_ms_per_step"),
                      "exchange_hidden_us": recs[workloads[0]].get("exchange_hidden_us"),
                      "exchange_early_us": recs[workloads[0]].get("exchange_early_us"),
                      "rehearsal_one_gpu_gloo": rehearsal}

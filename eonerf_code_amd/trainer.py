@@ -91,10 +91,7 @@ class FusedTrainer:
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.zsteps = _zsteps(dev, self.n_samples_per_ray)
         self.n_early = int(self.L.eonerf_grad_early_floats(self.ctx))
-        if self._exchanges() and self.buckets == 2 and not self.exchange_async:
-            self._early_event = torch.cuda.Event()
-            self._early_event.record()          # (the HIP event exists from its first record on)
-            _lib.check(self.L.eonerf_set_exchange_event(self.ctx, C.c_void_p(self._early_event.cuda_event), self.comm_cus))
+        self.set_exchange_buckets(self.buckets)
         if self.world > 1:     # identical replicas: broadcast rank 0's parameters once (train_eonerf.py has one process)
             torch.distributed.broadcast(self.flat, src=0)
             _lib.check(self.L.eonerf_set_weights(self.ctx, _ptr(self.flat), _stream()))
@@ -202,6 +199,20 @@ class FusedTrainer:
                                                      _ptr(self.d_flat), _ptr(ws), ws.numel(), st))
         if self.keep_message or self._exchanges():     # the flag travels with the message; alone, k_adam reads the status word itself
             _lib.check(self.L.eonerf_grad_seal(self.ctx, _ptr(self.d_flat), st))
+
+    def set_exchange_buckets(self, n):
+        """2: the early block of the gradient message (eonerf_grad_early_floats) is all-reduced from the event the library records behind the
+        camera pass' pipelined backward, the rest behind the backward's last kernel; 1: one all-reduce there.  Takes effect with the next
+        step; only a trainer that exchanges on its side stream has two buckets (EONERF_EXCHANGE_BUCKETS sets the default)."""
+        self.buckets = 2 if n == 2 else 1
+        if self.buckets == 2 and self._exchanges() and not self.exchange_async:
+            if self._early_event is None:
+                self._early_event = torch.cuda.Event()
+                self._early_event.record()          # (the HIP event exists from its first record on)
+            _lib.check(self.L.eonerf_set_exchange_event(self.ctx, C.c_void_p(self._early_event.cuda_event), self.comm_cus))
+        else:
+            _lib.check(self.L.eonerf_set_exchange_event(self.ctx, None, 0))
+            self._early_event = None
 
     def _exchanges(self):
         return self.dist_on and (self.world > 1 or os.environ.get("EONERF_FORCE_ALLREDUCE") == "1")

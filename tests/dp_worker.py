@@ -11,6 +11,7 @@ MODE "fault": as "pipe", but rank 1's context was created with EONERF_PIPE_FAULT
 watchdog fires, the fault flag travels in the gradient message, NEITHER rank applies the update, and BOTH ranks raise.
 MODE "nccl1": world size 1 over RCCL (backend "nccl") with EONERF_FORCE_ALLREDUCE=1: the pipelined step with the collective on the
 side stream, in the process group the 8-GPU job uses.
+MODE "pretog": as "pre0", with FusedTrainer.set_exchange_buckets switching between one and two buckets from step to step.
 MODE "pre1" / "pre0": world size 1 over RCCL with the forced all-reduce, deterministic backward, production (Philox) noise: five steps over
 a small ray table with / without the next batch's sampler enqueued under the exchange (FusedTrainer.step(next_batch=...)); the test compares
 the two runs' parameters bit for bit.
@@ -28,8 +29,8 @@ def main():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     import torch
-    backend = "nccl" if mode in ("nccl1", "pre0", "pre1") else "gloo"
-    if mode in ("pre0", "pre1", "pipedet"):
+    backend = "nccl" if mode in ("nccl1", "pre0", "pre1", "pretog") else "gloo"
+    if mode in ("pre0", "pre1", "pretog", "pipedet"):
         os.environ["EONERF_DETERMINISTIC"] = "1"                      # read when the context is created
     if backend == "nccl":
         os.environ["EONERF_FORCE_ALLREDUCE"] = "1"
@@ -44,7 +45,7 @@ def main():
     from eonerf_code_amd.radiance_fields.eonerf import EONerfMLP, _ptr, _stream
     from eonerf_code_amd.trainer import FusedTrainer, rank_slice
     n_img, R = 4, 256
-    piped = mode in ("pipe", "pipedet", "fault", "nccl1", "pre0", "pre1")
+    piped = mode in ("pipe", "pipedet", "fault", "nccl1", "pre0", "pre1", "pretog")
     # rank 1 starts from DIFFERENT weights: the trainer's initial broadcast must make the replicas identical
     sd = orc.random_state_dict(n_img, seed=91 + 7 * rank, bias_scale=0.05)
     sd["sigma_layer.output_layer.bias"] += 1.0
@@ -64,7 +65,7 @@ def main():
         L = _lib.lib()
         _lib.check(L.eonerf_render_forward(tr.ctx, None, None, None, None, None, None, None, R, _lib.F_TRAIN, None, None, None, 0, _stream()))
         raise SystemExit("unreachable: the C ABI accepted null pointers")
-    if mode in ("pre0", "pre1"):
+    if mode in ("pre0", "pre1", "pretog"):
         from eonerf_code_amd.trainer import RayTable
         tr.set_noise_seed(5)
         big = orc.synthetic_batch(R * 5, n_img, seed=93)
@@ -74,6 +75,8 @@ def main():
         tr._presample = lambda *a: (calls.append(1), orig(*a))[1]
         losses = []
         for i in range(5):
+            if mode == "pretog":                                   # the exchange's order switched between steps (bench.py's untimed A/B does that)
+                tr.set_exchange_buckets(1 + i % 2)
             r, im, px = table.batch(0, i, R)
             nxt = (table.batch(0, i + 1, R)[0], table.batch(0, i + 1, R)[1], epoch) if (mode == "pre1" and i < 4) else None
             losses.append(tr.step(r, im, px, epoch, next_batch=nxt))

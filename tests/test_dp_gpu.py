@@ -220,6 +220,10 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["presample_under_exchange"] is True and 0 < d["step_tail_presample_us"] < d["step_tail_us"]      # the next step's sampler inside it
     assert line["conditioning_steps"] >= 20 and len(line["step_ms"]["all"]) == 2
     assert len(line["conditioning_first_block_step_ms"]) == 10 and min(line["conditioning_first_block_step_ms"]) > 0
+    # the untimed A/B of the exchange's two orders behind the timed region: two blocks each, the default order restored afterwards
+    ab = d["exchange_ab_ms_per_step"]
+    assert "error" not in ab and len(ab["one_bucket"]) == 2 and len(ab["two_buckets"]) == 2 and min(ab["one_bucket"] + ab["two_buckets"]) > 0
+    assert d["exchange_buckets"] == 2
 
 
 def test_launcher_two_ranks_keeps_replicas_identical(tmp_path):
@@ -254,6 +258,13 @@ def test_two_bucket_exchange_is_bit_identical_to_the_single_all_reduce(tmp_path,
         codes, outs = _run_job(d1, "pre0", 3, world=1)
         assert codes == [0], outs
         res[buckets] = (r0, torch.load(d1 / "pre0.pt"))
+    # ... and the order may change from step to step (FusedTrainer.set_exchange_buckets: what bench.py's untimed A/B at N > 1 does)
+    dt = tmp_path / "rccl_toggle"
+    dt.mkdir()
+    codes, outs = _run_job(dt, "pretog", 3, world=1)
+    assert codes == [0], outs
+    tog = torch.load(dt / "pretog.pt")
+    assert torch.equal(tog["flat"], res["2"][1]["flat"]) and tog["loss"] == res["2"][1]["loss"]
     (g1, n1), (g2, n2) = res["1"], res["2"]
     assert torch.equal(g1["d_flat"], g2["d_flat"]) and torch.equal(g1["flat"], g2["flat"]) and g1["loss"] == g2["loss"]
     assert torch.equal(n1["flat"], n2["flat"]) and n1["loss"] == n2["loss"]
