@@ -92,12 +92,22 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 #ifndef EO_PIPE_DMA03
 #define EO_PIPE_DMA03 0
 #endif
+// EO_PIPE_DDEPTH (round 6): prefetch distance of the dY image alone (the X image keeps EO_PIPE_DEPTH).  The dY tile of a step comes from the
+// producer stage through the Infinity Cache, the X image from HBM; what a stage fetches DDEPTH steps ahead its producer must have published
+// DDEPTH steps ahead, so every step of dY distance is a step of lag on each of the six edges of a pipeline (fill + drain: 9 % of a launch).
+// 2 since round 6: -1.4 % / -1.0 % on the camera / shadow-pass launch against 3 (profiles/r06_dy_prefetch_distance.txt).  A distance of 1
+// (dY pieces issued first thing in a step, one step to land) compiles to 139 spilled registers in every variant tried.
+#ifndef EO_PIPE_DDEPTH
+#define EO_PIPE_DDEPTH (EO_PIPE_DMA03 || EO_PIPE_SPREAD || EO_COR ? EO_PIPE_DEPTH : 2)
+#endif
 #ifndef EO_PIPE_STAMPS      // 1: the per-phase cycle stamps of scripts/pipe_stamps.py are compiled in (scripts/stamp.sh builds that library)
 #define EO_PIPE_STAMPS 0
 #endif
 constexpr int NSLOT = EO_COR ? 3 : 4, DEPTH = EO_PIPE_DEPTH;      // LDS ring slots; steps of DMA in flight ahead of the one being multiplied (<= NSLOT - 1)
 EO_DEV int slot_of(int k) { return (NSLOT & (NSLOT - 1)) == 0 ? (k & (NSLOT - 1)) : k % NSLOT; }
 static_assert(DEPTH >= 2 && DEPTH <= NSLOT - 1, "prefetch distance");
+constexpr int DDEPTH = EO_PIPE_DDEPTH;
+static_assert(DDEPTH >= 2 && DDEPTH <= DEPTH && (DDEPTH == DEPTH || (!EO_PIPE_DMA03 && !EO_PIPE_SPREAD && !EO_COR)), "dY prefetch distance");
 constexpr uint32_t RING_USE = EO_RING_USE;
 static_assert(RING_USE <= PIPE_RING && (RING_USE & (RING_USE - 1)) == 0, "ring slots in use");
 constexpr int N_DMA = 4;                          // LDS-DMA pieces per wave per step: 2 dY + 2 X
@@ -120,7 +130,10 @@ template <bool CTRL, bool ORDB> struct Cnt {
     // First order: the pieces of step s-2 and all of step s-1 are younger than those stores; second order: only step s-1
     // (first order, DMA side: the pieces of step s were issued DEPTH steps ago behind that step's stores, so DEPTH - 1 whole steps are
     //  younger; the stricter of the two conditions counts)
-    static constexpr int TOP = ORDB ? C : ((DEPTH - 1) * C < ND + C ? (DEPTH - 1) * C : ND + C);
+    // (DDEPTH < DEPTH, first order: the dY pieces of step s were issued DDEPTH steps ago behind that step's stores, in front of its X pieces:
+    //  with DDEPTH = 2 the X pieces of step s-2 and all of step s-1 are younger -- ND / 2 + C; the stores of step s-2 are older.  Second order
+    //  and control wave: unchanged, the dY pieces of step s are older than what their conditions already wait for)
+    static constexpr int TOP = ORDB ? C : (DDEPTH < DEPTH ? ND / 2 + (DDEPTH - 1) * C : ((DEPTH - 1) * C < ND + C ? (DEPTH - 1) * C : ND + C));
     // control wave (first order): tighter -- only the payload stores and the pieces of step s-1 stay outstanding, so the flag polls
     // of step s-1 are in (one step of latency instead of two: every stage then runs one step closer behind its producer)
     static constexpr int TOP_CTRL = NST + ND;
@@ -217,13 +230,14 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     // output: the next stage's ring (MODE 0) or this pipeline's tiles of a linear buffer
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(MODE == 0 ? ring_out : grd_blk + (size_t)S.pipe * IMG_B, 0, -1, 0x00020000);
     const int v_dy = lane * 16 + (2 * wave) * 1024;               // this wave's two pieces of a 16-KiB unit-order image (loads and stores)
-    struct Dma { uint32_t so_d, so_x; uint8_t* slot; bool on; };
-    auto dma_prep = [&](int k) {
+    struct Dma { uint32_t so_d, so_x; uint8_t *slot, *slot_d; bool on; };      // slot: of the X image's step, slot_d: of the dY image's step
+    auto dma_prep = [&](int kx, int kd) {
         Dma d;
-        d.on = !((EO_PABL & 8) && k >= DEPTH);
-        d.slot = smem + slot_of(k) * SLOT_B;
-        d.so_d = ((uint32_t)k & d_mask) * d_mul;
-        d.so_x = (uint32_t)k * lin_stride;
+        d.on = !((EO_PABL & 8) && kx >= DEPTH);
+        d.slot = smem + slot_of(kx) * SLOT_B;
+        d.slot_d = smem + slot_of(kd) * SLOT_B;
+        d.so_d = ((uint32_t)kd & d_mask) * d_mul;
+        d.so_x = (uint32_t)kx * lin_stride;
         return d;
     };
     auto dma_piece = [&](const Dma& d, int i4) {      // i4: compile-time constant at every call site; pieces 4..7: the partner wave's share
@@ -233,23 +247,23 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
         if (i < 2) {
             // handed over inside this launch: sc1; the first stage's input comes from an earlier launch: streaming
             if (EO_XCD_NT && S.has_in && S.local)      // (experiment build: streaming instead of sc1 loads on an intra-XCD edge)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot_d + (2 * wave + i) * 1024), 16,
                                                          v_dy + i * 1024, d.so_d, 0, AUX_NT);
             else if (S.has_in)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot_d + (2 * wave + i) * 1024), 16,
                                                          v_dy + i * 1024, d.so_d, 0, AUX_SC1);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot + (2 * wave + i) * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(d.slot_d + (2 * wave + i) * 1024), 16,
                                                          v_dy + i * 1024, d.so_d, 0, AUX_NT);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(d.slot + IMG_B + (32 * wave + 16 * (i - 2)) * SEG_B), 16,
                                                      x_voff_[i - 2], d.so_x, 0, AUX_NT);
         }
     };
-    auto issue = [&](int k) {      // all pieces in one block (prologue)
-        const Dma d = dma_prep(k);
+    auto issue = [&](int k, bool with_dy) {      // all pieces in one block (prologue)
+        const Dma d = dma_prep(k, k);
 #pragma unroll
-        for (int i = 0; i < NDW; ++i) dma_piece(d, i);
+        for (int i = 0; i < NDW; ++i) if (with_dy || (i & 3) >= 2) dma_piece(d, i);
     };
 
     // ---- per-lane LDS read offsets ----
@@ -312,15 +326,15 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
     const uint32_t t_begin = stamp ? clk() : 0;
 
     // ---- prologue: first DEPTH steps in flight ----
-    if (CTRL && S.has_in) wait_for(f_in, n_k < DEPTH ? n_k : DEPTH, known_head);
+    if (CTRL && S.has_in) wait_for(f_in, n_k < DDEPTH ? n_k : DDEPTH, known_head);
     if (CTRL) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (ctl[0]) return;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) issue(d < n_k ? d : n_k - 1);
+    for (int d = 0; d < DEPTH; ++d) issue(d < n_k ? d : n_k - 1, d < DDEPTH);      // (X images DEPTH steps ahead, dY images DDEPTH)
     // step 0 only: nothing but the other two prologue steps is younger than its pieces (the loop's counted wait assumes the
     // steady state, where two whole steps of stores and pieces are)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * NDW) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * NDW - (DEPTH - DDEPTH) * (NDW / 2)) : "memory");
 
     if (CTRL && lane == 0 && S.done) __hip_atomic_store(S.done + 1, n_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if EO_PABL      // (diagnostic variants: a shorter body must not be unrolled into a different register budget)
@@ -343,7 +357,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
                 if (RING_OUT && vt > known_tail) known_tail = vt;
             }
             // make sure (slow path only when the pipeline is starved or backed up) that what this step needs exists
-            const int need_in = (k + DEPTH + ((EO_PABL & 512) ? 1 : 0) < n_k ? k + DEPTH + ((EO_PABL & 512) ? 1 : 0) : n_k - 1) + 1;       // tiles that must be published for this step's DMA
+            const int need_in = (k + DDEPTH + ((EO_PABL & 512) ? 1 : 0) < n_k ? k + DDEPTH + ((EO_PABL & 512) ? 1 : 0) : n_k - 1) + 1;       // tiles that must be published for this step's DMA
             const int need_out = k + 1 - RING_USE;                                   // tiles the consumer must have released
             const uint32_t ts0 = stamp ? clk() : 0;
             const bool slow = (S.has_in && known_head < need_in) || (RING_OUT && known_tail < need_out);
@@ -525,7 +539,7 @@ EO_DEV void run_stage(const BwdPipeArgs& a, const Stage& S, uint8_t* smem, int t
 #endif
         };
         const int k_next = k + DEPTH < n_k ? k + DEPTH : n_k - 1;       // refill: into the slot step k-1 used (free behind this step's barrier)
-        const Dma dma = dma_prep(k_next);
+        const Dma dma = dma_prep(k_next, k + DDEPTH < n_k ? k + DDEPTH : n_k - 1);      // (dY image: DDEPTH steps ahead, into the dY half of THAT step's slot)
         auto issue_block = [&]() {
 #if !EO_PIPE_SPREAD
 #pragma unroll
