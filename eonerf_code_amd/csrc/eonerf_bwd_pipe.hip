@@ -96,7 +96,7 @@ constexpr int SLOT_B = 2 * IMG_B;                 // dY image | X image
 // producer stage through the Infinity Cache, the X image from HBM; what a stage fetches DDEPTH steps ahead its producer must have published
 // DDEPTH steps ahead, so every step of dY distance is a step of lag on each of the six edges of a pipeline (fill + drain: 9 % of a launch).
 // 2 since round 6: -1.4 % / -1.0 % on the camera / shadow-pass launch against 3 (profiles/r06_dy_prefetch_distance.txt).  A distance of 1
-// (dY pieces issued first thing in a step, one step to land) compiles to 139 spilled registers in every variant tried.
+// (the DMA block issued first thing in a step, one step to land; profiles/r06_dy_distance_1_experiment.patch) is 5 % SLOWER: the load does not make it.
 #ifndef EO_PIPE_DDEPTH
 #define EO_PIPE_DDEPTH (EO_PIPE_DMA03 || EO_PIPE_SPREAD || EO_COR ? EO_PIPE_DEPTH : 2)
 #endif

@@ -5,6 +5,7 @@ HC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-f
 REST=$(ls build/*.o | grep -v -E 'eonerf_bwd_pipe.o|_v[0-9a-z]*\.o|pipe_abl')
 mk() { $HC $2 -c eonerf_bwd_pipe.hip -o build/pipe_vd$1.o && $HC -shared -o build/libeonerf_vd$1.so $REST build/pipe_vd$1.o || exit 1; }
 mk 3 "-DEO_PIPE_DDEPTH=3"
+
 mk 2 "-DEO_PIPE_DDEPTH=2"
 cd ../..
 B=$PWD/eonerf_code_amd/csrc/build
@@ -21,4 +22,5 @@ except Exception as e:
 for i in 1 2 3; do
   run "dY 3 steps ahead (as the X image) " $B/libeonerf_vd3.so
   run "dY 2 steps ahead                  " $B/libeonerf_vd2.so
+
 done
